@@ -1,0 +1,160 @@
+"""Synthetic scenes for parity tests and benchmarks (no dataset is available offline).
+
+Recipes follow SURVEY.md section 8(d) / BASELINE.md section 2:
+
+* ``scene_frustum`` ("S1M" at P=1_000_000, 1600x1063): camera at the origin looking +z,
+  Gaussians fill the frustum with 10 % overscan, sigma_px ~ LogNormal(ln 3, 0.5), per-axis
+  anisotropy LogNormal(0, 0.5), random unit quaternions, opacity ~ U[0.1, 0.9], SH degree 3.
+* ``scene_lego_like`` ("S10k", BASELINE config 1): P=10_000 points U[-1.3,1.3]^3 (as
+  reference scene/dataset_readers.py:241-247), camera on a radius-4.03 sphere looking at the
+  origin, camera_angle_x = 0.6911 (focal ~555.6 px at 400 px), white background.
+
+Camera matrices use the reference conventions (utils/graphics_utils.py:38-71,
+scene/cameras.py:50-58): ``viewmatrix`` = world-to-view, TRANSPOSED (row-vector
+convention); ``projmatrix`` = viewmatrix @ projection^T.
+
+Everything is generated on the CPU with numpy (seeded) and returned as a dict of float32
+numpy arrays + python scalars; callers move them to the device.
+"""
+import math
+import numpy as np
+
+
+def projection_matrix(znear, zfar, fovx, fovy):
+    """utils/graphics_utils.py:51-71 (returns the NON-transposed 4x4, float32)."""
+    tan_y = math.tan(fovy / 2)
+    tan_x = math.tan(fovx / 2)
+    top = tan_y * znear
+    bottom = -top
+    right = tan_x * znear
+    left = -right
+    P = np.zeros((4, 4), dtype=np.float32)
+    z_sign = 1.0
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = z_sign
+    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def camera(W, H, fovx, fovy, R=None, T=None, znear=0.01, zfar=100.0):
+    """R: camera-to-world rotation (3x3), T: world-to-view translation, as scene/cameras.py."""
+    if R is None:
+        R = np.eye(3)
+    if T is None:
+        T = np.zeros(3)
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = R.transpose()
+    Rt[:3, 3] = T
+    Rt[3, 3] = 1.0
+    w2v = np.float32(Rt)                      # getWorld2View2 with zero translate, scale 1
+    view_t = np.ascontiguousarray(w2v.T)      # .transpose(0,1)
+    proj_t = np.ascontiguousarray(projection_matrix(znear, zfar, fovx, fovy).T)
+    full = (view_t @ proj_t).astype(np.float32)
+    campos = np.linalg.inv(view_t.astype(np.float64))[3, :3].astype(np.float32)
+    return dict(W=int(W), H=int(H), tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5),
+                viewmatrix=view_t, projmatrix=np.ascontiguousarray(full), campos=campos)
+
+
+def _rand_sh(rng, P, deg_max=3):
+    M = (deg_max + 1) ** 2
+    sh = np.empty((P, M, 3), dtype=np.float32)
+    sh[:, 0] = rng.normal(0.0, 0.5, (P, 3))
+    if M > 1:
+        sh[:, 1:] = rng.normal(0.0, 0.1, (P, M - 1, 3))
+    return sh
+
+
+def scene_frustum(P, W=1600, H=1063, focal=1200.0, seed=0, sh_degree=3, sigma_px=3.0,
+                  zmin=1.0, zmax=20.0, bg=(0.0, 0.0, 0.0), kernel_size=0.0):
+    rng = np.random.default_rng(seed)
+    tanx = (W / 2) / focal
+    tany = (H / 2) / focal
+    fovx = 2 * math.atan(tanx)
+    fovy = 2 * math.atan(tany)
+    cam = camera(W, H, fovx, fovy)
+    z = rng.uniform(zmin, zmax, P)
+    x = z * tanx * rng.uniform(-1.1, 1.1, P)
+    y = z * tany * rng.uniform(-1.1, 1.1, P)
+    means = np.stack([x, y, z], 1).astype(np.float32)
+    base = np.exp(rng.normal(math.log(sigma_px), 0.5, P))          # pixels
+    aniso = np.exp(rng.normal(0.0, 0.5, (P, 3)))
+    scales = (base[:, None] * z[:, None] / focal * aniso).astype(np.float32)
+    q = rng.normal(0, 1, (P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rot = q.astype(np.float32)
+    opac = rng.uniform(0.1, 0.9, (P, 1)).astype(np.float32)
+    sh = _rand_sh(rng, P)
+    scene = dict(cam)
+    scene.update(means3D=means, scales=scales, rotations=rot, opacities=opac, shs=sh,
+                 sh_degree=int(sh_degree), bg=np.asarray(bg, dtype=np.float32), kernel_size=float(kernel_size),
+                 scale_modifier=1.0, subpixel_offset=np.zeros((H, W, 2), dtype=np.float32))
+    return scene
+
+
+def scene_lego_like(P=10_000, W=400, H=400, seed=0, sh_degree=3, bg=(1.0, 1.0, 1.0), kernel_size=0.0):
+    rng = np.random.default_rng(seed)
+    fovx = 0.6911112070083618
+    focal = W / (2 * math.tan(fovx / 2))
+    fovy = 2 * math.atan(H / (2 * focal))
+    # camera on a sphere of radius 4.03 looking at the origin
+    theta, phi = 0.7, 0.5
+    c = 4.03 * np.array([math.cos(phi) * math.sin(theta), -math.sin(phi), math.cos(phi) * math.cos(theta)])
+    fwd = -c / np.linalg.norm(c)
+    up = np.array([0.0, -1.0, 0.0])
+    right = np.cross(up, fwd); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R_c2w = np.stack([right, down, fwd], 1)       # columns = camera axes in world
+    T = -R_c2w.T @ c
+    cam = camera(W, H, fovx, fovy, R=R_c2w, T=T)
+    means = rng.uniform(-1.3, 1.3, (P, 3)).astype(np.float32)
+    # isotropic scale from the mean distance to the 3 nearest neighbours (simple_knn.distCUDA2 stand-in)
+    try:
+        from scipy.spatial import cKDTree
+        d, _ = cKDTree(means).query(means, k=4)
+        dist2 = np.maximum((d[:, 1:] ** 2).mean(1), 1e-7)
+    except Exception:  # pragma: no cover
+        dist2 = np.full(P, 0.01)
+    scales = np.repeat(np.sqrt(dist2)[:, None], 3, 1).astype(np.float32)
+    rot = np.zeros((P, 4), dtype=np.float32); rot[:, 0] = 1.0
+    opac = np.full((P, 1), 0.1, dtype=np.float32)
+    sh = _rand_sh(rng, P)
+    scene = dict(cam)
+    scene.update(means3D=means, scales=scales, rotations=rot, opacities=opac, shs=sh,
+                 sh_degree=int(sh_degree), bg=np.asarray(bg, dtype=np.float32), kernel_size=float(kernel_size),
+                 scale_modifier=1.0, subpixel_offset=np.zeros((H, W, 2), dtype=np.float32))
+    return scene
+
+
+def tetra_points(scene, per_gaussian=9):
+    """Query points as GaussianModel.get_tetra_points builds them (scene/gaussian_model.py:432-463):
+    8 corners of the 3-sigma box + the centre, without the frustum mask."""
+    means, scales, rot = scene["means3D"], scene["scales"] * 3.0, scene["rotations"]
+    r, x, y, z = rot[:, 0], rot[:, 1], rot[:, 2], rot[:, 3]
+    R = np.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float32)
+    v = corners[None] * scales[:, None, :]                 # (P,8,3)
+    v = np.einsum("pij,pkj->pki", R, v) + means[:, None, :]
+    pts = np.concatenate([v.reshape(-1, 3), means], 0).astype(np.float32)
+    return np.ascontiguousarray(pts)
+
+
+def freudenthal_tets(nx, ny, nz):
+    """6-tets-per-cube grid tetrahedralisation (CGAL Delaunay stand-in). Returns (verts (V,3) f32, tets (T,4) i64)."""
+    xs, ys, zs = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+    verts = np.stack([xs, ys, zs], -1).reshape(-1, 3).astype(np.float32)
+
+    def vid(i, j, k):
+        return (i * (ny + 1) + j) * (nz + 1) + k
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    ii, jj, kk = ii.ravel(), jj.ravel(), kk.ravel()
+    c = [vid(ii + a, jj + b, kk + d) for a in (0, 1) for b in (0, 1) for d in (0, 1)]  # index = a*4+b*2+d
+    perms = [(4, 6), (4, 5), (2, 6), (2, 3), (1, 5), (1, 3)]
+    tets = [np.stack([c[0], c[p], c[q], c[7]], 1) for p, q in perms]
+    return verts, np.ascontiguousarray(np.concatenate(tets, 0).astype(np.int64))

@@ -1,0 +1,199 @@
+/*
+ * gof_hip.h -- C ABI of libgof_hip.so, the MI355X (gfx950) Gaussian-opacity-field rasterizer.
+ *
+ * This is the drop-in boundary for the reference's torch/pybind11 module
+ * `diff_gaussian_rasterization._C`
+ * (reference: submodules/diff-gaussian-rasterization/ext.cpp:15-20).  Each entry point
+ * below names the reference interface it replaces.  Conventions:
+ *
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in the signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream).
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - all buffers are caller-owned; the library keeps no state between calls except a
+ *     thread-local error string.
+ *   - an absent optional input is NULL ("compute it"), exactly like the empty-tensor
+ *     convention of the reference binding (rasterize_points.cu:98-118 passes the
+ *     null data_ptr of `torch.Tensor([])`).
+ *   - return value: 0 = ok, negative = error (see GOF_E_*); gof_last_error() gives text.
+ *     No C++ exception crosses the boundary.
+ *   - all launches are asynchronous on `stream` except where a function is documented
+ *     as synchronising (gof_forward_prepare returns num_rendered to the host, like the
+ *     reference's cudaMemcpy at rasterizer_impl.cu:336).
+ *
+ * Workspaces are opaque byte buffers whose sizes come from the gof_*_bytes() queries
+ * (they replace GeometryState/ImageState/BinningState/PointState chunk sub-allocation,
+ * rasterizer_impl.cu:188-243, rasterizer_impl.h:22-88).  The Python layer keeps them as
+ * uint8 tensors so ctx.save_for_backward works as in the reference.
+ */
+#ifndef GOF_HIP_H_INCLUDED
+#define GOF_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOF_OK            0
+#define GOF_E_INVALID    -1   /* bad argument (shape / NULL / size)                  */
+#define GOF_E_WORKSPACE  -2   /* a workspace is smaller than the gof_*_bytes() query  */
+#define GOF_E_DEVICE     -3   /* HIP runtime error (text in gof_last_error())         */
+#define GOF_E_PREFILTER  -4   /* prefiltered=1 but a Gaussian was culled (debug only) */
+
+#define GOF_OUTPUT_CHANNELS 9  /* auxiliary.h:21-24: rgb 0-2, normal 3-5, depth 6, alpha 7, distortion 8 */
+
+/* All rasterization inputs of one view.  Mirrors the argument list of
+ * RasterizeGaussiansCUDA (rasterize_points.cu:36-58) / Rasterizer::forward
+ * (rasterizer_impl.cu:247-272).  POD, passed by pointer (host memory). */
+typedef struct GofRasterArgs {
+    int32_t P;              /* number of Gaussians                                            */
+    int32_t D;              /* active SH degree (0..3)                                        */
+    int32_t M;              /* SH coefficients per Gaussian in `shs` (sh.size(1)); 0 if none   */
+    int32_t W, H;           /* image width / height                                           */
+    float tan_fovx, tan_fovy;
+    float kernel_size;      /* 2D mip low-pass added to the screen covariance                 */
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t debug;          /* 1: synchronise + check after every launch (CHECK_CUDA, auxiliary.h:204-211) */
+    const float* background;            /* [3]                                   */
+    const float* means3D;               /* [P,3]                                 */
+    const float* shs;                   /* [P,M,3] or NULL                       */
+    const float* colors_precomp;        /* [P,3]   or NULL                       */
+    const float* opacities;             /* [P]                                   */
+    const float* scales;                /* [P,3]   or NULL (then cov3D_precomp AND view2gaussian_precomp) */
+    const float* rotations;             /* [P,4]   or NULL, used as given (NOT re-normalised, forward.cu:138) */
+    const float* cov3D_precomp;         /* [P,6]   or NULL                       */
+    const float* view2gaussian_precomp; /* [P,10]  or NULL                       */
+    const float* viewmatrix;            /* [16] row-vector convention (transposed), scene/cameras.py:56-58 */
+    const float* projmatrix;            /* [16] full projection, same convention */
+    const float* campos;                /* [3]                                   */
+    const float* subpixel_offset;       /* [H,W,2]; must be valid (integrateCUDA reads it, forward.cu:845) */
+} GofRasterArgs;
+
+/* ---- error text ----------------------------------------------------------------------- */
+const char* gof_last_error(void);
+/* library / ABI version, bumped when a signature or workspace layout changes */
+int gof_abi_version(void);
+
+/* ---- workspace size queries (host only) ------------------------------------------------ */
+/* replaces required<GeometryState>(P)  (rasterizer_impl.cu:277, 188-204) */
+size_t gof_geom_bytes(int32_t P);
+/* replaces required<ImageState>(W*H)   (rasterizer_impl.cu:290, 218-228) */
+size_t gof_image_bytes(int32_t W, int32_t H);
+/* replaces required<BinningState>(num_rendered) (rasterizer_impl.cu:338, 230-243) */
+size_t gof_binning_bytes(uint32_t num_rendered, int32_t W, int32_t H);
+/* replaces required<PointState>(PN)    (rasterizer_impl.cu:676, 206-216) */
+size_t gof_point_bytes(int32_t PN);
+
+/* ---- forward (replaces _C.rasterize_gaussians, rasterize_points.cu:36-122) ------------- */
+/* Stage 1: preprocess (forward.cu:283-404) + inclusive scan of tiles_touched
+ * (rasterizer_impl.cu:332) + read-back of the instance count (rasterizer_impl.cu:336).
+ * Writes radii[P] (int32; 0 for culled Gaussians) and *num_rendered_host.  SYNCHRONISES
+ * `stream` (one 4-byte D2H, as the reference). */
+int gof_forward_prepare(const GofRasterArgs* args,
+                        void* geom_ws, size_t geom_bytes,
+                        void* image_ws, size_t image_bytes,
+                        int32_t* radii,
+                        uint32_t* num_rendered_host,
+                        void* stream);
+/* Stage 2: duplicateWithKeys + stable radix sort + identifyTileRanges + forward blend
+ * (rasterizer_impl.cu:344-402, forward.cu:409-612).  out_color is [9,H,W]; every pixel of
+ * every channel is written. */
+int gof_forward_render(const GofRasterArgs* args,
+                       uint32_t num_rendered,
+                       void* geom_ws, size_t geom_bytes,
+                       void* binning_ws, size_t binning_bytes,
+                       void* image_ws, size_t image_bytes,
+                       float* out_color,
+                       void* stream);
+
+/* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
+/* dL_dout is [9,H,W].  All gradient outputs are fully written by the call (the library
+ * zero-fills them itself; the reference binding allocates them with torch::zeros,
+ * rasterize_points.cu:161-170).  dL_dcov3D [P,6] is all zero in the reference (its producer
+ * kernel is disabled, backward.cu:991-1007) and is zero-filled here if non-NULL. */
+int gof_backward(const GofRasterArgs* args,
+                 uint32_t num_rendered,
+                 const int32_t* radii,
+                 const void* geom_ws, size_t geom_bytes,
+                 const void* binning_ws, size_t binning_bytes,
+                 const void* image_ws, size_t image_bytes,
+                 const float* dL_dout,
+                 float* dL_dmeans2D,        /* [P,3] x,y signed; z = sum |.| (backward.cu:905-909) */
+                 float* dL_dcolors,         /* [P,3]  */
+                 float* dL_dopacity,        /* [P]    */
+                 float* dL_dmeans3D,        /* [P,3]  */
+                 float* dL_dcov3D,          /* [P,6] or NULL */
+                 float* dL_dsh,             /* [P,M,3] or NULL when M == 0 */
+                 float* dL_dscales,         /* [P,3]  */
+                 float* dL_drotations,      /* [P,4]  */
+                 float* dL_dview2gaussian,  /* [P,10] */
+                 void* stream);
+
+/* ---- integrate (replaces _C.integrate_gaussians_to_points, rasterize_points.cu:234-343) - */
+/* Stage 1 for the query points: preprocessPointsCUDA + scan + count read-back
+ * (forward.cu:722-766, rasterizer_impl.cu:681-702).  SYNCHRONISES `stream`. */
+int gof_integrate_prepare_points(const GofRasterArgs* args,
+                                 int32_t PN, const float* points3D,
+                                 void* point_ws, size_t point_bytes,
+                                 uint32_t* num_integrated_host,
+                                 void* stream);
+/* Stage 2: Gaussian binning (as gof_forward_render, without the blend), point binning
+ * (createWithKeys + sort + ranges, rasterizer_impl.cu:720-752) and integrateCUDA
+ * (forward.cu:803-1218).  out_alpha_integrated [PN] must be pre-filled with 1 and
+ * out_color_integrated [PN,3] with 0 by the caller (rasterize_points.cu:277-278);
+ * only points that project inside the image are written.  out_color is [9,H,W]; it must
+ * be zero-filled by the caller (channels 3-5 are never written, forward.cu:1002-1007). */
+int gof_integrate_run(const GofRasterArgs* args,
+                      uint32_t num_rendered,
+                      int32_t PN, uint32_t num_integrated,
+                      void* geom_ws, size_t geom_bytes,
+                      void* binning_ws, size_t binning_bytes,
+                      void* image_ws, size_t image_bytes,
+                      void* point_ws, size_t point_bytes,
+                      void* point_binning_ws, size_t point_binning_bytes,
+                      float* out_color,
+                      float* out_alpha_integrated,
+                      float* out_color_integrated,
+                      void* stream);
+
+/* ---- mark_visible (replaces _C.mark_visible, rasterize_points.cu:213-232) -------------- */
+int gof_mark_visible(int32_t P, const float* means3D,
+                     const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* ---- marching tetrahedra (replaces utils/tetmesh.py:47-138, pure torch in the reference) */
+/* Phase 1: classify tets, collect the unique crossing edges (sorted ascending by
+ * (min vertex, max vertex), the order torch.unique(dim=0) produces, tetmesh.py:110) and
+ * count faces.  SYNCHRONISES `stream`; returns the counts to the host. */
+size_t gof_mtets_ws_bytes(int64_t num_tets);
+int gof_mtets_count(int64_t num_verts, int64_t num_tets,
+                    const int64_t* tets /* [Tt,4] */, const float* sdf /* [V] */,
+                    void* ws, size_t ws_bytes,
+                    int64_t* num_edges_host, int64_t* num_faces_host, void* stream);
+/* Phase 2: emit edge end-point ids [E,2] (int64), end-point positions [E,2,3], end-point
+ * sdf [E,2], end-point scales [E,2] and faces [F,3] (int64) in the reference's order
+ * (all 1-triangle tets first, then the 2-triangle tets; tetmesh.py:126-136). */
+int gof_mtets_emit(int64_t num_verts, int64_t num_tets,
+                   const int64_t* tets, const float* vertices /* [V,3] */,
+                   const float* sdf, const float* scales /* [V] */,
+                   const void* ws, size_t ws_bytes,
+                   int64_t num_edges, int64_t num_faces,
+                   int64_t* edge_ids, float* edge_pos, float* edge_sdf, float* edge_scales,
+                   int64_t* faces, void* stream);
+
+/* ---- introspection for tests / benchmarks (no reference counterpart) ------------------- */
+/* Copies one named intermediate array out of the workspaces into `dst` (device memory).
+ * names: "depths" f32[P], "means2D" f32[P,2], "conic_opacity" f32[P,4], "rgb" f32[P,3],
+ * "view2gaussian" f32[P,10], "tiles_touched" u32[P], "point_offsets" u32[P],
+ * "clamped" u8[P,3], "point_list" u32[R], "point_list_keys" u64[R], "ranges" u32[T,2],
+ * "final_T" f32[4,H,W], "n_contrib" u32[2,H,W].  Returns the element count or <0. */
+int64_t gof_debug_fetch(const char* name, const GofRasterArgs* args, uint32_t num_rendered,
+                        const void* geom_ws, const void* binning_ws, const void* image_ws,
+                        void* dst, size_t dst_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOF_HIP_H_INCLUDED */
