@@ -1,0 +1,460 @@
+// api.hip -- host orchestration and the extern "C" boundary of libgof_hip.so (include/gof_hip.h).
+//
+// Replaces CudaRasterizer::Rasterizer::{forward,backward,integrate,markVisible}
+// (reference rasterizer_impl.cu:247-405, 409-526, 530-792, 174-186) and the torch binding's
+// buffer management (reference rasterize_points.cu:28-122).  No torch types, no global state,
+// every launch on the caller's stream.
+#include "gof_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace gof {
+
+// ---- kernels / helpers defined in the other translation units -------------------------------------
+
+__global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                               const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                               const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
+                               float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
+                               int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out,
+                               uint32_t* tiles_touched, uint8_t* clamped, uint32_t* flags);
+__global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
+                               const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
+                               const float* dL_dv2g, const float* dL_dcolor, float* dL_dmeans, float* dL_dsh,
+                               float* dL_dscales, float* dL_drots);
+__global__ void preprocess_points(int PN, const float* points3D, Cam cam, int W, int H, float focal_x, float focal_y,
+                                  float2* points2D, float* depths, uint32_t* tiles_touched);
+__global__ void mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present);
+
+uint32_t higher_msb(uint32_t n);
+size_t scan_temp_bytes(size_t n);
+hipError_t scan_tiles(void* tmp, size_t tmp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t stream);
+size_t sort_temp_bytes(size_t n);
+hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                      uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream);
+__global__ void duplicate_keys(int P, const SplatRec* rec, const float* depths, const uint32_t* offsets, uint64_t* keys,
+                               uint32_t* vals, const int32_t* radii, uint32_t gx, uint32_t gy);
+__global__ void point_keys(int PN, const float2* points2D, const float* depths, const uint32_t* offsets,
+                           const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals, uint32_t gx, uint32_t gy);
+__global__ void tile_ranges(uint32_t L, const uint64_t* keys, uint2* ranges);
+
+__global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, int W, int H,
+                              float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
+                              float* out_color, uint32_t gx, uint32_t ntiles);
+__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic,
+                               int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
+                               const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity,
+                               float* dL_dcolors, float* dL_dv2g, uint32_t gx, uint32_t ntiles);
+__global__ void integrate_kernel(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
+                                 const uint32_t* point_list, const SplatRec* rec, int W, int H, float focal_x, float focal_y,
+                                 const float2* points2D, const float* point_depths, float* point_T, const float* bg_color, float* final_T,
+                                 uint32_t* n_contrib, float* out_color, float* out_alpha_integrated,
+                                 float* out_color_integrated, uint32_t gx, uint32_t ntiles);
+
+// ---- error text --------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+void set_error(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+// ---- workspace layouts -------------------------------------------------------------------------------
+template <typename T>
+static inline void carve(char*& p, T*& ptr, size_t count)
+{
+    p = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(p)));
+    ptr = reinterpret_cast<T*>(p);
+    p += count * sizeof(T);
+}
+
+size_t geom_layout(int32_t P, void* base, GeomWs* out)
+{
+    GeomWs g;
+    char* p = static_cast<char*>(base);
+    const size_t n = (size_t)P;
+    carve(p, g.rec, n);
+    carve(p, g.conic, n);
+    carve(p, g.depths, n);
+    carve(p, g.tiles_touched, n);
+    carve(p, g.point_offsets, n);
+    carve(p, g.clamped, n);
+    carve(p, g.flags, 4);
+    g.scan_tmp_bytes = scan_temp_bytes(n);
+    char* st; carve(p, st, g.scan_tmp_bytes); g.scan_tmp = st;
+    if (out) *out = g;
+    return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+}
+size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
+{
+    ImageWs im;
+    char* p = static_cast<char*>(base);
+    const size_t N = (size_t)W * H;
+    const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    carve(p, im.ranges, T);
+    carve(p, im.point_ranges, T);
+    carve(p, im.final_T, 4 * N);
+    carve(p, im.n_contrib, 2 * N);
+    if (out) *out = im;
+    return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+}
+size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out)
+{
+    (void)W; (void)H;
+    BinWs b;
+    char* p = static_cast<char*>(base);
+    const size_t n = (size_t)R;
+    carve(p, b.vals, n);            // sorted point_list first: the only part the backward reads
+    carve(p, b.keys, n);
+    carve(p, b.keys_unsorted, n);
+    carve(p, b.vals_unsorted, n);
+    b.sort_tmp_bytes = sort_temp_bytes(n);
+    char* st; carve(p, st, b.sort_tmp_bytes); b.sort_tmp = st;
+    if (out) *out = b;
+    return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+}
+size_t point_layout(int32_t PN, void* base, PointWs* out)
+{
+    PointWs w;
+    char* p = static_cast<char*>(base);
+    const size_t n = (size_t)PN;
+    carve(p, w.depths, n);
+    carve(p, w.points2D, n);
+    carve(p, w.tiles_touched, n);
+    carve(p, w.point_offsets, n);
+    carve(p, w.T_state, n);
+    w.scan_tmp_bytes = scan_temp_bytes(n);
+    char* st; carve(p, st, w.scan_tmp_bytes); w.scan_tmp = st;
+    if (out) *out = w;
+    return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+}
+
+static inline void* aligned_base(const void* ws) { return reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(ws))); }
+
+static int validate(const GofRasterArgs* a)
+{
+    if (!a) { set_error("args is NULL"); return GOF_E_INVALID; }
+    if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad P/W/H (%d, %d, %d)", a->P, a->W, a->H); return GOF_E_INVALID; }
+    if (a->P == 0) return GOF_OK;
+    if (!a->means3D || !a->opacities || !a->background || !a->viewmatrix || !a->projmatrix || !a->campos) {
+        set_error("a required pointer is NULL"); return GOF_E_INVALID; }
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return GOF_E_INVALID; }
+    if (a->shs && (a->M <= 0 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M)) { set_error("SH degree %d does not fit M=%d", a->D, a->M); return GOF_E_INVALID; }
+    if (!a->cov3D_precomp && (!a->scales || !a->rotations)) { set_error("scales/rotations or cov3D_precomp required"); return GOF_E_INVALID; }
+    if (!a->view2gaussian_precomp && (!a->scales || !a->rotations)) { set_error("scales/rotations required to compute view2gaussian"); return GOF_E_INVALID; }
+    return GOF_OK;
+}
+
+struct Dims { uint32_t gx, gy, ntiles; float focal_x, focal_y; };
+static inline Dims dims_of(const GofRasterArgs* a)
+{
+    Dims d;
+    d.gx = (a->W + TILE_X - 1) / TILE_X;
+    d.gy = (a->H + TILE_Y - 1) / TILE_Y;
+    d.ntiles = d.gx * d.gy;
+    d.focal_y = a->H / (2.0f * a->tan_fovy);    // rasterizer_impl.cu:274-275
+    d.focal_x = a->W / (2.0f * a->tan_fovx);
+    return d;
+}
+
+// K4..K6 shared by forward and integrate
+static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, const GeomWs& g, const BinWs& b, const ImageWs& im,
+                         const int32_t* radii, hipStream_t stream)
+{
+    const int dbg = a->debug;
+    if (R > 0) {
+        hipLaunchKernelGGL(duplicate_keys, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.rec, g.depths, g.point_offsets,
+                           b.keys_unsorted, b.vals_unsorted, radii, d.gx, d.gy);
+        GOF_LAUNCH_CHECK(stream, dbg);
+        const int end_bit = 32 + (int)higher_msb(d.ntiles);
+        GOF_HIP_CHECK(sort_pairs(b.sort_tmp, b.sort_tmp_bytes, b.keys_unsorted, b.keys, b.vals_unsorted, b.vals, R, end_bit, stream));
+        GOF_LAUNCH_CHECK(stream, dbg);
+    }
+    GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
+    if (R > 0) {
+        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.keys, im.ranges);
+        GOF_LAUNCH_CHECK(stream, dbg);
+    }
+    return GOF_OK;
+}
+
+} // namespace gof
+
+using namespace gof;
+
+extern "C" {
+
+const char* gof_last_error(void) { return g_error.c_str(); }
+int gof_abi_version(void) { return 1; }
+
+size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
+size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
+size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H) { return bin_layout(R, W, H, nullptr, nullptr) + ALIGN; }
+size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
+
+int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
+                        int32_t* radii, uint32_t* num_rendered_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!num_rendered_host) { set_error("num_rendered_host is NULL"); return GOF_E_INVALID; }
+    *num_rendered_host = 0;
+    if (a->P == 0) return GOF_OK;
+    if (!radii || !geom_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P)) { set_error("geometry workspace too small: %zu < %zu", geom_bytes, gof_geom_bytes(a->P)); return GOF_E_WORKSPACE; }
+    if (image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace too small"); return GOF_E_WORKSPACE; }
+    GeomWs g;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    const Dims d = dims_of(a);
+    const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
+
+    GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
+                       a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
+                       a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
+                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic,
+                       g.tiles_touched, g.clamped, g.flags);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    GOF_HIP_CHECK(scan_tiles(g.scan_tmp, g.scan_tmp_bytes, g.tiles_touched, g.point_offsets, (size_t)a->P, stream));
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
+    uint32_t host_words[2] = { 0, 0 };
+    GOF_HIP_CHECK(hipMemcpyAsync(&host_words[0], g.point_offsets + a->P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (a->prefiltered)
+        GOF_HIP_CHECK(hipMemcpyAsync(&host_words[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    *num_rendered_host = host_words[0];
+    if (a->prefiltered && host_words[1]) {
+        set_error("Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:193-197
+        return GOF_E_PREFILTER;
+    }
+    return GOF_OK;
+}
+
+int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii, void* geom_ws, size_t geom_bytes,
+                       void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes, float* out_color, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!out_color) { set_error("out_color is NULL"); return GOF_E_INVALID; }
+    const size_t HW = (size_t)a->W * a->H;
+    if (a->P == 0) {   // rasterize_points.cu:68, 85: zero image, nothing rendered
+        GOF_HIP_CHECK(hipMemsetAsync(out_color, 0, GOF_OUTPUT_CHANNELS * HW * sizeof(float), stream));
+        return GOF_OK;
+    }
+    if (!radii || !geom_ws || !binning_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
+        set_error("workspace too small (geom %zu, image %zu, binning %zu)", geom_bytes, image_bytes, binning_bytes); return GOF_E_WORKSPACE; }
+    GeomWs g; ImageWs im; BinWs b;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    image_layout(a->W, a->H, aligned_base(image_ws), &im);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    const Dims d = dims_of(a);
+    rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                       im.ranges, b.vals, g.rec, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.final_T, im.n_contrib, out_color, d.gx, d.ntiles);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    return GOF_OK;
+}
+
+size_t gof_backward_scratch_bytes(int32_t P) { (void)P; return 0; }
+
+int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes,
+                 const void* binning_ws, size_t binning_bytes, const void* image_ws, size_t image_bytes, const float* dL_dout,
+                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian, void* scratch, size_t scratch_bytes, void* stream_)
+{
+    (void)scratch; (void)scratch_bytes;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (a->P == 0) return GOF_OK;
+    if (!dL_dout || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_dview2gaussian ||
+        (a->M > 0 && a->shs && !dL_dsh) || !radii) { set_error("a gradient / radii pointer is NULL"); return GOF_E_INVALID; }
+    if (!a->scales || !a->rotations) { set_error("backward needs scales and rotations (backward.cu:621)"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
+        set_error("workspace too small"); return GOF_E_WORKSPACE; }
+    GeomWs g; ImageWs im; BinWs b;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    image_layout(a->W, a->H, aligned_base(image_ws), &im);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    const Dims d = dims_of(a);
+    const size_t P = (size_t)a->P;
+    // torch::zeros of the binding (rasterize_points.cu:161-170): required, K8 accumulates and K9 skips culled Gaussians
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans2D, 0, 3 * P * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dcolors, 0, 3 * P * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans3D, 0, 3 * P * sizeof(float), stream));
+    if (dL_dcov3D) GOF_HIP_CHECK(hipMemsetAsync(dL_dcov3D, 0, 6 * P * sizeof(float), stream));
+    if (dL_dsh && a->M > 0) GOF_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, 3 * P * (size_t)a->M * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dscales, 0, 3 * P * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_drotations, 0, 4 * P * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dview2gaussian, 0, 10 * P * sizeof(float), stream));
+
+    if (R > 0) {
+        hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                           im.ranges, b.vals, g.rec, g.conic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
+                           im.n_contrib, dL_dout, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian, d.gx, d.ntiles);
+        GOF_LAUNCH_CHECK(stream, a->debug);
+    }
+    const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
+    hipLaunchKernelGGL(preprocess_bwd, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
+                       g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales,
+                       dL_drotations);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    return GOF_OK;
+}
+
+int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float* points3D, void* point_ws, size_t point_bytes,
+                                 uint32_t* num_integrated_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!num_integrated_host) { set_error("num_integrated_host is NULL"); return GOF_E_INVALID; }
+    *num_integrated_host = 0;
+    if (PN <= 0) return GOF_OK;
+    if (!points3D || !point_ws) { set_error("points3D / workspace is NULL"); return GOF_E_INVALID; }
+    if (point_bytes < gof_point_bytes(PN)) { set_error("point workspace too small"); return GOF_E_WORKSPACE; }
+    PointWs w;
+    point_layout(PN, aligned_base(point_ws), &w);
+    const Dims d = dims_of(a);
+    const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
+    hipLaunchKernelGGL(preprocess_points, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, points3D, cam, a->W, a->H,
+                       d.focal_x, d.focal_y, w.points2D, w.depths, w.tiles_touched);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    GOF_HIP_CHECK(scan_tiles(w.scan_tmp, w.scan_tmp_bytes, w.tiles_touched, w.point_offsets, (size_t)PN, stream));
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    uint32_t n = 0;
+    GOF_HIP_CHECK(hipMemcpyAsync(&n, w.point_offsets + PN - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    *num_integrated_host = n;
+    return GOF_OK;
+}
+
+int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, int32_t PN, uint32_t NI,
+                      void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                      void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                      float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (a->P == 0 || PN <= 0) return GOF_OK;     // rasterize_points.cu:301
+    if (!radii || !out_color || !out_alpha_integrated || !out_color_integrated) { set_error("an output / radii pointer is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H) ||
+        point_bytes < gof_point_bytes(PN) || point_binning_bytes < gof_binning_bytes(NI, a->W, a->H)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
+    GeomWs g; ImageWs im; BinWs b, pb; PointWs w;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    image_layout(a->W, a->H, aligned_base(image_ws), &im);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    point_layout(PN, aligned_base(point_ws), &w);
+    bin_layout(NI, a->W, a->H, aligned_base(point_binning_ws), &pb);
+    const Dims d = dims_of(a);
+    rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
+    if (rc) return rc;
+    // points: createWithKeys + sort + ranges (rasterizer_impl.cu:720-752)
+    if (NI > 0) {
+        hipLaunchKernelGGL(point_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.points2D, w.depths, w.point_offsets,
+                           w.tiles_touched, pb.keys_unsorted, pb.vals_unsorted, d.gx, d.gy);
+        GOF_LAUNCH_CHECK(stream, a->debug);
+        const int end_bit = 32 + (int)higher_msb(d.ntiles);
+        GOF_HIP_CHECK(sort_pairs(pb.sort_tmp, pb.sort_tmp_bytes, pb.keys_unsorted, pb.keys, pb.vals_unsorted, pb.vals, NI, end_bit, stream));
+        GOF_LAUNCH_CHECK(stream, a->debug);
+    }
+    GOF_HIP_CHECK(hipMemsetAsync(im.point_ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
+    if (NI > 0) {
+        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.keys, im.point_ranges);
+        GOF_LAUNCH_CHECK(stream, a->debug);
+    }
+    hipLaunchKernelGGL(integrate_kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                       im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, a->W, a->H, d.focal_x, d.focal_y, w.points2D, w.depths, w.T_state,
+                       a->background, im.final_T, im.n_contrib, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    return GOF_OK;
+}
+
+int gof_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0) { set_error("bad P"); return GOF_E_INVALID; }
+    if (P == 0) return GOF_OK;
+    if (!means3D || !viewmatrix || !projmatrix || !present) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    const Cam cam = { viewmatrix, projmatrix, nullptr };
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, cam, present);
+    GOF_LAUNCH_CHECK(stream, 0);
+    return GOF_OK;
+}
+
+// ---- introspection ------------------------------------------------------------------------------------
+} // extern "C"
+
+namespace gof {
+__global__ void unpack_rec(int P, const SplatRec* __restrict__ rec, const float4* __restrict__ conic, const uint8_t* __restrict__ clamped,
+                           int what, float* __restrict__ dstf, uint8_t* __restrict__ dstb)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float* f = rec[idx].f;
+    switch (what) {
+    case 0: dstf[2 * idx] = f[REC_XY]; dstf[2 * idx + 1] = f[REC_XY + 1]; break;                                  // means2D
+    case 1: { const float4 c = conic[idx]; dstf[4 * idx] = c.x; dstf[4 * idx + 1] = c.y; dstf[4 * idx + 2] = c.z; dstf[4 * idx + 3] = f[REC_W]; } break;
+    case 2: dstf[3 * idx] = f[REC_RGB]; dstf[3 * idx + 1] = f[REC_RGB + 1]; dstf[3 * idx + 2] = f[REC_RGB + 2]; break;
+    case 3: for (int i = 0; i < 10; i++) dstf[10 * idx + i] = f[i]; break;
+    case 4: { const uint8_t b = clamped[idx]; dstb[3 * idx] = b & 1; dstb[3 * idx + 1] = (b >> 1) & 1; dstb[3 * idx + 2] = (b >> 2) & 1; } break;
+    }
+}
+}
+
+extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uint32_t R, const void* geom_ws, const void* binning_ws,
+                                   const void* image_ws, void* dst, size_t dst_bytes, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!name || !a || !dst) { set_error("NULL argument"); return GOF_E_INVALID; }
+    GeomWs g; ImageWs im; BinWs b;
+    const size_t P = (size_t)a->P, HW = (size_t)a->W * a->H;
+    const Dims d = dims_of(a);
+    if (geom_ws) geom_layout(a->P, aligned_base(geom_ws), &g);
+    if (image_ws) image_layout(a->W, a->H, aligned_base(image_ws), &im);
+    if (binning_ws) bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    const void* src = nullptr; size_t bytes = 0; int64_t count = 0;
+    int unpack = -1; size_t per = 0; bool bytes_out = false;
+    const std::string n(name);
+    if (n == "depths" && geom_ws) { src = g.depths; count = P; bytes = P * 4; }
+    else if (n == "tiles_touched" && geom_ws) { src = g.tiles_touched; count = P; bytes = P * 4; }
+    else if (n == "point_offsets" && geom_ws) { src = g.point_offsets; count = P; bytes = P * 4; }
+    else if (n == "means2D" && geom_ws) { unpack = 0; per = 2; }
+    else if (n == "conic_opacity" && geom_ws) { unpack = 1; per = 4; }
+    else if (n == "rgb" && geom_ws) { unpack = 2; per = 3; }
+    else if (n == "view2gaussian" && geom_ws) { unpack = 3; per = 10; }
+    else if (n == "clamped" && geom_ws) { unpack = 4; per = 3; bytes_out = true; }
+    else if (n == "point_list" && binning_ws) { src = b.vals; count = R; bytes = (size_t)R * 4; }
+    else if (n == "point_list_keys" && binning_ws) { src = b.keys; count = R; bytes = (size_t)R * 8; }
+    else if (n == "ranges" && image_ws) { src = im.ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
+    else if (n == "point_ranges" && image_ws) { src = im.point_ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
+    else if (n == "final_T" && image_ws) { src = im.final_T; count = 4 * HW; bytes = 4 * HW * 4; }
+    else if (n == "n_contrib" && image_ws) { src = im.n_contrib; count = 2 * HW; bytes = 2 * HW * 4; }
+    else { set_error("unknown array '%s' (or its workspace is NULL)", name); return GOF_E_INVALID; }
+    if (unpack >= 0) {
+        count = (int64_t)(P * per);
+        bytes = P * per * (bytes_out ? 1 : 4);
+        if (dst_bytes < bytes) { set_error("dst too small"); return GOF_E_INVALID; }
+        if (P) hipLaunchKernelGGL(unpack_rec, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.rec, g.conic, g.clamped, unpack,
+                                  static_cast<float*>(dst), static_cast<uint8_t*>(dst));
+        if (hipGetLastError() != hipSuccess) { set_error("unpack launch failed"); return GOF_E_DEVICE; }
+        return count;
+    }
+    if (dst_bytes < bytes) { set_error("dst too small"); return GOF_E_INVALID; }
+    if (bytes && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) { set_error("copy failed"); return GOF_E_DEVICE; }
+    return count;
+}

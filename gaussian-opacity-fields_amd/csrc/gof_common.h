@@ -1,0 +1,275 @@
+// gof_common.h -- shared declarations of libgof_hip.so (gfx950 only).
+//
+// Workspace layouts, launch helpers and the small device math library used by every kernel.
+// All kernels are compiled with -ffp-contract=off: every multiply-add that is fused is
+// written as an explicit fmaf(), so the device evaluates exactly the fp32/fp64 operation
+// sequence documented in DESIGN.md ("arithmetic contract").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gof_hip.h"
+
+namespace gof {
+
+// ---- compile-time constants of the reference (config.h:15-17, auxiliary.h:21-34) -----------
+constexpr int TILE_X = 16;
+constexpr int TILE_Y = 16;
+constexpr int TILE_PIX = TILE_X * TILE_Y;     // 256 threads = 4 wave64
+constexpr int WAVE = 64;
+constexpr int MAX_NUM_CONTRIBUTORS = 256;
+constexpr int MAX_NUM_PROJECTED = 256;
+#define GOF_NEAR_PLANE 0.2
+#define GOF_FAR_PLANE 100.0
+
+// ---- per-Gaussian record staged by the blend kernels ---------------------------------------
+// One 64-byte line per Gaussian: everything the forward blend needs, so a tile-list entry is
+// gathered with four 16-byte loads from one aligned line.
+//   f[0..9]  view2gaussian (6 upper-triangle Sigma', 3 B, 1 C)      (forward.cu:268-277)
+//   f[10]    opacity * low-pass coefficient  (conic_opacity.w)       (forward.cu:389)
+//   f[11..13] rgb (SH colour, clamped at 0, or colors_precomp)       (forward.cu:378-381)
+//   f[14..15] means2D (pixel coordinates)                             (forward.cu:387)
+struct __attribute__((aligned(64))) SplatRec { float f[16]; };
+constexpr int REC_W = 10, REC_RGB = 11, REC_XY = 14;
+
+constexpr size_t ALIGN = 256;
+__host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return (x + a - 1) / a * a; }
+
+// Geometry workspace (replaces GeometryState, rasterizer_impl.h:29-45)
+struct GeomWs {
+    float* depths;          // [P]
+    SplatRec* rec;          // [P]
+    float4* conic;          // [P] conic.xyz (2D inverse covariance), w unused -- backward only
+    uint32_t* tiles_touched;// [P]
+    uint32_t* point_offsets;// [P] inclusive scan
+    uint8_t* clamped;       // [P] bit c set when colour channel c was clamped (forward.cu:67-69)
+    uint32_t* flags;        // [4] device-side status words (prefilter violation, ...)
+    void* scan_tmp; size_t scan_tmp_bytes;
+};
+// Image workspace (replaces ImageState, rasterizer_impl.h:57-67)
+struct ImageWs {
+    uint2* ranges;          // [T]
+    uint2* point_ranges;    // [T] integrate only
+    float* final_T;         // [4][H*W]  T, dist1, dist2, distortion (forward.cu:591-594)
+    uint32_t* n_contrib;    // [2][H*W]  last contributor, max contributor (forward.cu:596-597)
+};
+// Binning workspace (replaces BinningState, rasterizer_impl.h:69-79)
+struct BinWs {
+    uint64_t* keys_unsorted; uint64_t* keys;      // [R]
+    uint32_t* vals_unsorted; uint32_t* vals;      // [R]  vals = sorted point_list
+    void* sort_tmp; size_t sort_tmp_bytes;
+};
+// Point workspace (replaces PointState, rasterizer_impl.h:47-55)
+struct PointWs {
+    float* depths; float2* points2D; uint32_t* tiles_touched; uint32_t* point_offsets;
+    float* T_state;         // [PN] running transmittance of each query point (integrate pass 2)
+    void* scan_tmp; size_t scan_tmp_bytes;
+};
+
+// camera matrices stay in device memory (no host copy, no sync); the addresses are wave-uniform so
+// the compiler reads them with scalar loads.
+struct Cam {
+    const float* __restrict__ view;    // [16]
+    const float* __restrict__ proj;    // [16]
+    const float* __restrict__ campos;  // [3]
+};
+
+size_t geom_layout(int32_t P, void* base, GeomWs* out);
+size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out);
+size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out);
+size_t point_layout(int32_t PN, void* base, PointWs* out);
+
+// ---- error handling ----------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define GOF_HIP_CHECK(expr)                                                                   \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) {                                      \
+        gof::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        return GOF_E_DEVICE; } } while (0)
+// after a launch: always catch launch errors; in debug mode also synchronise (CHECK_CUDA semantics)
+#define GOF_LAUNCH_CHECK(stream, debug)                                                       \
+    do { GOF_HIP_CHECK(hipGetLastError());                                                    \
+         if (debug) GOF_HIP_CHECK(hipStreamSynchronize(stream)); } while (0)
+
+// XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (private L2s), so
+// give each XCD a contiguous band of tiles -- neighbouring tiles gather the same splat records.
+__device__ __forceinline__ uint32_t xcd_tile_id(uint32_t bid, uint32_t ntiles)
+{
+    constexpr uint32_t NXCD = 8;
+    const uint32_t per = (ntiles + NXCD - 1) / NXCD;
+    const uint32_t t = (bid % NXCD) * per + bid / NXCD;
+    return t;   // may be >= ntiles for the padded tail: caller checks
+}
+inline uint32_t xcd_padded_tiles(uint32_t ntiles) { return (ntiles + 7) / 8 * 8; }
+
+// ---- device math ---------------------------------------------------------------------------------
+// Deterministic fp32 exp (Cephes scheme): only IEEE mul / fma / rint / ldexp, <= 1 ulp on
+// [-87, 88].  The oracle evaluates the identical sequence, which makes per-pair alpha
+// bit-identical between host and device.
+__device__ __forceinline__ float gexpf(float x)
+{
+    x = (x < -87.0f) ? -87.0f : x;     // written as compares so NaN propagates exactly as on the host
+    x = (x > 88.0f) ? 88.0f : x;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float y = fmaf(p, r2, r);
+    y = y + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ V3 operator-(V3 a) { return V3{ -a.x, -a.y, -a.z }; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{ s * a.x, s * a.y, s * a.z }; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{ a.x * s, a.y * s, a.z * s }; }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return V3{ a.x / s, a.y / s, a.z / s }; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { const float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z; return tx + ty + tz; }
+
+// column-major 3x3 / 4x4 with the product order used by the reference's matrix library:
+// r[c][row] = (a[0][row]*b[c][0] + a[1][row]*b[c][1]) + a[2][row]*b[c][2]
+struct M3 { float m[3][3]; };
+struct M4 { float m[4][4]; };
+__device__ __forceinline__ M3 mk3(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2, float z2)
+{
+    M3 r; r.m[0][0] = x0; r.m[0][1] = y0; r.m[0][2] = z0; r.m[1][0] = x1; r.m[1][1] = y1; r.m[1][2] = z1; r.m[2][0] = x2; r.m[2][1] = y2; r.m[2][2] = z2; return r;
+}
+__device__ __forceinline__ M3 mul(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int row = 0; row < 3; row++)
+            r.m[c][row] = a.m[0][row] * b.m[c][0] + a.m[1][row] * b.m[c][1] + a.m[2][row] * b.m[c][2];
+    return r;
+}
+__device__ __forceinline__ V3 mul(const M3& m, V3 v)   // m * v
+{
+    return V3{ m.m[0][0] * v.x + m.m[1][0] * v.y + m.m[2][0] * v.z,
+               m.m[0][1] * v.x + m.m[1][1] * v.y + m.m[2][1] * v.z,
+               m.m[0][2] * v.x + m.m[1][2] * v.y + m.m[2][2] * v.z };
+}
+__device__ __forceinline__ V3 mul(V3 v, const M3& m)   // v * m
+{
+    return V3{ m.m[0][0] * v.x + m.m[0][1] * v.y + m.m[0][2] * v.z,
+               m.m[1][0] * v.x + m.m[1][1] * v.y + m.m[1][2] * v.z,
+               m.m[2][0] * v.x + m.m[2][1] * v.y + m.m[2][2] * v.z };
+}
+__device__ __forceinline__ M4 mul(const M4& a, const M4& b)
+{
+    M4 r;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int row = 0; row < 4; row++)
+            r.m[c][row] = a.m[0][row] * b.m[c][0] + a.m[1][row] * b.m[c][1] + a.m[2][row] * b.m[c][2] + a.m[3][row] * b.m[c][3];
+    return r;
+}
+__device__ __forceinline__ M3 transpose(const M3& m)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int row = 0; row < 3; row++) r.m[c][row] = m.m[row][c];
+    return r;
+}
+__device__ __forceinline__ M4 transpose(const M4& m)
+{
+    M4 r;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int row = 0; row < 4; row++) r.m[c][row] = m.m[row][c];
+    return r;
+}
+__device__ __forceinline__ M3 neg(const M3& m)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int row = 0; row < 3; row++) r.m[c][row] = -m.m[c][row];
+    return r;
+}
+__device__ __forceinline__ M3 add(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int row = 0; row < 3; row++) r.m[c][row] = a.m[c][row] + b.m[c][row];
+    return r;
+}
+__device__ __forceinline__ M3 outer(V3 c, V3 r)
+{
+    M3 m;
+    const float rr[3] = { r.x, r.y, r.z };
+#pragma unroll
+    for (int i = 0; i < 3; i++) { m.m[i][0] = c.x * rr[i]; m.m[i][1] = c.y * rr[i]; m.m[i][2] = c.z * rr[i]; }
+    return m;
+}
+
+// rotation matrix from a quaternion used as given (forward.cu:138-149)
+__device__ __forceinline__ M3 quat_to_R(float r, float x, float y, float z)
+{
+    return mk3(
+        1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+// tile rectangle of a splat (auxiliary.h:64-74)
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, uint32_t& minx, uint32_t& miny, uint32_t& maxx, uint32_t& maxy, uint32_t gx, uint32_t gy)
+{
+    minx = min(gx, (uint32_t)max(0, (int)((px - max_radius) / TILE_X)));
+    miny = min(gy, (uint32_t)max(0, (int)((py - max_radius) / TILE_Y)));
+    maxx = min(gx, (uint32_t)max(0, (int)((px + max_radius + TILE_X - 1) / TILE_X)));
+    maxy = min(gy, (uint32_t)max(0, (int)((py + max_radius + TILE_Y - 1) / TILE_Y)));
+}
+
+__device__ __forceinline__ V3 transform_point_4x3(V3 p, const float* __restrict__ m)
+{
+    return V3{ m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+               m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+               m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] };
+}
+
+// Everything that depends on a (pixel ray, splat) pair: forward.cu:499-533, backward.cu:771-804.
+struct PairEval {
+    float n0, n1, n2;      // un-normalised view-space normal Sigma' * ray
+    double AA, BB;
+    float t, G, alpha;
+    bool skip;
+};
+__device__ __forceinline__ void eval_pair(const float* __restrict__ v, float w, float rx, float ry, PairEval& p)
+{
+    p.n0 = v[0] * rx + v[1] * ry + v[2];
+    p.n1 = v[1] * rx + v[3] * ry + v[4];
+    p.n2 = v[2] * rx + v[4] * ry + v[5];
+    const float AAf = rx * p.n0 + ry * p.n1 + p.n2;
+    const float BBf = 2 * (v[6] * rx + v[7] * ry + v[8]);
+    p.AA = (double)AAf;
+    p.BB = (double)BBf;
+    // -BB/(2*AA) == -(BB/AA)/2 exactly (power-of-two scaling commutes with rounding), so one
+    // fp64 division serves both t and min_value.
+    const double q = p.BB / p.AA;
+    p.t = (float)(-q * 0.5);
+    p.skip = ((double)p.t <= GOF_NEAR_PLANE);
+    const double min_value = (-q) * (p.BB * 0.25) + (double)v[9];
+    float power = (float)(-0.5 * min_value);
+    if (power > 0.0f) power = 0.0f;
+    p.G = gexpf(power);
+    p.alpha = fminf(0.99f, w * p.G);
+    if (p.alpha < 1.0f / 255.0f) p.skip = true;
+}
+
+} // namespace gof

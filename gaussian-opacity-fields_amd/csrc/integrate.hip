@@ -1,0 +1,223 @@
+// integrate.hip -- K14, the opacity-field level-set query (replaces integrateCUDA, reference
+// forward.cu:803-1218).
+//
+// The reference keeps ~8 KB of per-thread arrays (contributed_ids[1024], projected_*[256],
+// point_alphas/Ts[256]) -- scratch-memory traffic on any GPU -- and walks every tile list twice
+// per 256-point chunk of a pixel.  MI355X redesign, same results:
+//
+//   per staged batch of 256 tile-list entries (64-byte SplatRec lines in LDS):
+//     phase A (pixel-centric, thread = pixel): advance the 5-sub-ray blending state machine of
+//       forward.cu:886-993 and record, per pixel, WHICH list positions contributed as a 256-bit
+//       mask in LDS (s_used[word][pixel]: conflict-free for the writers).
+//     phase B (point-centric, thread = query point): every point of the tile walks the set
+//       bits of ITS pixel's mask in ascending order (the restricted re-walk of
+//       forward.cu:1138-1196) and updates its own (alpha_sum, T) pair, carried across batches in
+//       out_alpha_integrated / the point workspace.  No per-thread arrays, no second pass over
+//       global memory, any number of points per pixel in one sweep.
+//
+// Observable quirks reproduced: the pass-1 walk never terminates on saturation (`continue`,
+// forward.cu:951-956), only on the 1024-contributor cap (:986-990); no T termination and the
+// t-clamp in pass 2 (:1172-1190); colour of a point = colour of its pixel (:1207-1208);
+// channel 8 = number of points per pixel INCLUDING the re-count of the tile's last point that
+// the reference's outer while-loop performs when another pixel of the tile holds more than 256
+// points (:1025-1096, see oracle/gof_oracle_integrate.inc).
+// Documented deviation: contributor ids are not truncated to uint16 (:983); identical as long as
+// a tile list has at most 65535 entries.
+#include "gof_common.h"
+
+namespace gof {
+
+__global__ void __launch_bounds__(256)
+integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restrict__ point_ranges,
+                 const uint32_t* __restrict__ gaussian_list, const uint32_t* __restrict__ point_list,
+                 const SplatRec* __restrict__ rec, int W, int H, float focal_x, float focal_y,
+                 const float2* __restrict__ points2D, const float* __restrict__ point_depths, float* __restrict__ point_T,
+                 const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                 float* __restrict__ out_color, float* __restrict__ out_alpha_integrated, float* __restrict__ out_color_integrated,
+                 uint32_t gx, uint32_t ntiles)
+{
+    const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t px = tx * TILE_X + (tid % TILE_X), py = ty * TILE_Y + (tid / TILE_X);
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const uint32_t pix_id = (uint32_t)W * py + px;
+    const size_t HW = (size_t)W * H;
+    const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
+
+    const uint2 range = gaussian_ranges[tile];
+    const uint2 prange = point_ranges[tile];
+    int toDo = (int)(range.y - range.x);
+    const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
+    const int nbatches = rounds > 0 ? rounds : 1;
+
+    __shared__ float4 s_rec[4][TILE_PIX];
+    __shared__ uint32_t s_used[8][TILE_PIX];
+    __shared__ float s_pixcol[3][TILE_PIX];
+    __shared__ uint32_t s_cnt[TILE_PIX];
+    __shared__ uint32_t s_iter;
+
+    // the 5 sub-rays: centre + 4 half-pixel corners (forward.cu:881-883, 920)
+    float srx[5], sry[5];
+    {
+        const float offx[5] = { 0.0f, -0.5f, 0.5f, -0.5f, 0.5f };
+        const float offy[5] = { 0.0f, -0.5f, -0.5f, 0.5f, 0.5f };
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            srx[c] = (float)(((double)(pixfx + offx[c]) - W / 2.) / (double)focal_x);
+            sry[c] = (float)(((double)(pixfy + offy[c]) - H / 2.) / (double)focal_y);
+        }
+    }
+    float cT[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
+    float C0 = 0, C1 = 0, C2 = 0, Cdepth = 0, Calpha = 0;
+    uint32_t contributor = 0, last_contributor = 0, n_local = 0;
+    bool done = !inside;
+
+    s_cnt[tid] = 0;
+    if (tid == 0) s_iter = 1;
+
+    for (int b = 0; b < nbatches; b++, toDo -= TILE_PIX) {
+        __syncthreads();   // previous phase B finished with s_rec / s_used
+        const uint32_t k = range.x + (uint32_t)b * TILE_PIX + tid;
+        if (k < range.y) {
+            const uint32_t id = gaussian_list[k];
+            const float4* src = reinterpret_cast<const float4*>(&rec[id]);
+            const float4 a4 = src[0], b4 = src[1], c4 = src[2], d4 = src[3];
+            s_rec[0][tid] = a4; s_rec[1][tid] = b4; s_rec[2][tid] = c4; s_rec[3][tid] = d4;
+        }
+        __syncthreads();
+
+        // ---- phase A: pixel-centric pass 1 over this batch ----
+        const int n = toDo < 0 ? 0 : (toDo < TILE_PIX ? toDo : TILE_PIX);
+        for (int w = 0; w < 8; w++) {
+            uint32_t word = 0;
+            const int j0 = w * 32;
+            const int j1 = (j0 + 32 < n) ? j0 + 32 : n;
+            for (int j = j0; j < j1; j++) {
+                if (done) continue;
+                contributor++;
+                const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
+                const float wgt = c4.z;
+                bool used = false;
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const float rx = srx[c], ry = sry[c];
+                    const float n0 = a4.x * rx + a4.y * ry + a4.z;
+                    const float n1 = a4.y * rx + a4.w * ry + b4.x;
+                    const float n2 = a4.z * rx + b4.x * ry + b4.y;
+                    const float AA = rx * n0 + ry * n1 + n2;
+                    const float BB = 2 * (b4.z * rx + b4.w * ry + c4.x);
+                    const float CC = c4.y;
+                    const float t = -BB / (2 * AA);
+                    if ((double)t <= GOF_NEAR_PLANE) continue;
+                    const double min_value = (double)(-(BB / AA)) * ((double)BB / 4.) + (double)CC;
+                    float power = (float)(-0.5 * min_value);
+                    if (power > 0.0f) power = 0.0f;
+                    const float alpha = fminf(0.99f, wgt * gexpf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    const float test_T = cT[c] * (1 - alpha);
+                    if (test_T < 0.0001f) continue;
+                    if (c == 0) {
+                        const float4 d4 = s_rec[3][j];
+                        C0 += c4.w * alpha * cT[c];
+                        C1 += d4.x * alpha * cT[c];
+                        C2 += d4.y * alpha * cT[c];
+                    }
+                    if (t > Cdepth) Cdepth = t;
+                    if (c == 0) Calpha += alpha * cT[c];
+                    cT[c] = test_T;
+                    used = true;
+                }
+                if (used) {
+                    last_contributor = contributor;
+                    word |= 1u << (j - j0);
+                    n_local += 1;
+                    if (n_local >= (uint32_t)MAX_NUM_CONTRIBUTORS * 4) done = true;
+                }
+            }
+            s_used[w][tid] = word;
+        }
+        const bool last_batch = (b == nbatches - 1);
+        if (last_batch) {
+            s_pixcol[0][tid] = C0 + cT[0] * bg_color[0];
+            s_pixcol[1][tid] = C1 + cT[0] * bg_color[1];
+            s_pixcol[2][tid] = C2 + cT[0] * bg_color[2];
+        }
+        __syncthreads();
+
+        // ---- phase B: point-centric pass 2 over this batch ----
+        for (uint32_t base = prange.x; base < prange.y; base += TILE_PIX) {
+            const uint32_t pi = base + tid;
+            if (pi >= prange.y) continue;
+            const uint32_t pid = point_list[pi];
+            const float2 xy = points2D[pid];
+            const float ray_depth = point_depths[pid];
+            const uint32_t lp = ((uint32_t)xy.y - ty * TILE_Y) * TILE_X + ((uint32_t)xy.x - tx * TILE_X);
+            float T, acc;
+            if (b == 0) { T = 1.f; acc = 0.f; atomicAdd(&s_cnt[lp], 1u); }
+            else { T = point_T[pid]; acc = out_alpha_integrated[pid]; }
+            const float rx = (float)(((double)xy.x - W / 2.) / (double)focal_x);
+            const float ry = (float)(((double)xy.y - H / 2.) / (double)focal_y);
+            for (int w = 0; w < 8; w++) {
+                uint32_t mask = s_used[w][lp];
+                while (mask) {
+                    const int bit = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    const int j = w * 32 + bit;
+                    const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
+                    const float n0 = a4.x * rx + a4.y * ry + a4.z;
+                    const float n1 = a4.y * rx + a4.w * ry + b4.x;
+                    const float n2 = a4.z * rx + b4.x * ry + b4.y;
+                    const float AA = rx * n0 + ry * n1 + n2;
+                    const float BB = 2 * (b4.z * rx + b4.w * ry + c4.x);
+                    const float CC = c4.y;
+                    float t = -BB / (2 * AA);
+                    if (t > ray_depth) t = ray_depth;
+                    const float power = -0.5f * (AA * t * t + BB * t + CC);
+                    const float alpha = fminf(0.99f, c4.z * gexpf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    const float test_T = T * (1 - alpha);
+                    acc += alpha * T;
+                    T = test_T;
+                }
+            }
+            out_alpha_integrated[pid] = acc;
+            if (!last_batch) point_T[pid] = T;
+            else {
+                out_color_integrated[3 * (size_t)pid + 0] = s_pixcol[0][lp];
+                out_color_integrated[3 * (size_t)pid + 1] = s_pixcol[1][lp];
+                out_color_integrated[3 * (size_t)pid + 2] = s_pixcol[2][lp];
+            }
+        }
+    }
+    __syncthreads();
+
+    // number of outer-loop iterations the reference's block would run: max over pixels of
+    // max(1, ceil(points_in_pixel / 256))
+    const uint32_t m = s_cnt[tid];
+    const uint32_t needed = m > (uint32_t)MAX_NUM_PROJECTED ? (m + MAX_NUM_PROJECTED - 1) / MAX_NUM_PROJECTED : 1u;
+    if (inside && needed > 1) atomicMax(&s_iter, needed);
+    __syncthreads();
+
+    if (inside) {
+        final_T[pix_id] = cT[0];
+        n_contrib[pix_id] = last_contributor;
+        out_color[0 * HW + pix_id] = C0 + cT[0] * bg_color[0];
+        out_color[1 * HW + pix_id] = C1 + cT[0] * bg_color[1];
+        out_color[2 * HW + pix_id] = C2 + cT[0] * bg_color[2];
+        out_color[6 * HW + pix_id] = Cdepth;
+        out_color[7 * HW + pix_id] = Calpha;
+        uint32_t total = m;
+        const uint32_t n_iter = s_iter;
+        if (n_iter > needed && prange.y > prange.x) {
+            const uint32_t lastpid = point_list[prange.y - 1];
+            const float2 lxy = points2D[lastpid];
+            const uint32_t llp = ((uint32_t)lxy.y - ty * TILE_Y) * TILE_X + ((uint32_t)lxy.x - tx * TILE_X);
+            if (llp == tid) total += n_iter - needed;
+        }
+        out_color[8 * HW + pix_id] = (float)total;
+    }
+}
+
+} // namespace gof

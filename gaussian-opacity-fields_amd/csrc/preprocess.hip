@@ -1,0 +1,448 @@
+// preprocess.hip -- per-Gaussian / per-point streaming kernels (HBM-bound).
+//
+//   preprocess_fwd   K1  replaces preprocessCUDA        (reference forward.cu:283-404)
+//   preprocess_bwd   K9  replaces backward preprocessCUDA (reference backward.cu:593-631)
+//   preprocess_points K10 replaces preprocessPointsCUDA (reference forward.cu:722-766)
+//   mark_visible     K15 replaces checkFrustum          (reference rasterizer_impl.cu:54-66)
+//
+// Layout decisions (MI355X): one thread per Gaussian, 256-thread blocks; inputs are read with
+// the widest loads the reference's [P,k] row-major layouts allow (16-byte loads for rotations
+// and the 192-byte SH block, which is 16-byte aligned); outputs go to the 64-byte SplatRec line
+// (4 x 16-byte stores) so that the blend kernels gather one aligned line per tile-list entry.
+// cov3D is NOT stored: its only consumer in the reference is dead code (backward.cu:627-630).
+#include "gof_common.h"
+
+namespace gof {
+
+__constant__ float SH_C0 = 0.28209479177387814f;
+__constant__ float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
+__constant__ float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+
+// SH -> RGB (forward.cu:20-71). sh points at this Gaussian's [M][3] block.
+__device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float* __restrict__ shp, uint32_t& clamp_bits)
+{
+    V3 dir = pos - campos;
+    dir = dir / sqrtf(dot3(dir, dir));
+    const V3* sh = reinterpret_cast<const V3*>(shp);
+    V3 result = SH_C0 * sh[0];
+    if (deg > 0) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        result = result - SH_C1 * y * sh[1] + SH_C1 * z * sh[2] - SH_C1 * x * sh[3];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            result = result +
+                SH_C2[0] * xy * sh[4] +
+                SH_C2[1] * yz * sh[5] +
+                SH_C2[2] * (2.0f * zz - xx - yy) * sh[6] +
+                SH_C2[3] * xz * sh[7] +
+                SH_C2[4] * (xx - yy) * sh[8];
+            if (deg > 2) {
+                result = result +
+                    SH_C3[0] * y * (3.0f * xx - yy) * sh[9] +
+                    SH_C3[1] * xy * z * sh[10] +
+                    SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[11] +
+                    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12] +
+                    SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[13] +
+                    SH_C3[5] * z * (xx - yy) * sh[14] +
+                    SH_C3[6] * x * (xx - 3.0f * yy) * sh[15];
+            }
+        }
+    }
+    result = result + V3{ 0.5f, 0.5f, 0.5f };
+    clamp_bits = (result.x < 0 ? 1u : 0u) | (result.y < 0 ? 2u : 0u) | (result.z < 0 ? 4u : 0u);
+    return V3{ fmaxf(result.x, 0.0f), fmaxf(result.y, 0.0f), fmaxf(result.z, 0.0f) };
+}
+
+// Intermediates shared by computeView2Gaussian forward and backward (forward.cu:168-261)
+struct V2GInter {
+    M4 G2V; M4 W2V;
+    M3 Rt;           // R_transpose
+    V3 t2;
+    double Sx, Sy, Sz;
+    M3 SR;           // S_inv_square_R
+};
+__device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot, const float* __restrict__ vm, V2GInter& I)
+{
+    const M3 R = quat_to_R(rot.x, rot.y, rot.z, rot.w);
+    M4 G2W;
+    G2W.m[0][0] = R.m[0][0]; G2W.m[0][1] = R.m[1][0]; G2W.m[0][2] = R.m[2][0]; G2W.m[0][3] = 0.0f;
+    G2W.m[1][0] = R.m[0][1]; G2W.m[1][1] = R.m[1][1]; G2W.m[1][2] = R.m[2][1]; G2W.m[1][3] = 0.0f;
+    G2W.m[2][0] = R.m[0][2]; G2W.m[2][1] = R.m[1][2]; G2W.m[2][2] = R.m[2][2]; G2W.m[2][3] = 0.0f;
+    G2W.m[3][0] = mean.x; G2W.m[3][1] = mean.y; G2W.m[3][2] = mean.z; G2W.m[3][3] = 1.0f;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) I.W2V.m[c][r] = vm[4 * c + r];
+    I.G2V = mul(I.W2V, G2W);
+    const M4& G = I.G2V;
+    I.Rt = mk3(G.m[0][0], G.m[1][0], G.m[2][0],
+               G.m[0][1], G.m[1][1], G.m[2][1],
+               G.m[0][2], G.m[1][2], G.m[2][2]);
+    const V3 t = { G.m[3][0], G.m[3][1], G.m[3][2] };
+    I.t2 = mul(neg(I.Rt), t);
+    I.Sx = 1.0f / ((double)scale.x * scale.x + 1e-7);
+    I.Sy = 1.0f / ((double)scale.y * scale.y + 1e-7);
+    I.Sz = 1.0f / ((double)scale.z * scale.z + 1e-7);
+    const M3& Rt = I.Rt;
+    I.SR = mk3((float)(I.Sx * Rt.m[0][0]), (float)(I.Sy * Rt.m[0][1]), (float)(I.Sz * Rt.m[0][2]),
+               (float)(I.Sx * Rt.m[1][0]), (float)(I.Sy * Rt.m[1][1]), (float)(I.Sz * Rt.m[1][2]),
+               (float)(I.Sx * Rt.m[2][0]), (float)(I.Sy * Rt.m[2][1]), (float)(I.Sz * Rt.m[2][2]));
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd(int P, int D, int M,
+               const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+               const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+               const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+               const float* __restrict__ v2g_precomp, Cam cam,
+               int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
+               uint32_t gx, uint32_t gy, int prefiltered,
+               int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
+               float4* __restrict__ conic_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
+               uint32_t* __restrict__ flags)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    int32_t my_radii = 0;
+    uint32_t my_tiles = 0;
+
+    const V3 p_orig = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+    const V3 p_view = transform_point_4x3(p_orig, cam.view);
+    // near cull only (auxiliary.h:189): the lateral frustum test is commented out in the reference
+    if (p_view.z <= 0.2f) {
+        if (prefiltered) atomicOr(&flags[0], 1u);
+        radii[idx] = 0; tiles_touched[idx] = 0;
+        return;
+    }
+    do {
+        const float* pm = cam.proj;
+        const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
+        const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
+        const float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+
+        V3 scale = { 0, 0, 0 };
+        float4 rot = { 0, 0, 0, 0 };
+        if (scales) scale = V3{ scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
+        if (rotations) rot = reinterpret_cast<const float4*>(rotations)[idx];
+
+        // 3D covariance (forward.cu:129-163)
+        float c3[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            M3 S = mk3(1, 0, 0, 0, 1, 0, 0, 0, 1);
+            S.m[0][0] = scale_modifier * scale.x;
+            S.m[1][1] = scale_modifier * scale.y;
+            S.m[2][2] = scale_modifier * scale.z;
+            const M3 R = quat_to_R(rot.x, rot.y, rot.z, rot.w);
+            const M3 Mm = mul(S, R);
+            const M3 Sigma = mul(transpose(Mm), Mm);
+            c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+            c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+        }
+
+        // 2D covariance + mip low-pass coefficient (forward.cu:74-124)
+        V3 t = p_view;
+        const float limx = 1.3f * tan_fovx;
+        const float limy = 1.3f * tan_fovy;
+        const float txtz = t.x / t.z;
+        const float tytz = t.y / t.z;
+        t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+        t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+        const M3 J = mk3(focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z),
+                         0.0f, focal_y / t.z, -(focal_y * t.y) / (t.z * t.z),
+                         0, 0, 0);
+        const float* vm = cam.view;
+        const M3 Wm = mk3(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+        const M3 T = mul(Wm, J);
+        const M3 Vrk = mk3(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+        M3 cov = mul(mul(transpose(T), transpose(Vrk)), T);
+        const float det_0 = (float)fmax(1e-6, (double)(cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1]));
+        const float det_1 = (float)fmax(1e-6, (double)((cov.m[0][0] + kernel_size) * (cov.m[1][1] + kernel_size) - cov.m[0][1] * cov.m[0][1]));
+        float coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+        if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = 0.0f;
+        const float covx = cov.m[0][0] + kernel_size, covy = cov.m[0][1], covz = cov.m[1][1] + kernel_size;
+
+        const float det = (covx * covz - covy * covy);
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float conx = covz * det_inv, cony = -covy * det_inv, conz = covx * det_inv;
+
+        const float mid = 0.5f * (covx + covz);
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix = (float)((((double)projx + 1.0) * W - 1.0) * 0.5);
+        const float piy = (float)((((double)projy + 1.0) * H - 1.0) * 0.5);
+        uint32_t minx, miny, maxx, maxy;
+        get_rect(pix, piy, (int)my_radius, minx, miny, maxx, maxy, gx, gy);
+        if ((maxx - minx) * (maxy - miny) == 0) break;
+
+        SplatRec r;
+        uint32_t cb = 0;
+        if (colors_precomp == nullptr) {
+            const V3 campos = { cam.campos[0], cam.campos[1], cam.campos[2] };
+            const V3 rgb = sh_to_rgb(D, p_orig, campos, shs + (size_t)idx * M * 3, cb);
+            r.f[REC_RGB] = rgb.x; r.f[REC_RGB + 1] = rgb.y; r.f[REC_RGB + 2] = rgb.z;
+        } else {
+            r.f[REC_RGB] = colors_precomp[3 * (size_t)idx]; r.f[REC_RGB + 1] = colors_precomp[3 * (size_t)idx + 1]; r.f[REC_RGB + 2] = colors_precomp[3 * (size_t)idx + 2];
+        }
+        clamped[idx] = (uint8_t)cb;
+
+        if (v2g_precomp == nullptr) {
+            V2GInter I;
+            v2g_intermediates(scale, p_orig, rot, cam.view, I);
+            const V3 t2 = I.t2;
+            const double C = (double)(t2.x * t2.x) * I.Sx + (double)(t2.y * t2.y) * I.Sy + (double)(t2.z * t2.z) * I.Sz;
+            const V3 B = mul(t2, I.SR);
+            const M3 Sigma = mul(transpose(I.Rt), I.SR);
+            r.f[0] = Sigma.m[0][0]; r.f[1] = Sigma.m[0][1]; r.f[2] = Sigma.m[0][2];
+            r.f[3] = Sigma.m[1][1]; r.f[4] = Sigma.m[1][2]; r.f[5] = Sigma.m[2][2];
+            r.f[6] = B.x; r.f[7] = B.y; r.f[8] = B.z; r.f[9] = (float)C;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; i++) r.f[i] = v2g_precomp[10 * (size_t)idx + i];
+        }
+        r.f[REC_W] = opacities[idx] * coef;
+        r.f[REC_XY] = pix; r.f[REC_XY + 1] = piy;
+
+        float4* dst = reinterpret_cast<float4*>(&rec[idx]);
+        dst[0] = make_float4(r.f[0], r.f[1], r.f[2], r.f[3]);
+        dst[1] = make_float4(r.f[4], r.f[5], r.f[6], r.f[7]);
+        dst[2] = make_float4(r.f[8], r.f[9], r.f[10], r.f[11]);
+        dst[3] = make_float4(r.f[12], r.f[13], r.f[14], r.f[15]);
+        conic_out[idx] = make_float4(conx, cony, conz, 0.f);
+        depths[idx] = p_view.z;
+        my_radii = (int32_t)my_radius;
+        my_tiles = (maxy - miny) * (maxx - minx);
+    } while (0);
+    radii[idx] = my_radii;
+    tiles_touched[idx] = my_tiles;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K9: backward of the per-Gaussian stage (backward.cu:593-631): view2gaussian backward
+// (overwrites dL_dmeans / dL_dscales / dL_drots, backward.cu:494-497, 570-573, 585-586) and SH
+// backward (adds to dL_dmeans, backward.cu:138).  Skips radii <= 0.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sh_backward(int deg, V3 pos, V3 campos, const float* __restrict__ shp, uint32_t clamp_bits,
+                                            V3 dL_dRGB, float* __restrict__ dL_dshp, int M, V3& dL_dmean_add)
+{
+    const V3 dir_orig = pos - campos;
+    const V3 dir = dir_orig / sqrtf(dot3(dir_orig, dir_orig));
+    const V3* sh = reinterpret_cast<const V3*>(shp);
+    dL_dRGB.x *= (clamp_bits & 1u) ? 0 : 1;
+    dL_dRGB.y *= (clamp_bits & 2u) ? 0 : 1;
+    dL_dRGB.z *= (clamp_bits & 4u) ? 0 : 1;
+    V3 dRGBdx = { 0, 0, 0 }, dRGBdy = { 0, 0, 0 }, dRGBdz = { 0, 0, 0 };
+    const float x = dir.x, y = dir.y, z = dir.z;
+    V3* dL_dsh = reinterpret_cast<V3*>(dL_dshp);
+
+    dL_dsh[0] = SH_C0 * dL_dRGB;
+    if (deg > 0) {
+        const float dRGBdsh1 = -SH_C1 * y;
+        const float dRGBdsh2 = SH_C1 * z;
+        const float dRGBdsh3 = -SH_C1 * x;
+        dL_dsh[1] = dRGBdsh1 * dL_dRGB;
+        dL_dsh[2] = dRGBdsh2 * dL_dRGB;
+        dL_dsh[3] = dRGBdsh3 * dL_dRGB;
+        dRGBdx = -SH_C1 * sh[3];
+        dRGBdy = -SH_C1 * sh[1];
+        dRGBdz = SH_C1 * sh[2];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            const float dRGBdsh4 = SH_C2[0] * xy;
+            const float dRGBdsh5 = SH_C2[1] * yz;
+            const float dRGBdsh6 = SH_C2[2] * (2.f * zz - xx - yy);
+            const float dRGBdsh7 = SH_C2[3] * xz;
+            const float dRGBdsh8 = SH_C2[4] * (xx - yy);
+            dL_dsh[4] = dRGBdsh4 * dL_dRGB;
+            dL_dsh[5] = dRGBdsh5 * dL_dRGB;
+            dL_dsh[6] = dRGBdsh6 * dL_dRGB;
+            dL_dsh[7] = dRGBdsh7 * dL_dRGB;
+            dL_dsh[8] = dRGBdsh8 * dL_dRGB;
+            dRGBdx = dRGBdx + (SH_C2[0] * y * sh[4] + SH_C2[2] * 2.f * -x * sh[6] + SH_C2[3] * z * sh[7] + SH_C2[4] * 2.f * x * sh[8]);
+            dRGBdy = dRGBdy + (SH_C2[0] * x * sh[4] + SH_C2[1] * z * sh[5] + SH_C2[2] * 2.f * -y * sh[6] + SH_C2[4] * 2.f * -y * sh[8]);
+            dRGBdz = dRGBdz + (SH_C2[1] * y * sh[5] + SH_C2[2] * 2.f * 2.f * z * sh[6] + SH_C2[3] * x * sh[7]);
+            if (deg > 2) {
+                const float dRGBdsh9 = SH_C3[0] * y * (3.f * xx - yy);
+                const float dRGBdsh10 = SH_C3[1] * xy * z;
+                const float dRGBdsh11 = SH_C3[2] * y * (4.f * zz - xx - yy);
+                const float dRGBdsh12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                const float dRGBdsh13 = SH_C3[4] * x * (4.f * zz - xx - yy);
+                const float dRGBdsh14 = SH_C3[5] * z * (xx - yy);
+                const float dRGBdsh15 = SH_C3[6] * x * (xx - 3.f * yy);
+                dL_dsh[9] = dRGBdsh9 * dL_dRGB;
+                dL_dsh[10] = dRGBdsh10 * dL_dRGB;
+                dL_dsh[11] = dRGBdsh11 * dL_dRGB;
+                dL_dsh[12] = dRGBdsh12 * dL_dRGB;
+                dL_dsh[13] = dRGBdsh13 * dL_dRGB;
+                dL_dsh[14] = dRGBdsh14 * dL_dRGB;
+                dL_dsh[15] = dRGBdsh15 * dL_dRGB;
+                dRGBdx = dRGBdx + (
+                    SH_C3[0] * sh[9] * 3.f * 2.f * xy +
+                    SH_C3[1] * sh[10] * yz +
+                    SH_C3[2] * sh[11] * -2.f * xy +
+                    SH_C3[3] * sh[12] * -3.f * 2.f * xz +
+                    SH_C3[4] * sh[13] * (-3.f * xx + 4.f * zz - yy) +
+                    SH_C3[5] * sh[14] * 2.f * xz +
+                    SH_C3[6] * sh[15] * 3.f * (xx - yy));
+                dRGBdy = dRGBdy + (
+                    SH_C3[0] * sh[9] * 3.f * (xx - yy) +
+                    SH_C3[1] * sh[10] * xz +
+                    SH_C3[2] * sh[11] * (-3.f * yy + 4.f * zz - xx) +
+                    SH_C3[3] * sh[12] * -3.f * 2.f * yz +
+                    SH_C3[4] * sh[13] * -2.f * xy +
+                    SH_C3[5] * sh[14] * -2.f * yz +
+                    SH_C3[6] * sh[15] * -3.f * 2.f * xy);
+                dRGBdz = dRGBdz + (
+                    SH_C3[1] * sh[10] * xy +
+                    SH_C3[2] * sh[11] * 4.f * 2.f * yz +
+                    SH_C3[3] * sh[12] * 3.f * (2.f * zz - xx - yy) +
+                    SH_C3[4] * sh[13] * 4.f * 2.f * xz +
+                    SH_C3[5] * sh[14] * (xx - yy));
+            }
+        }
+    }
+    (void)M;
+    const V3 dv = { dot3(dRGBdx, dL_dRGB), dot3(dRGBdy, dL_dRGB), dot3(dRGBdz, dL_dRGB) };
+    const V3 v = dir_orig;
+    // auxiliary.h:125-135
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dL_dmean_add.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    dL_dmean_add.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    dL_dmean_add.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_bwd(int P, int D, int M,
+               const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
+               const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
+               Cam cam, const float* __restrict__ dL_dv2g, const float* __restrict__ dL_dcolor,
+               float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drots)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+    const V3 mean = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+    const V3 scale = { scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
+    const float4 rot = reinterpret_cast<const float4*>(rotations)[idx];
+    const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+
+    V2GInter I;
+    v2g_intermediates(scale, mean, rot, cam.view, I);
+    const M3& Rt = I.Rt;
+    const M3& SR = I.SR;
+    const V3 t2 = I.t2;
+    const M4& G2V = I.G2V;
+    const double Sx = I.Sx, Sy = I.Sy, Sz = I.Sz;
+    float d[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) d[i] = dL_dv2g[10 * (size_t)idx + i];
+
+    const M3 dL_dSigma = mk3(d[0], 0.5f * d[1], 0.5f * d[2],
+                             0.5f * d[1], d[3], 0.5f * d[4],
+                             0.5f * d[2], 0.5f * d[4], d[5]);
+    const V3 dL_dB = { d[6], d[7], d[8] };
+    const float dL_dC = d[9];
+
+    const M3 q = add(mul(Rt, dL_dSigma), outer(t2, dL_dB));                 // dL_dS_inv_square_R
+    M3 dL_dRt = transpose(mul(dL_dSigma, transpose(SR)));
+    dL_dRt = add(dL_dRt, mk3((float)(Sx * q.m[0][0]), (float)(Sy * q.m[0][1]), (float)(Sz * q.m[0][2]),
+                             (float)(Sx * q.m[1][0]), (float)(Sy * q.m[1][1]), (float)(Sz * q.m[1][2]),
+                             (float)(Sx * q.m[2][0]), (float)(Sy * q.m[2][1]), (float)(Sz * q.m[2][2])));
+    float dSx = q.m[0][0] * Rt.m[0][0] + q.m[1][0] * Rt.m[1][0] + q.m[2][0] * Rt.m[2][0];
+    float dSy = q.m[0][1] * Rt.m[0][1] + q.m[1][1] * Rt.m[1][1] + q.m[2][1] * Rt.m[2][1];
+    float dSz = q.m[0][2] * Rt.m[0][2] + q.m[1][2] * Rt.m[1][2] + q.m[2][2] * Rt.m[2][2];
+    const float dtx = (float)(2 * t2.x * Sx * dL_dC + dL_dB.x * SR.m[0][0] + dL_dB.y * SR.m[1][0] + dL_dB.z * SR.m[2][0]);
+    const float dty = (float)(2 * t2.y * Sy * dL_dC + dL_dB.x * SR.m[0][1] + dL_dB.y * SR.m[1][1] + dL_dB.z * SR.m[2][1]);
+    const float dtz = (float)(2 * t2.z * Sz * dL_dC + dL_dB.x * SR.m[0][2] + dL_dB.y * SR.m[1][2] + dL_dB.z * SR.m[2][2]);
+    dSx += dL_dC * t2.x * t2.x;
+    dSy += dL_dC * t2.y * t2.y;
+    dSz += dL_dC * t2.z * t2.z;
+    dL_dscales[3 * idx + 0] = (float)(-2 / scale.x * Sx * dSx);
+    dL_dscales[3 * idx + 1] = (float)(-2 / scale.y * Sy * dSy);
+    dL_dscales[3 * idx + 2] = (float)(-2 / scale.z * Sz * dSz);
+
+    const M3 G2V_R_t = mk3(G2V.m[0][0], G2V.m[1][0], G2V.m[2][0],
+                           G2V.m[0][1], G2V.m[1][1], G2V.m[2][1],
+                           G2V.m[0][2], G2V.m[1][2], G2V.m[2][2]);
+    const V3 G2V_t = { G2V.m[3][0], G2V.m[3][1], G2V.m[3][2] };
+    const V3 dV = { dtx, dty, dtz };
+    const M3 dL_dV2G_R_t = transpose(dL_dRt);
+    const M3 from_t = mk3(-dV.x * G2V_t.x, -dV.x * G2V_t.y, -dV.x * G2V_t.z,
+                          -dV.y * G2V_t.x, -dV.y * G2V_t.y, -dV.y * G2V_t.z,
+                          -dV.z * G2V_t.x, -dV.z * G2V_t.y, -dV.z * G2V_t.z);
+    const M3 dL_dG2V_R = add(dL_dV2G_R_t, from_t);
+    const V3 dL_dG2V_t = mul(-dV, G2V_R_t);
+    M4 dL_dG2V;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { dL_dG2V.m[c][0] = dL_dG2V_R.m[c][0]; dL_dG2V.m[c][1] = dL_dG2V_R.m[c][1]; dL_dG2V.m[c][2] = dL_dG2V_R.m[c][2]; dL_dG2V.m[c][3] = 0.0f; }
+    dL_dG2V.m[3][0] = dL_dG2V_t.x; dL_dG2V.m[3][1] = dL_dG2V_t.y; dL_dG2V.m[3][2] = dL_dG2V_t.z; dL_dG2V.m[3][3] = 0.0f;
+    const M4 dL_dG2W = mul(transpose(I.W2V), dL_dG2V);
+    const float (*Mt)[4] = dL_dG2W.m;   // dL_dMt[c][r] = dL_dG2W[c][r] for c,r < 3
+
+    V3 dmean = { dL_dG2W.m[3][0], dL_dG2W.m[3][1], dL_dG2W.m[3][2] };
+
+    float4 dq;
+    dq.x = 2 * z * (Mt[0][1] - Mt[1][0]) + 2 * y * (Mt[2][0] - Mt[0][2]) + 2 * x * (Mt[1][2] - Mt[2][1]);
+    dq.y = 2 * y * (Mt[1][0] + Mt[0][1]) + 2 * z * (Mt[2][0] + Mt[0][2]) + 2 * r * (Mt[1][2] - Mt[2][1]) - 4 * x * (Mt[2][2] + Mt[1][1]);
+    dq.z = 2 * x * (Mt[1][0] + Mt[0][1]) + 2 * r * (Mt[2][0] - Mt[0][2]) + 2 * z * (Mt[1][2] + Mt[2][1]) - 4 * y * (Mt[2][2] + Mt[0][0]);
+    dq.w = 2 * r * (Mt[0][1] - Mt[1][0]) + 2 * x * (Mt[2][0] + Mt[0][2]) + 2 * y * (Mt[1][2] + Mt[2][1]) - 4 * z * (Mt[1][1] + Mt[0][0]);
+    reinterpret_cast<float4*>(dL_drots)[idx] = dq;
+
+    if (shs) {
+        const V3 campos = { cam.campos[0], cam.campos[1], cam.campos[2] };
+        const V3 dL_dRGB = { dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2] };
+        V3 addm;
+        sh_backward(D, mean, campos, shs + (size_t)idx * M * 3, clamped[idx], dL_dRGB, dL_dsh + (size_t)idx * M * 3, M, addm);
+        dmean = dmean + addm;
+    }
+    dL_dmeans[3 * idx + 0] = dmean.x;
+    dL_dmeans[3 * idx + 1] = dmean.y;
+    dL_dmeans[3 * idx + 2] = dmean.z;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K10: query points (forward.cu:722-766)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+preprocess_points(int PN, const float* __restrict__ points3D, Cam cam, int W, int H, float focal_x, float focal_y,
+                  float2* __restrict__ points2D, float* __restrict__ depths, uint32_t* __restrict__ tiles_touched)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= PN) return;
+    uint32_t touched = 0;
+    const V3 p = { points3D[3 * idx], points3D[3 * idx + 1], points3D[3 * idx + 2] };
+    const V3 pv = transform_point_4x3(p, cam.view);
+    if (!(pv.z <= 0.2f)) {
+        const float pix = (float)((double)(focal_x * pv.x / (pv.z + 0.0000001f)) + W / 2.);
+        const float piy = (float)((double)(focal_y * pv.y / (pv.z + 0.0000001f)) + H / 2.);
+        if (!(pix < 0 || pix >= W || piy < 0 || piy >= H)) {
+            depths[idx] = pv.z;
+            points2D[idx] = make_float2(pix, piy);
+            touched = 1;
+        }
+    }
+    tiles_touched[idx] = touched;
+}
+
+// K15 (rasterizer_impl.cu:54-66)
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, Cam cam, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const V3 p = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+    const V3 pv = transform_point_4x3(p, cam.view);
+    present[idx] = (pv.z <= 0.2f) ? 0 : 1;
+}
+
+} // namespace gof

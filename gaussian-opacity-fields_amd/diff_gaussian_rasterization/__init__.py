@@ -1,0 +1,141 @@
+"""MI355X-native ``diff_gaussian_rasterization``: the Python surface of the reference
+(submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py) --
+``GaussianRasterizationSettings``, ``GaussianRasterizer`` (forward / integrate / markVisible),
+``rasterize_gaussians`` -- on top of hand-written gfx950 kernels (libgof_hip.so).
+
+``gaussian_renderer.render()`` / ``integrate()`` of the reference import exactly these names
+(gaussian_renderer/__init__.py:14) and run unchanged against this package.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _backend as _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    # field order and names as the reference (diff_gaussian_rasterization/__init__.py:167-181)
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    subpixel_offset: torch.Tensor
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU deep copy of an argument tuple for the debug dumps (reference :18-20)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_with_snapshot(fn, args, debug, dump_name, what):
+    """pipe.debug behaviour of the reference (:89-96, :141-148): on failure dump the inputs and re-raise."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print("\nAn error occured in %s. Please forward %s for debugging." % (what, dump_name))
+        raise
+
+
+def _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, sh):
+    """Argument order of the native forward/integrate entry points after the leading (bg[, points3D])."""
+    return (means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view2gaussian_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
+            rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                view2gaussian_precomp, raster_settings):
+        rs = raster_settings
+        args = (rs.bg,) + _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     view2gaussian_precomp, sh)
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _call_with_snapshot(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
+                              geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
+         geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size,
+                rs.subpixel_offset, grad_out_color, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
+                binningBuffer, imgBuffer, rs.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_view2gaussian_precomp) = _call_with_snapshot(
+            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        # one gradient per forward input, in the forward's order (reference :152-165)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, grad_view2gaussian_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        view2gaussian_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     view2gaussian_precomp, raster_settings)
+
+
+def _normalise_optionals(shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp):
+    """Input contract of GaussianRasterizer.forward/integrate (reference :203-223): exactly one colour source,
+    exactly one covariance source; absent inputs become empty tensors (NULL for the native side)."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    has_sr = scales is not None or rotations is not None
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+    empty = torch.Tensor([])
+    fill = lambda t: empty if t is None else t   # noqa: E731
+    return fill(shs), fill(colors_precomp), fill(scales), fill(rotations), fill(cov3D_precomp), fill(view2gaussian_precomp)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points that pass the near-plane test of the camera (reference :188-197)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, view2gaussian_precomp=None):
+        shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp = _normalise_optionals(
+            shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   view2gaussian_precomp, self.raster_settings)
+
+    def integrate(self, points3D, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                  cov3D_precomp=None, view2gaussian_precomp=None):
+        """Opacity-field query: no autograd (reference :239-305).  Returns
+        ``(color, alpha_integrated, color_integrated, radii)``."""
+        shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp = _normalise_optionals(
+            shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp)
+        rs = self.raster_settings
+        args = (rs.bg, points3D) + _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                              view2gaussian_precomp, shs)
+        (num_rendered, color, alpha_integrated, color_integrated, radii, geomBuffer, binningBuffer, imgBuffer) = \
+            _call_with_snapshot(_C.integrate_gaussians_to_points, args, rs.debug, "snapshot_fw.dump", "forward")
+        return color, alpha_integrated, color_integrated, radii

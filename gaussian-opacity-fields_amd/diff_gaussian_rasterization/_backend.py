@@ -1,0 +1,268 @@
+"""ctypes backend: the four entry points of the reference's pybind11 module
+``diff_gaussian_rasterization._C`` (reference submodules/diff-gaussian-rasterization/ext.cpp:15-20,
+rasterize_points.cu) implemented on top of the C ABI of ``libgof_hip.so`` (include/gof_hip.h).
+
+PyTorch is used for device memory, streams and autograd plumbing only; every kernel lives in
+the shared library.  There is NO fallback: if the library is missing or cannot be loaded,
+importing this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.environ.get("GOF_HIP_LIB", os.path.join(_PKG, "lib", "libgof_hip.so"))
+
+OUTPUT_CHANNELS = 9
+
+
+class GofRasterArgs(C.Structure):
+    """Mirror of ``GofRasterArgs`` in include/gof_hip.h."""
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("kernel_size", C.c_float), ("scale_modifier", C.c_float),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("view2gaussian_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libgof_hip.so not found at %s -- build it with `python gaussian-opacity-fields_amd/build.py` "
+            "(hipcc, gfx950). There is no CPU / PyTorch fallback for the rasterizer." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32, u32, i64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_int64
+    A = C.POINTER(GofRasterArgs)
+    lib.gof_last_error.restype = C.c_char_p
+    lib.gof_abi_version.restype = C.c_int
+    for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]),
+                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32]), ("gof_mtets_ws_bytes", [i64])):
+        f = getattr(lib, name)
+        f.restype = sz
+        f.argtypes = args
+    lib.gof_forward_prepare.argtypes = [A, vp, sz, vp, sz, vp, C.POINTER(u32), vp]
+    lib.gof_forward_render.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 9 + [vp, sz, vp]
+    lib.gof_integrate_prepare_points.argtypes = [A, i32, vp, vp, sz, C.POINTER(u32), vp]
+    lib.gof_integrate_run.argtypes = [A, u32, vp, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
+    lib.gof_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gof_mtets_count.argtypes = [i64, i64, vp, vp, vp, sz, C.POINTER(i64), C.POINTER(i64), vp]
+    lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
+    lib.gof_debug_fetch.restype = i64
+    lib.gof_debug_fetch.argtypes = [C.c_char_p, A, u32, vp, vp, vp, vp, sz, vp]
+    for name in ("gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
+                 "gof_integrate_run", "gof_mark_visible", "gof_mtets_count", "gof_mtets_emit"):
+        getattr(lib, name).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("libgof_hip: " + lib.gof_last_error().decode(errors="replace"))
+
+
+def _ptr(t):
+    """Device pointer of a tensor, or NULL for the reference's "absent" convention (an empty tensor)."""
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, device, what):
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError("%s must be on %s (got %s)" % (what, device, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (what, t.dtype))
+    return t.contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _View:
+    """Validated, contiguous inputs of one rasterization call + the POD handed to the library."""
+
+    def __init__(self, background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                 view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
+                 image_height, image_width, sh, degree, campos, prefiltered, debug):
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:61-63
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("diff_gaussian_rasterization (gfx950 backend) needs tensors on a ROCm device, got %s" % dev)
+        self.device = dev
+        self.P = int(means3D.size(0))
+        self.H, self.W = int(image_height), int(image_width)
+        k = self.keep = {}
+        k["bg"] = _dev_f32(background, dev, "bg")
+        k["means3D"] = _dev_f32(means3D, dev, "means3D")
+        k["colors"] = _dev_f32(colors, dev, "colors_precomp")
+        k["opacity"] = _dev_f32(opacity, dev, "opacities")
+        k["scales"] = _dev_f32(scales, dev, "scales")
+        k["rotations"] = _dev_f32(rotations, dev, "rotations")
+        k["cov3D"] = _dev_f32(cov3D_precomp, dev, "cov3D_precomp")
+        k["v2g"] = _dev_f32(view2gaussian_precomp, dev, "view2gaussian_precomp")
+        k["view"] = _dev_f32(viewmatrix, dev, "viewmatrix")
+        k["proj"] = _dev_f32(projmatrix, dev, "projmatrix")
+        k["campos"] = _dev_f32(campos, dev, "campos")
+        k["subpix"] = _dev_f32(subpixel_offset, dev, "subpixel_offset")
+        k["sh"] = _dev_f32(sh, dev, "sh")
+        self.M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0   # rasterize_points.cu:87-91
+        a = self.args = GofRasterArgs()
+        a.P, a.D, a.M, a.W, a.H = self.P, int(degree), self.M, self.W, self.H
+        a.tan_fovx, a.tan_fovy = float(tan_fovx), float(tan_fovy)
+        a.kernel_size, a.scale_modifier = float(kernel_size), float(scale_modifier)
+        a.prefiltered, a.debug = int(bool(prefiltered)), int(bool(debug))
+        a.background = _ptr(k["bg"]); a.means3D = _ptr(k["means3D"]); a.shs = _ptr(k["sh"])
+        a.colors_precomp = _ptr(k["colors"]); a.opacities = _ptr(k["opacity"])
+        a.scales = _ptr(k["scales"]); a.rotations = _ptr(k["rotations"])
+        a.cov3D_precomp = _ptr(k["cov3D"]); a.view2gaussian_precomp = _ptr(k["v2g"])
+        a.viewmatrix = _ptr(k["view"]); a.projmatrix = _ptr(k["proj"]); a.campos = _ptr(k["campos"])
+        a.subpixel_offset = _ptr(k["subpix"])
+
+    def ref(self):
+        return C.byref(self.args)
+
+    def bytes_tensor(self, n):
+        return torch.empty(int(n), dtype=torch.uint8, device=self.device)
+
+
+def _prepare_and_bin(v):
+    """Stage 1 shared by forward and integrate: preprocess + scan + instance count."""
+    geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
+    img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
+    radii = torch.zeros(v.P, dtype=torch.int32, device=v.device)
+    n = C.c_uint32(0)
+    _check(lib.gof_forward_prepare(v.ref(), _ptr(geom), geom.numel(), _ptr(img), img.numel(), _ptr(radii), C.byref(n), _stream()))
+    rendered = int(n.value)
+    binning = v.bytes_tensor(lib.gof_binning_bytes(rendered, v.W, v.H))
+    return geom, img, binning, radii, rendered
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
+                        image_height, image_width, sh, degree, campos, prefiltered, debug):
+    """Replaces ``_C.rasterize_gaussians`` (RasterizeGaussiansCUDA, rasterize_points.cu:36-122).
+    Returns ``(num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer)``."""
+    v = _View(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, view2gaussian_precomp,
+              viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh,
+              degree, campos, prefiltered, debug)
+    with torch.cuda.device(v.device):
+        out_color = torch.empty((OUTPUT_CHANNELS, v.H, v.W), dtype=torch.float32, device=v.device)
+        if v.P == 0:
+            out_color.zero_()
+            empty = v.bytes_tensor(0)
+            return 0, out_color, torch.zeros(0, dtype=torch.int32, device=v.device), empty, empty.clone(), empty.clone()
+        geom, img, binning, radii, rendered = _prepare_and_bin(v)
+        _check(lib.gof_forward_render(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                      _ptr(img), img.numel(), _ptr(out_color), _stream()))
+    return rendered, out_color, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size,
+                                 subpixel_offset, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                 imageBuffer, debug):
+    """Replaces ``_C.rasterize_gaussians_backward`` (rasterize_points.cu:124-211).  Returns
+    ``(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+    dL_dview2gaussian)``."""
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    # opacity is not an input of the reference's backward; the library needs a non-NULL pointer only for validation
+    v = _View(background, means3D, colors, means3D, scales, rotations, scale_modifier, cov3D_precomp, view2gaussian_precomp,
+              viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, H, W, sh, degree, campos, False, debug)
+    P, M, dev = v.P, v.M, v.device
+    f = dict(dtype=torch.float32, device=dev)
+    g_means3D = torch.empty((P, 3), **f); g_means2D = torch.empty((P, 3), **f); g_colors = torch.empty((P, 3), **f)
+    g_opacity = torch.empty((P, 1), **f); g_cov3D = torch.empty((P, 6), **f); g_sh = torch.empty((P, M, 3), **f)
+    g_scales = torch.empty((P, 3), **f); g_rot = torch.empty((P, 4), **f); g_v2g = torch.empty((P, 10), **f)
+    if P != 0:
+        dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
+        with torch.cuda.device(dev):
+            nscratch = lib.gof_backward_scratch_bytes(P)
+            scratch = v.bytes_tensor(nscratch) if nscratch else None
+            _check(lib.gof_backward(v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                                    binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),
+                                    _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D),
+                                    _ptr(g_sh), _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g),
+                                    _ptr(scratch), nscratch, _stream()))
+    return g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_v2g
+
+
+def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                  cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                  kernel_size, subpixel_offset, image_height, image_width, sh, degree, campos,
+                                  prefiltered, debug):
+    """Replaces ``_C.integrate_gaussians_to_points`` (IntegrateGaussiansToPointsCUDA, rasterize_points.cu:234-343).
+    Returns ``(num_rendered, out_color, out_alpha_integrated, out_color_integrated, radii, geomBuffer,
+    binningBuffer, imgBuffer)``."""
+    if points3D.dim() != 2 or points3D.size(1) != 3:
+        raise RuntimeError("points3D must have dimensions (num_points, 3)")
+    v = _View(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, view2gaussian_precomp,
+              viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh,
+              degree, campos, prefiltered, debug)
+    dev = v.device
+    PN = int(points3D.size(0))
+    pts = _dev_f32(points3D, dev, "points3D")
+    f = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        out_color = torch.zeros((OUTPUT_CHANNELS, v.H, v.W), **f)
+        out_alpha = torch.ones((PN,), **f)            # rasterize_points.cu:277
+        out_color_pts = torch.zeros((PN, 3), **f)     # rasterize_points.cu:278
+        radii = torch.zeros(v.P, dtype=torch.int32, device=dev)
+        empty = v.bytes_tensor(0)
+        if v.P == 0 or PN == 0:
+            return 0, out_color, out_alpha, out_color_pts, radii, empty, empty.clone(), empty.clone()
+        geom, img, binning, radii, rendered = _prepare_and_bin(v)
+        pws = v.bytes_tensor(lib.gof_point_bytes(PN))
+        ni = C.c_uint32(0)
+        _check(lib.gof_integrate_prepare_points(v.ref(), PN, _ptr(pts), _ptr(pws), pws.numel(), C.byref(ni), _stream()))
+        pbin = v.bytes_tensor(lib.gof_binning_bytes(int(ni.value), v.W, v.H))
+        _check(lib.gof_integrate_run(v.ref(), rendered, _ptr(radii), PN, int(ni.value), _ptr(geom), geom.numel(),
+                                     _ptr(binning), binning.numel(), _ptr(img), img.numel(), _ptr(pws), pws.numel(),
+                                     _ptr(pbin), pbin.numel(), _ptr(out_color), _ptr(out_alpha), _ptr(out_color_pts), _stream()))
+    return rendered, out_color, out_alpha, out_color_pts, radii, geom, binning, img
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """Replaces ``_C.mark_visible`` (rasterize_points.cu:213-232)."""
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros(P, dtype=torch.bool, device=dev)
+    if P:
+        m = _dev_f32(means3D, dev, "means3D"); vm = _dev_f32(viewmatrix, dev, "viewmatrix"); pm = _dev_f32(projmatrix, dev, "projmatrix")
+        with torch.cuda.device(dev):
+            _check(lib.gof_mark_visible(P, _ptr(m), _ptr(vm), _ptr(pm), C.c_void_p(present.data_ptr()), _stream()))
+    return present
+
+
+_FETCH = {"depths": (torch.float32, 1), "means2D": (torch.float32, 2), "conic_opacity": (torch.float32, 4), "rgb": (torch.float32, 3),
+          "view2gaussian": (torch.float32, 10), "tiles_touched": (torch.int32, 1), "point_offsets": (torch.int32, 1),
+          "clamped": (torch.uint8, 3), "point_list": (torch.int32, 0), "point_list_keys": (torch.int64, 0),
+          "ranges": (torch.int32, 0), "point_ranges": (torch.int32, 0), "final_T": (torch.float32, 0), "n_contrib": (torch.int32, 0)}
+
+
+def debug_fetch(name, view, num_rendered, geom, binning, img):
+    """Test/benchmark helper: copy a named intermediate out of the opaque workspaces (gof_debug_fetch)."""
+    dtype, per = _FETCH[name]
+    P, HW = view.P, view.H * view.W
+    T = ((view.W + 15) // 16) * ((view.H + 15) // 16)
+    count = {"point_list": num_rendered, "point_list_keys": num_rendered, "ranges": 2 * T, "point_ranges": 2 * T,
+             "final_T": 4 * HW, "n_contrib": 2 * HW}.get(name, P * per)
+    out = torch.empty(count, dtype=dtype, device=view.device)
+    n = lib.gof_debug_fetch(name.encode(), view.ref(), int(num_rendered), _ptr(geom), _ptr(binning), _ptr(img),
+                            C.c_void_p(out.data_ptr()), out.numel() * out.element_size(), _stream())
+    if n < 0:
+        _check(int(n))
+    return out

@@ -102,6 +102,7 @@ int gof_forward_prepare(const GofRasterArgs* args,
  * every channel is written. */
 int gof_forward_render(const GofRasterArgs* args,
                        uint32_t num_rendered,
+                       const int32_t* radii,          /* [P] as written by gof_forward_prepare */
                        void* geom_ws, size_t geom_bytes,
                        void* binning_ws, size_t binning_bytes,
                        void* image_ws, size_t image_bytes,
@@ -109,6 +110,8 @@ int gof_forward_render(const GofRasterArgs* args,
                        void* stream);
 
 /* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
+/* Scratch the backward needs besides the outputs (accumulators); may be 0. */
+size_t gof_backward_scratch_bytes(int32_t P);
 /* dL_dout is [9,H,W].  All gradient outputs are fully written by the call (the library
  * zero-fills them itself; the reference binding allocates them with torch::zeros,
  * rasterize_points.cu:161-170).  dL_dcov3D [P,6] is all zero in the reference (its producer
@@ -129,6 +132,7 @@ int gof_backward(const GofRasterArgs* args,
                  float* dL_dscales,         /* [P,3]  */
                  float* dL_drotations,      /* [P,4]  */
                  float* dL_dview2gaussian,  /* [P,10] */
+                 void* scratch, size_t scratch_bytes,  /* gof_backward_scratch_bytes(P); NULL if 0 */
                  void* stream);
 
 /* ---- integrate (replaces _C.integrate_gaussians_to_points, rasterize_points.cu:234-343) - */
@@ -147,6 +151,7 @@ int gof_integrate_prepare_points(const GofRasterArgs* args,
  * be zero-filled by the caller (channels 3-5 are never written, forward.cu:1002-1007). */
 int gof_integrate_run(const GofRasterArgs* args,
                       uint32_t num_rendered,
+                      const int32_t* radii,           /* [P] as written by gof_forward_prepare */
                       int32_t PN, uint32_t num_integrated,
                       void* geom_ws, size_t geom_bytes,
                       void* binning_ws, size_t binning_bytes,

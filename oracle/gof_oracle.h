@@ -24,6 +24,10 @@ int gofref_forward(const GofRasterArgs* a, float* out_color, int32_t* radii, Gof
 int gofref_backward(const GofRasterArgs* a, const GofRefState* s, const float* dL_dout,
                     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
                     float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian);
+/* the per-Gaussian backward stage alone (backward.cu:593-631) on given dL_dview2gaussian / dL_dcolors;
+ * outputs must be zero-initialised by the caller */
+int gofref_preprocess_backward(const GofRasterArgs* a, const GofRefState* s, const float* dL_dview2gaussian,
+                               const float* dL_dcolors, float* dL_dmeans3D, float* dL_dsh, float* dL_dscales, float* dL_drotations);
 /* integrate (rasterize_points.cu:234-343 + rasterizer_impl.cu:530-792) */
 int gofref_integrate(const GofRasterArgs* a, int32_t PN, const float* points3D,
                      float* out_color, float* out_alpha_integrated, float* out_color_integrated,

@@ -49,6 +49,7 @@ def lib():
         L.gofref_expf.argtypes = [C.c_float]
         L.gofref_forward.argtypes = [C.POINTER(GofRasterArgs), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gofref_backward.argtypes = [C.POINTER(GofRasterArgs), C.c_void_p] + [C.c_void_p] * 10
+        L.gofref_preprocess_backward.argtypes = [C.POINTER(GofRasterArgs), C.c_void_p] + [C.c_void_p] * 6
         L.gofref_integrate.argtypes = [C.POINTER(GofRasterArgs), C.c_int32] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p)]
         L.gofref_mark_visible.argtypes = [C.c_int32] + [C.c_void_p] * 4
         L.gofref_free.argtypes = [C.c_void_p]
@@ -165,6 +166,16 @@ class OracleScene:
         self._check(lib().gofref_backward(C.byref(self.args), self.state, _p(d), _p(g["means2D"]), _p(g["colors"]), _p(g["opacity"]),
                                           _p(g["means3D"]), _p(g["cov3D"]), _p(g["sh"]) if M else None, _p(g["scales"]),
                                           _p(g["rotations"]), _p(g["view2gaussian"])))
+        return g
+
+    def preprocess_backward(self, dL_dview2gaussian, dL_dcolors):
+        """K9 alone on given inputs -> dict(means3D, sh, scales, rotations)."""
+        P, M = self.P, self.M
+        g = dict(means3D=np.zeros((P, 3), np.float32), sh=np.zeros((P, M, 3), np.float32),
+                 scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
+        dv = _f32(dL_dview2gaussian); dc = _f32(dL_dcolors)
+        self._check(lib().gofref_preprocess_backward(C.byref(self.args), self.state, _p(dv), _p(dc), _p(g["means3D"]),
+                                                     _p(g["sh"]) if M else None, _p(g["scales"]), _p(g["rotations"])))
         return g
 
     def integrate(self, points3D):

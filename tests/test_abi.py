@@ -1,0 +1,63 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/gof_hip.h declares;
+host-only size queries behave."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gof_hip.h")
+LIB = os.path.join(ROOT, "gaussian-opacity-fields_amd", "lib", "libgof_hip.so")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gof_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exists_and_loads():
+    assert os.path.exists(LIB), "build with python gaussian-opacity-fields_amd/build.py"
+    ctypes.CDLL(LIB)
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ctypes.CDLL(LIB)
+    names = declared_functions()
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_size_queries_are_host_only_and_monotone():
+    from diff_gaussian_rasterization import _backend as B
+    L = B.lib
+    assert L.gof_abi_version() >= 1
+    assert L.gof_geom_bytes(0) > 0
+    assert L.gof_geom_bytes(1000) < L.gof_geom_bytes(100000)
+    assert L.gof_geom_bytes(1_000_000) >= 1_000_000 * (64 + 16 + 4 + 4 + 4 + 1)
+    assert L.gof_image_bytes(1600, 1063) >= 1600 * 1063 * 24
+    assert L.gof_binning_bytes(0, 400, 400) > 0
+    assert L.gof_binning_bytes(5_000_000, 1600, 1063) >= 5_000_000 * 24
+    assert L.gof_point_bytes(10) < L.gof_point_bytes(10_000_000)
+
+
+def test_struct_layout_matches_header():
+    """The ctypes mirrors (product binding and oracle binding) agree with each other and with the
+    field list of the header."""
+    from diff_gaussian_rasterization import _backend as B
+    import oracle_binding as ob
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct GofRasterArgs {"):src.index("} GofRasterArgs;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.replace("*", " ").split(",")
+        first = names[0].split()[-1]
+        fields.append(first)
+        fields.extend(n.strip() for n in names[1:])
+    assert [f[0] for f in B.GofRasterArgs._fields_] == fields
+    assert [f[0] for f in ob.GofRasterArgs._fields_] == fields
+    assert ctypes.sizeof(B.GofRasterArgs) == ctypes.sizeof(ob.GofRasterArgs) == 11 * 4 + 4 + 13 * 8

@@ -1,0 +1,75 @@
+"""CPU-only, world_size 2, gloo: the data-parallel exchange step (gradient all-reduce, densification
+statistics, view sharding) -- the N>1 path of bench.py / training."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-opacity-fields_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dp import GradientAllReducer, shard_views
+    from dp.reducer import all_reduce_densification_stats
+    P = 257
+    g = torch.Generator().manual_seed(100)              # identical parameters on every rank (replica)
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4)]   # the 6 param groups, 59 floats / Gaussian
+    params = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    gr = torch.Generator().manual_seed(200 + rank)      # different view -> different gradients
+    local = [torch.randn(s, generator=gr) for s in shapes]
+    for p, l in zip(params, local):
+        p.grad = l.clone()
+    params[3].grad = None if False else params[3].grad   # all present
+    red = GradientAllReducer(params)
+    red.all_reduce()
+    expect = []
+    for s_i, s in enumerate(shapes):
+        tot = torch.zeros(s)
+        for r in range(world):
+            gg = torch.Generator().manual_seed(200 + r)
+            ls = [torch.randn(sh, generator=gg) for sh in shapes]
+            tot += ls[s_i]
+        expect.append(tot)
+    ok = all(torch.allclose(p.grad, e, atol=1e-6) for p, e in zip(params, expect))
+    # mean variant + a parameter without gradient is skipped
+    for p, l in zip(params, local):
+        p.grad = l.clone()
+    params[1].grad = None
+    GradientAllReducer(params, average=True).all_reduce()
+    ok = ok and params[1].grad is None and torch.allclose(params[0].grad, expect[0] / world, atol=1e-6)
+    # densification statistics
+    acc = torch.full((P, 1), float(rank + 1)); acc_abs = acc.clone(); denom = torch.ones(P, 1)
+    radii = torch.full((P,), float(rank)); absmax = torch.full((P, 1), float(10 - rank))
+    all_reduce_densification_stats(acc, acc_abs, denom, radii, absmax)
+    ok = ok and float(acc[0]) == sum(range(1, world + 1)) and float(denom[0]) == world and float(radii[0]) == world - 1 and float(absmax[0]) == 10
+    views = list(range(10))
+    mine = shard_views(views, rank, world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    ok = ok and sorted(sum(gathered, [])) == views and len(set(map(tuple, gathered))) == world
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
