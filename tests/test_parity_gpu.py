@@ -194,7 +194,7 @@ def test_integrate_matches_oracle():
     pts = S.tetra_points(sc)
     rng = np.random.default_rng(0)
     # pile > 256 points into one pixel (exercises the reference's outer while loop) and add far / behind points
-    pile = np.tile(np.array([[0.0, 0.0, 5.0]], np.float32), (300, 1)) + rng.normal(0, 1e-3, (300, 3)).astype(np.float32)
+    pile = np.tile(np.array([[0.5 * 5.0 / 70.0, 0.5 * 5.0 / 70.0, 5.0]], np.float32), (300, 1))   # centre of pixel (48, 32) + rng.normal(0, 1e-3, (300, 3)).astype(np.float32)
     pts = np.concatenate([pts, pile, np.array([[0, 0, -1.0], [50, 0, 1.0]], np.float32)]).astype(np.float32)
     o = ob.OracleScene(sc)
     oc, oal, ocol, orad = o.integrate(pts)
