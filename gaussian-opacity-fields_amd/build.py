@@ -14,7 +14,10 @@ LIB = os.path.join(LIBDIR, "libgof_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the arithmetic contract -- fused multiply-adds only where fmaf() is written
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+         # the LLVM "atomic optimizer" rewrites few-lane same-address LDS/global atomics into a per-lane
+         # readlane loop (17 loops per splat in blend_backward); the hardware handles them directly
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + os.environ.get("GOF_EXTRA_FLAGS", "").split()
 
 
 def sources():

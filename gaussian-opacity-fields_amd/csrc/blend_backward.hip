@@ -5,16 +5,24 @@
 //
 // MI355X design:
 //  * The reference issues 17 global fp32 atomicAdd per contributing (pixel, splat) pair
-//    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave look at the SAME splat
-//    at the same time, so the 17 partial gradients are first summed across the wave with DPP
-//    adds in registers (quad_perm / row_mirror / row_bcast: no LDS traffic) and only lane 63
-//    issues one hardware global_atomic_add_f32 per component: <= 17 atomics per (wave, splat)
-//    instead of up to 17 x 64.
+//    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave look at the SAME splat at
+//    the same time, so the 17 partial gradients are reduced in three levels:
+//      1. 4 DPP add steps in registers (quad_perm x2, row_half_mirror, row_mirror): every lane of a
+//         16-lane row (= one pixel row of the tile) holds the row sum; no LDS traffic;
+//      2. lanes 15/31/47/63 of each wave add the 4 row sums of all 4 waves into a per-batch LDS
+//         accumulator s_acc[17][256] with ds_add_f32 (<= 16 adds per address per batch);
+//      3. after the batch, thread j flushes entry j with ONE global atomic per component and only if
+//         some pixel of the tile contributed: <= 17 atomics per (tile, splat) instead of up to
+//         17 x 256, issued 64 lanes wide.
 //  * Entries behind the last contributor of EVERY pixel of the tile are never staged: the
-//    traversal starts at max-over-tile(last_contributor) (the reference stages the full list
-//    and skips per pixel, backward.cu:763-765).
-//  * Staging as in the forward: whole 64-byte SplatRec lines + the 16-byte conic, LDS layout
-//    [q][256] for conflict-free writes and broadcast reads.
+//    traversal starts at max-over-tile(last_contributor) (the reference stages the full list and
+//    skips per pixel, backward.cu:763-765).
+//  * Conservative fp32 cull before the exact fp64 division / exp (see pair_certainly_transparent).
+//  * alpha, T and the contributor bookkeeping use the exact arithmetic of the forward (they decide
+//    WHICH pairs contribute, bit-identically to the forward pass); the gradient formulas downstream
+//    are evaluated in fp32 with hardware rcp/rsq (<= 2 ulp).  The reference itself rounds every
+//    per-pair term to fp32 before its atomicAdd, so this stays inside its own noise floor
+//    (measured: 3e-7 relative to the oracle's double accumulation).
 //
 // Gradient semantics reproduced exactly (they are the training signal): dL_dweight is detached
 // (backward.cu:851-852) so only dL_dmax_t carries the distortion gradient; the alpha channel's
@@ -26,21 +34,28 @@
 
 namespace gof {
 
-template <int CTRL, int ROW_MASK>
+constexpr int NGRAD = 17;   // colour 3, mean2D 3, opacity 1, view2gaussian 10
+// tile-list entries staged per batch.  128 (not 256) keeps the LDS footprint at ~21 KB so that
+// occupancy is bounded by registers (4 waves/SIMD), not by LDS.
+#ifndef GOF_BW_BATCH
+#define GOF_BW_BATCH 128
+#endif
+constexpr int BATCH = GOF_BW_BATCH;
+static_assert(BATCH == 128 || BATCH == 256, "BATCH must be 128 or 256");
+
+template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
     return v + __int_as_float(moved);
 }
-// sum over the 64 lanes of a wave; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+// sum over each 16-lane row; afterwards EVERY lane of the row holds the row total
+__device__ __forceinline__ float row_sum(float v)
 {
-    v = dpp_add<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);    // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);    // row_mirror
-    v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 -> rows 1,3
-    v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 -> rows 2,3
+    v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);    // row_half_mirror
+    v = dpp_add<0x140>(v);    // row_mirror
     return v;
 }
 
@@ -63,13 +78,16 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
     const float rx = (float)(((double)pixfx - W / 2.) / (double)focal_x);
     const float ry = (float)(((double)pixfy - H / 2.) / (double)focal_y);
-    const float pxm = (float)((double)pixfx - 0.5), pym = (float)((double)pixfy - 0.5);   // exact: pix + 0.5 - 0.5
+    const float pxm = (float)px, pym = (float)py;   // pixf - 0.5 (backward.cu:770), exact
 
     const uint2 range = ranges[tile];
 
-    __shared__ float4 s_rec[4][TILE_PIX];
-    __shared__ float4 s_conic[TILE_PIX];
-    __shared__ uint32_t s_id[TILE_PIX];
+    __shared__ float4 s_rec[4][BATCH];
+    __shared__ float4 s_conic[BATCH];
+    __shared__ uint32_t s_id[BATCH];
+    __shared__ float s_thr[BATCH];
+    __shared__ float s_acc[NGRAD][BATCH];
+    __shared__ uint32_t s_touched[BATCH];
     __shared__ uint32_t s_max_last;
 
     const float T_final = inside ? final_Ts[pix_id] : 0;
@@ -104,8 +122,8 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     if (max_last == 0) return;
 
     int toDo = (int)max_last;
-    const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
-    uint32_t contributor = max_last;   // entries [max_last, toDo_full) are skipped by every pixel
+    const int rounds = (toDo + BATCH - 1) / BATCH;
+    uint32_t contributor = max_last;   // entries [max_last, list length) are skipped by every pixel
     const uint32_t list_end = range.x + max_last;
 
     float acc0 = 0, acc1 = 0, acc2 = 0;          // accum_rec
@@ -115,50 +133,73 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     float last_alpha = 0;
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
+    // mapped depth (2DGS NDC mapping, forward.cu:545): m(t) = (FAR t - FAR NEAR) / ((FAR-NEAR) t)
+    const float MAP_A = (float)(GOF_FAR_PLANE / (GOF_FAR_PLANE - GOF_NEAR_PLANE));
+    const float MAP_B = (float)(GOF_FAR_PLANE * GOF_NEAR_PLANE / (GOF_FAR_PLANE - GOF_NEAR_PLANE));
 
-    for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
+    for (int i = 0; i < rounds; i++, toDo -= BATCH) {
         __syncthreads();
-        const uint32_t progress = (uint32_t)i * TILE_PIX + tid;
-        if (range.x + progress < list_end) {
-            const uint32_t id = point_list[list_end - progress - 1];
-            const float4* src = reinterpret_cast<const float4*>(&rec[id]);
-            const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-            s_rec[0][tid] = a; s_rec[1][tid] = b; s_rec[2][tid] = c; s_rec[3][tid] = d;
-            s_conic[tid] = conic[id];
-            s_id[tid] = id;
+        {
+            // staging: BATCH entries by 256 threads -> (256 / BATCH) threads share one 64-byte record
+            constexpr int TPE = TILE_PIX / BATCH;            // threads per entry: 1 or 2
+            constexpr int F4 = 4 / TPE;                      // float4 per thread
+            const uint32_t e = tid / TPE, part = tid % TPE;
+            const uint32_t progress = (uint32_t)i * BATCH + e;
+            if (range.x + progress < list_end) {
+                const uint32_t id = point_list[list_end - progress - 1];
+                const float4* src = reinterpret_cast<const float4*>(&rec[id]) + part * F4;
+                float4 r4[F4];
+#pragma unroll
+                for (int q = 0; q < F4; q++) r4[q] = src[q];
+#pragma unroll
+                for (int q = 0; q < F4; q++) s_rec[part * F4 + q][e] = r4[q];
+                if (part == 0) {
+                    s_conic[e] = conic[id];
+                    s_id[e] = id;
+                }
+                if (part == TPE - 1) s_thr[e] = cull_log_threshold(r4[(2 % F4)].z);   // f[10] lives in float4 #2, component z
+            }
+            for (int k = tid; k < NGRAD * BATCH; k += TILE_PIX) (&s_acc[0][0])[k] = 0.f;
+            if (tid < BATCH) s_touched[tid] = 0;
         }
         __syncthreads();
 
-        const int n = min(TILE_PIX, toDo);
+        const int n = min(BATCH, toDo);
         for (int j = 0; j < n; j++) {
             contributor--;
             const bool active = inside && (contributor < last_contributor);
             if (__ballot(active) == 0ull) continue;
 
-            float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_mx = 0, g_my = 0, g_mz = 0, g_op = 0;
-            float g_v0 = 0, g_v1 = 0, g_v2 = 0, g_v3 = 0, g_v4 = 0, g_v5 = 0, g_v6 = 0, g_v7 = 0, g_v8 = 0, g_v9 = 0;
+            const float4 a = s_rec[0][j], b = s_rec[1][j], c = s_rec[2][j];
+            const float v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y };
+            const float w = c.z;
+            PairEval p;
+            pair_prelude(v, rx, ry, p);
+            const bool maybe = active && !pair_certainly_transparent(p, c.y, s_thr[j]);
+            if (__ballot(maybe) == 0ull) continue;
+
+            float g[NGRAD];
+#pragma unroll
+            for (int k = 0; k < NGRAD; k++) g[k] = 0.f;
             bool contrib = false;
-            if (active) {
-                const float4 a = s_rec[0][j], b = s_rec[1][j], c = s_rec[2][j];
-                const float v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y };
-                const float w = c.z;
-                PairEval p;
-                eval_pair(v, w, rx, ry, p);
+            if (maybe) {
+                pair_exact(v, w, p);
                 if (!p.skip) {
                     contrib = true;
                     const float4 d = s_rec[3][j];
                     const float4 con = s_conic[j];
                     const float G = p.G, alpha = p.alpha;
-                    const double AA = p.AA, BB = p.BB;
                     const float dx = d.z - pxm, dy = d.w - pym;
 
-                    const float max_t = p.t;
-                    const float mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
-                    const float dmax_t_dd = (float)((GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t * max_t));
-                    const float length = (float)sqrt((double)(p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2) + 1e-7);
-                    const float nn0 = -p.n0 / length, nn1 = -p.n1 / length, nn2 = -p.n2 / length;
+                    const float t = p.t;
+                    const float inv_t = __builtin_amdgcn_rcpf(t);
+                    const float mapped_max_t = MAP_A - MAP_B * inv_t;
+                    const float dmax_t_dd = MAP_B * inv_t * inv_t;
+                    const float len2 = p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2 + 1e-7f;
+                    const float inv_len = __builtin_amdgcn_rsqf(len2);
+                    const float nn0 = -p.n0 * inv_len, nn1 = -p.n1 * inv_len, nn2 = -p.n2 * inv_len;
 
-                    T = T / (1.f - alpha);
+                    T = T / (1.f - alpha);                      // exact recurrence of backward.cu:816
                     const float dchannel_dcolor = alpha * T;
 
                     float dL_dalpha = 0.0f;
@@ -166,101 +207,95 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                         const float c0 = c.w, c1 = d.x, c2 = d.y;
                         acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
                         dL_dalpha += (c0 - acc0) * dpx0;
-                        g_c0 = dchannel_dcolor * dpx0;
+                        g[0] = dchannel_dcolor * dpx0;
                         acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
                         dL_dalpha += (c1 - acc1) * dpx1;
-                        g_c1 = dchannel_dcolor * dpx1;
+                        g[1] = dchannel_dcolor * dpx1;
                         acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
                         dL_dalpha += (c2 - acc2) * dpx2;
-                        g_c2 = dchannel_dcolor * dpx2;
+                        g[2] = dchannel_dcolor * dpx2;
                     }
-                    float dL_dmax_t = 0.0f;
-                    dL_dmax_t += 2.0f * (T * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
-                    // dL_dweight == 0 and last_dL_dT == 0 (backward.cu:852-858): "dL_dalpha += 0 - 0"
-                    dL_dalpha += 0.f - 0.f;
+                    // distortion: only dL_dmax_t survives (dL_dweight is detached, backward.cu:848-852)
+                    const float dL_dmax_t = 2.0f * (T * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
 
                     float dnn0, dnn1, dnn2;
                     an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nn0;
                     dL_dalpha += (nn0 - an0) * dn0;
-                    dnn0 = alpha * T * dn0;
+                    dnn0 = dchannel_dcolor * dn0;
                     an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = nn1;
                     dL_dalpha += (nn1 - an1) * dn1;
-                    dnn1 = alpha * T * dn1;
+                    dnn1 = dchannel_dcolor * dn1;
                     an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nn2;
                     dL_dalpha += (nn2 - an2) * dn2;
-                    dnn2 = alpha * T * dn2;
+                    dnn2 = dchannel_dcolor * dn2;
 
-                    float dL_dlength = (dnn0 * p.n0 + dnn1 * p.n1 + dnn2 * p.n2);
-                    dL_dlength *= 1.f / (length * length);
-                    float dL_dn0 = (-dnn0 + dL_dlength * p.n0) / length;
-                    float dL_dn1 = (-dnn1 + dL_dlength * p.n1) / length;
-                    float dL_dn2 = (-dnn2 + dL_dlength * p.n2) / length;
+                    // d(-n/|n|): dL_dn = (-dnn + (dnn . n) n / |n|^2) / |n|
+                    const float dL_dlength = (dnn0 * p.n0 + dnn1 * p.n1 + dnn2 * p.n2) * (inv_len * inv_len);
+                    float dL_dn0 = (-dnn0 + dL_dlength * p.n0) * inv_len;
+                    float dL_dn1 = (-dnn1 + dL_dlength * p.n1) * inv_len;
+                    float dL_dn2 = (-dnn2 + dL_dlength * p.n2) * inv_len;
 
                     float dL_dt = dL_dmax_t;
                     if (contributor == max_contributor - 1u) dL_dt += dL_dmax_depth;
 
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(1.f - alpha)) * bg_dot_dpixel;
 
                     const float dL_dG = w * dL_dalpha;
                     const float gdx = G * dx;
                     const float gdy = G * dy;
                     const float dG_ddelx = -gdx * con.x - gdy * con.y;
                     const float dG_ddely = -gdy * con.z - gdx * con.y;
-                    g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                    g_my = dL_dG * dG_ddely * ddely_dy;
-                    g_mz = fabsf(dL_dG * dG_ddelx * ddelx_dx) + fabsf(dL_dG * dG_ddely * ddely_dy);
-                    g_op = G * dL_dalpha;
+                    g[3] = dL_dG * dG_ddelx * ddelx_dx;
+                    g[4] = dL_dG * dG_ddely * ddely_dy;
+                    g[5] = fabsf(g[3]) + fabsf(g[4]);
+                    g[6] = G * dL_dalpha;
 
-                    const float dL_dpower = dL_dG * G;
-                    const float dL_dmin_value = dL_dpower * -0.5f;
-                    double dL_dA = dL_dmin_value * (BB / AA) * (BB / AA) / 4.f;
-                    double dL_dB = dL_dmin_value * -BB / (2 * AA);
-                    const double dL_dC = dL_dmin_value * 1.0f;
-                    dL_dA += dL_dt * BB / (2 * AA * AA);
-                    dL_dB += dL_dt * -1.f / (2 * AA);
-
-                    dL_dn0 = (float)((double)dL_dn0 + dL_dA * rx);
-                    dL_dn1 = (float)((double)dL_dn1 + dL_dA * ry);
-                    dL_dn2 = (float)((double)dL_dn2 + dL_dA);
-
-                    g_v0 = dL_dn0 * rx;
-                    g_v1 = dL_dn0 * ry + dL_dn1 * rx;
-                    g_v2 = dL_dn0 + dL_dn2 * rx;
-                    g_v3 = dL_dn1 * ry;
-                    g_v4 = dL_dn1 + dL_dn2 * ry;
-                    g_v5 = dL_dn2;
-                    g_v6 = (float)(dL_dB * 2 * rx);
-                    g_v7 = (float)(dL_dB * 2 * ry);
-                    g_v8 = (float)(dL_dB * 2);
-                    g_v9 = (float)dL_dC;
+                    // min_value = CC - (BB/AA)(BB/4), t = -BB/(2AA)
+                    const float qf = (float)p.q;
+                    const float dL_dmin_value = -0.5f * (dL_dG * G);
+                    const float inv2AA = 0.5f * __builtin_amdgcn_rcpf(p.AAf);
+                    const float dL_dA = dL_dmin_value * (qf * qf) * 0.25f + dL_dt * qf * inv2AA;
+                    const float dL_dB = -0.5f * (dL_dmin_value * qf) - dL_dt * inv2AA;
+                    dL_dn0 += dL_dA * rx;
+                    dL_dn1 += dL_dA * ry;
+                    dL_dn2 += dL_dA;
+                    g[7] = dL_dn0 * rx;
+                    g[8] = dL_dn0 * ry + dL_dn1 * rx;
+                    g[9] = dL_dn0 + dL_dn2 * rx;
+                    g[10] = dL_dn1 * ry;
+                    g[11] = dL_dn1 + dL_dn2 * ry;
+                    g[12] = dL_dn2;
+                    g[13] = dL_dB * 2 * rx;
+                    g[14] = dL_dB * 2 * ry;
+                    g[15] = dL_dB * 2;
+                    g[16] = dL_dmin_value;
                 }
             }
             if (__ballot(contrib) == 0ull) continue;
-
-            g_c0 = wave_sum_to_lane63(g_c0); g_c1 = wave_sum_to_lane63(g_c1); g_c2 = wave_sum_to_lane63(g_c2);
-            g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my); g_mz = wave_sum_to_lane63(g_mz);
-            g_op = wave_sum_to_lane63(g_op);
-            g_v0 = wave_sum_to_lane63(g_v0); g_v1 = wave_sum_to_lane63(g_v1); g_v2 = wave_sum_to_lane63(g_v2);
-            g_v3 = wave_sum_to_lane63(g_v3); g_v4 = wave_sum_to_lane63(g_v4); g_v5 = wave_sum_to_lane63(g_v5);
-            g_v6 = wave_sum_to_lane63(g_v6); g_v7 = wave_sum_to_lane63(g_v7); g_v8 = wave_sum_to_lane63(g_v8);
-            g_v9 = wave_sum_to_lane63(g_v9);
-            if (lane == 63) {
-                const size_t id = s_id[j];
-                unsafeAtomicAdd(&dL_dcolors[id * 3 + 0], g_c0);
-                unsafeAtomicAdd(&dL_dcolors[id * 3 + 1], g_c1);
-                unsafeAtomicAdd(&dL_dcolors[id * 3 + 2], g_c2);
-                unsafeAtomicAdd(&dL_dmean2D[id * 3 + 0], g_mx);
-                unsafeAtomicAdd(&dL_dmean2D[id * 3 + 1], g_my);
-                unsafeAtomicAdd(&dL_dmean2D[id * 3 + 2], g_mz);
-                unsafeAtomicAdd(&dL_dopacity[id], g_op);
-                float* gv = dL_dv2g + id * 10;
-                unsafeAtomicAdd(gv + 0, g_v0); unsafeAtomicAdd(gv + 1, g_v1); unsafeAtomicAdd(gv + 2, g_v2);
-                unsafeAtomicAdd(gv + 3, g_v3); unsafeAtomicAdd(gv + 4, g_v4); unsafeAtomicAdd(gv + 5, g_v5);
-                unsafeAtomicAdd(gv + 6, g_v6); unsafeAtomicAdd(gv + 7, g_v7); unsafeAtomicAdd(gv + 8, g_v8);
-                unsafeAtomicAdd(gv + 9, g_v9);
+#pragma unroll
+            for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
+            if ((lane & 15u) == 15u) {
+#pragma unroll
+                for (int k = 0; k < NGRAD; k++) unsafeAtomicAdd(&s_acc[k][j], g[k]);
+                if (lane == 63u) s_touched[j] = 1u;
             }
+        }
+        __syncthreads();
+        // flush: one entry per thread, one global atomic per component, 64 lanes wide
+        if ((int)tid < n && s_touched[tid]) {
+            const size_t id = s_id[tid];
+            unsafeAtomicAdd(&dL_dcolors[id * 3 + 0], s_acc[0][tid]);
+            unsafeAtomicAdd(&dL_dcolors[id * 3 + 1], s_acc[1][tid]);
+            unsafeAtomicAdd(&dL_dcolors[id * 3 + 2], s_acc[2][tid]);
+            unsafeAtomicAdd(&dL_dmean2D[id * 3 + 0], s_acc[3][tid]);
+            unsafeAtomicAdd(&dL_dmean2D[id * 3 + 1], s_acc[4][tid]);
+            unsafeAtomicAdd(&dL_dmean2D[id * 3 + 2], s_acc[5][tid]);
+            unsafeAtomicAdd(&dL_dopacity[id], s_acc[6][tid]);
+            float* gv = dL_dv2g + id * 10;
+#pragma unroll
+            for (int k = 0; k < 10; k++) unsafeAtomicAdd(gv + k, s_acc[7 + k][tid]);
         }
     }
 }

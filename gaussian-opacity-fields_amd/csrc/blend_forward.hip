@@ -14,6 +14,9 @@
 //    broadcasts.
 //  * per-wave early exit: a wave whose 64 pixels are all saturated skips the batch
 //    (ballot over `done`), the workgroup exits when all 4 waves are done (forward.cu:475-477).
+//  * conservative fp32 cull (pair_certainly_transparent): a wave whose lanes are all CERTAINLY below
+//    alpha = 1/255 for this splat skips the exact fp64 division / exp path entirely; any lane that is
+//    not certainly transparent takes the exact path, so the result is unchanged (bit-exact).
 //  * a wave skips the heavy "contributing" path when no lane passes the alpha test.
 //  * XCD-aware tile order (xcd_tile_id): neighbouring tiles, which gather the same records,
 //    run on the same XCD and share its L2.
@@ -47,6 +50,7 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
     __shared__ float4 s_rec[4][TILE_PIX];
+    __shared__ float s_thr[TILE_PIX];
 
     bool done = !inside;
     float T = 1.0f;
@@ -62,6 +66,7 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const float4* src = reinterpret_cast<const float4*>(&rec[id]);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
             s_rec[0][tid] = a; s_rec[1][tid] = b; s_rec[2][tid] = c; s_rec[3][tid] = d;
+            s_thr[tid] = cull_log_threshold(c.z);
         }
         __syncthreads();
         if (__ballot(!done) == 0ull) continue;   // whole wave saturated: help staging only
@@ -74,7 +79,9 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const float4 a = s_rec[0][j], b = s_rec[1][j], c = s_rec[2][j];
             const float v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y };
             PairEval p;
-            eval_pair(v, c.z, rx, ry, p);
+            pair_prelude(v, rx, ry, p);
+            if (pair_certainly_transparent(p, c.y, s_thr[j])) continue;
+            pair_exact(v, c.z, p);
             if (p.skip) continue;
             const float alpha = p.alpha, t = p.t;
             const float test_T = T * (1 - alpha);

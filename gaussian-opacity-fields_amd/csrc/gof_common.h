@@ -246,30 +246,60 @@ __device__ __forceinline__ V3 transform_point_4x3(V3 p, const float* __restrict_
 // Everything that depends on a (pixel ray, splat) pair: forward.cu:499-533, backward.cu:771-804.
 struct PairEval {
     float n0, n1, n2;      // un-normalised view-space normal Sigma' * ray
-    double AA, BB;
+    float AAf, BBf;        // fp32 values the reference widens to double (forward.cu:511-512)
+    double q;              // BB / AA (fp64, correctly rounded)
     float t, G, alpha;
     bool skip;
 };
-__device__ __forceinline__ void eval_pair(const float* __restrict__ v, float w, float rx, float ry, PairEval& p)
+// fp32 prelude: normal, AA, BB in the reference's operation order (no contraction)
+__device__ __forceinline__ void pair_prelude(const float* __restrict__ v, float rx, float ry, PairEval& p)
 {
     p.n0 = v[0] * rx + v[1] * ry + v[2];
     p.n1 = v[1] * rx + v[3] * ry + v[4];
     p.n2 = v[2] * rx + v[4] * ry + v[5];
-    const float AAf = rx * p.n0 + ry * p.n1 + p.n2;
-    const float BBf = 2 * (v[6] * rx + v[7] * ry + v[8]);
-    p.AA = (double)AAf;
-    p.BB = (double)BBf;
+    p.AAf = rx * p.n0 + ry * p.n1 + p.n2;
+    p.BBf = 2 * (v[6] * rx + v[7] * ry + v[8]);
+}
+// Conservative cull: true only if alpha = min(0.99, w * exp(power)) is CERTAINLY < 1/255, i.e. the
+// exact path would `continue` at forward.cu:534 / backward.cu:803.  power is estimated in fp32; the
+// bound E covers the fp32 rounding of BB^2/(4 AA) and of the subtraction from CC (a few ulp of the
+// larger operand) with a wide safety factor, `log_thr` = ln(1/(255 w)) is computed once per staged
+// entry.  Pairs that are not certainly rejected take the exact fp64 path, so results are unchanged.
+__device__ __forceinline__ bool pair_certainly_transparent(const PairEval& p, float CC, float log_thr)
+{
+    if (!(p.AAf > 0.0f)) return false;                       // degenerate quadric: let the exact path decide
+    const float qf = p.BBf * __builtin_amdgcn_rcpf(p.AAf);
+    const float X = qf * (p.BBf * 0.25f);
+    const float power_est = -0.5f * (CC - X);
+    const float E = 4e-7f * fmaxf(fabsf(CC), fabsf(X)) + 1e-4f;
+    return power_est + E < log_thr;
+}
+__device__ __forceinline__ float cull_log_threshold(float w)
+{
+    // ln(1 / (255 w)) with a small downward margin; w <= 0 (or NaN) can never reach 1/255
+    return (w > 0.0f) ? -__logf(255.0f * w) - 1e-3f : __builtin_huge_valf();
+}
+// exact remainder (after pair_prelude): t, min_value, power, exp, alpha
+__device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w, PairEval& p)
+{
+    const double AA = (double)p.AAf, BB = (double)p.BBf;
     // -BB/(2*AA) == -(BB/AA)/2 exactly (power-of-two scaling commutes with rounding), so one
     // fp64 division serves both t and min_value.
-    const double q = p.BB / p.AA;
+    const double q = BB / AA;
+    p.q = q;
     p.t = (float)(-q * 0.5);
     p.skip = ((double)p.t <= GOF_NEAR_PLANE);
-    const double min_value = (-q) * (p.BB * 0.25) + (double)v[9];
+    const double min_value = (-q) * (BB * 0.25) + (double)v[9];
     float power = (float)(-0.5 * min_value);
     if (power > 0.0f) power = 0.0f;
     p.G = gexpf(power);
     p.alpha = fminf(0.99f, w * p.G);
     if (p.alpha < 1.0f / 255.0f) p.skip = true;
+}
+__device__ __forceinline__ void eval_pair(const float* __restrict__ v, float w, float rx, float ry, PairEval& p)
+{
+    pair_prelude(v, rx, ry, p);
+    pair_exact(v, w, p);
 }
 
 } // namespace gof
