@@ -1,0 +1,106 @@
+"""ctypes binding of oracle/_ref/libgof_cudaref*.so (TEST INFRASTRUCTURE): the REFERENCE CUDA
+rasterizer compiled for gfx950 by oracle/build_ref.sh.  Device memory via torch."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from oracle_binding import GofRasterArgs, ROOT
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def available(variant=""):
+    return os.path.exists(os.path.join(REF_DIR, "libgof_cudaref%s.so" % variant))
+
+
+_ELEM = {"depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "view2gaussian": np.float32, "conic_opacity": np.float32,
+         "rgb": np.float32, "clamped": np.uint8, "tiles_touched": np.uint32, "point_offsets": np.uint32, "point_list": np.uint32,
+         "point_list_keys": np.uint64, "ranges": np.uint32, "final_T": np.float32, "n_contrib": np.uint32}
+
+
+class Reference:
+    def __init__(self, scene_dev, variant=""):
+        L = self.L = C.CDLL(os.path.join(REF_DIR, "libgof_cudaref%s.so" % variant))
+        L.cudaref_create.restype = C.c_void_p
+        L.cudaref_destroy.argtypes = [C.c_void_p]
+        L.cudaref_forward.argtypes = [C.c_void_p, C.POINTER(GofRasterArgs), C.c_void_p, C.c_void_p]
+        L.cudaref_backward.argtypes = [C.c_void_p, C.POINTER(GofRasterArgs)] + [C.c_void_p] * 12
+        L.cudaref_integrate.argtypes = [C.c_void_p, C.POINTER(GofRasterArgs), C.c_int] + [C.c_void_p] * 5
+        L.cudaref_fetch.restype = C.c_void_p
+        L.cudaref_fetch.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
+        self.h = C.c_void_p(L.cudaref_create())
+        sd = self.sd = scene_dev
+        self.P = sd["means3D"].shape[0]
+        self.M = sd["shs"].shape[1]
+        self.H, self.W = sd["H"], sd["W"]
+        a = self.args = GofRasterArgs()
+        a.P, a.D, a.M, a.W, a.H = self.P, sd["sh_degree"], self.M, self.W, self.H
+        a.tan_fovx, a.tan_fovy, a.kernel_size, a.scale_modifier = sd["tanfovx"], sd["tanfovy"], sd["kernel_size"], sd["scale_modifier"]
+        a.prefiltered, a.debug = 0, 0
+        self.keep = {k: sd[k].contiguous() for k in ("bg", "means3D", "shs", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "campos", "subpixel_offset")}
+        k = self.keep
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        a.background = p(k["bg"]); a.means3D = p(k["means3D"]); a.shs = p(k["shs"]); a.colors_precomp = None
+        a.opacities = p(k["opacities"]); a.scales = p(k["scales"]); a.rotations = p(k["rotations"])
+        a.cov3D_precomp = None; a.view2gaussian_precomp = None
+        a.viewmatrix = p(k["viewmatrix"]); a.projmatrix = p(k["projmatrix"]); a.campos = p(k["campos"]); a.subpixel_offset = p(k["subpixel_offset"])
+
+    def __del__(self):
+        try:
+            self.L.cudaref_destroy(self.h)
+        except Exception:
+            pass
+
+    def forward(self):
+        dev = self.sd["means3D"].device
+        self.out = torch.zeros((9, self.H, self.W), device=dev)
+        self.radii = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        self.R = self.L.cudaref_forward(self.h, C.byref(self.args), C.c_void_p(self.out.data_ptr()), C.c_void_p(self.radii.data_ptr()))
+        return self.out.cpu().numpy(), self.radii.cpu().numpy()
+
+    def fetch(self, name):
+        n = C.c_longlong(0)
+        ptr = self.L.cudaref_fetch(self.h, name.encode(), C.byref(n))
+        if n.value < 0:
+            raise KeyError(name)
+        dt = np.dtype(_ELEM[name])
+        host = np.empty(n.value, dtype=dt)
+        if n.value:
+            t = torch.empty(n.value * dt.itemsize, dtype=torch.uint8, device=self.sd["means3D"].device)
+            # device-to-device copy through hipMemcpy via torch: build a tensor view by ctypes memmove is not possible; use hip
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), n.value * dt.itemsize, 3) == 0
+            host = t.cpu().numpy().view(dt).copy()
+        return host
+
+    def backward(self, dL):
+        dev = self.sd["means3D"].device
+        P, M = self.P, self.M
+        z = lambda *s: torch.zeros(s, device=dev)   # noqa: E731
+        g = dict(means2D=z(P, 3), colors=z(P, 3), opacity=z(P, 1), means3D=z(P, 3), cov3D=z(P, 6), sh=z(P, M, 3), scales=z(P, 3),
+                 rotations=z(P, 4), view2gaussian=z(P, 10))
+        conic = z(P, 4)
+        d = torch.from_numpy(np.ascontiguousarray(dL, dtype=np.float32)).to(dev)
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        torch.cuda.synchronize()
+        self.L.cudaref_backward(self.h, C.byref(self.args), p(self.radii), p(d), p(g["means2D"]), p(g["colors"]), p(g["opacity"]),
+                                p(g["means3D"]), p(g["cov3D"]), p(g["sh"]), p(g["scales"]), p(g["rotations"]), p(g["view2gaussian"]), p(conic))
+        return {k: v.cpu().numpy() for k, v in g.items()}
+
+    def integrate(self, points3D):
+        dev = self.sd["means3D"].device
+        pts = torch.from_numpy(np.ascontiguousarray(points3D, dtype=np.float32)).to(dev)
+        PN = pts.shape[0]
+        out = torch.zeros((9, self.H, self.W), device=dev)
+        alpha = torch.ones(PN, device=dev)
+        col = torch.zeros((PN, 3), device=dev)
+        radii = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        torch.cuda.synchronize()
+        self.R = self.L.cudaref_integrate(self.h, C.byref(self.args), PN, p(pts), p(out), p(alpha), p(col), p(radii))
+        return out.cpu().numpy(), alpha.cpu().numpy(), col.cpu().numpy(), radii.cpu().numpy()
