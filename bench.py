@@ -86,11 +86,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if rank == 0:
+        B.profile_enable(True)      # HIP events around every kernel launch, on the launch stream, over the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_times = None
+    if rank == 0:
+        kernel_times = B.profile_report()
+        B.profile_enable(False)
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -102,7 +108,7 @@ def main():
     out = None
     if rank == 0:
         # ---- per-stage timing with HIP events on the launch stream + roofline of the dominant HBM kernel ----
-        stage = stage_times(B, sd, dL, dev, reps=max(5, min(20, args.steps)))
+        stage = stage_times(B, sd, dL, dev, kernel_times, args.steps)
         out = {
             "metric": "train iters/sec (fwd+bwd of the rasterizer, 1 view/GPU/step), S1M synthetic",
             "value": round(iters_per_s, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -122,48 +128,58 @@ def main():
         dist.destroy_process_group()
 
 
-def stage_times(B, sd, dL, dev, reps):
-    """Forward / backward wall time and the preprocess kernel's duration measured with HIP events on the
-    current stream (the stream the library launches on)."""
-    empty = torch.Tensor([])
-    a = (sd["bg"], sd["means3D"], empty, sd["opacities"], sd["scales"], sd["rotations"], sd["scale_modifier"], empty, empty,
-         sd["viewmatrix"], sd["projmatrix"], sd["tanfovx"], sd["tanfovy"], sd["kernel_size"], sd["subpixel_offset"], sd["H"], sd["W"],
-         sd["shs"], sd["sh_degree"], sd["campos"], False, False)
-    ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
-    fwd, bwd = [], []
-    R = 0
-    for _ in range(reps):
-        e0, e1, e2 = ev(), ev(), ev()
-        e0.record()
-        R, color, radii, geom, binning, img = B.rasterize_gaussians(*a)
-        e1.record()
-        B.rasterize_gaussians_backward(a[0], a[1], radii, a[2], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14],
-                                       dL, a[17], a[18], a[19], geom, R, binning, img, False)
-        e2.record()
-        torch.cuda.synchronize()
-        fwd.append(e0.elapsed_time(e1)); bwd.append(e1.elapsed_time(e2))
-    fwd_ms, bwd_ms = float(np.median(fwd)), float(np.median(bwd))
-    # dominant HBM-bound kernel: K1 preprocess (355 B / Gaussian algorithmic: 236 read + 119 written, SURVEY 8d).
-    # Timed alone through gof_forward_prepare (K1 + scan + 4-byte read-back) minus nothing: an upper bound on K1's time.
-    v = B._View(*a)
-    geom = v.bytes_tensor(B.lib.gof_geom_bytes(v.P)); img = v.bytes_tensor(B.lib.gof_image_bytes(v.W, v.H))
-    radii = torch.zeros(v.P, dtype=torch.int32, device=dev)
-    import ctypes as C
-    n = C.c_uint32(0)
-    ts = []
-    for _ in range(reps):
-        e0, e1 = ev(), ev()
-        e0.record()
-        B._check(B.lib.gof_forward_prepare(v.ref(), B._ptr(geom), geom.numel(), B._ptr(img), img.numel(), B._ptr(radii), C.byref(n), B._stream()))
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    k1_ms = float(np.median(ts))
-    bytes_k1 = v.P * (236 + 119)
-    achieved = bytes_k1 / (k1_ms * 1e-3) / 1e9
-    roof = {"bound": "hbm", "kernel": "preprocess_fwd (+scan, upper bound on its duration)", "achieved": round(achieved, 1), "peak": 8000.0,
-            "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None}
-    return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": int(R), "roofline": roof}
+def stage_times(B, sd, dL, dev, kernel_times, steps):
+    """Per-kernel average durations (HIP events recorded by the library on its launch stream during the timed
+    region) and the HBM roofline of the dominant kernel on ALGORITHMIC bytes."""
+    from gpu_common import product_forward_raw, fetch
+    res = product_forward_raw(sd)
+    torch.cuda.synchronize()
+    P, W, H, R = res["view"].P, sd["W"], sd["H"], int(res["R"])
+    N = W * H
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ranges = fetch(res, "ranges").view(np.uint32).reshape(-1, 2).astype(np.int64)
+    lens = ranges[:, 1] - ranges[:, 0]
+    last = np.zeros((gy * 16, gx * 16), np.int64)
+    last[:H, :W] = fetch(res, "n_contrib").view(np.uint32).reshape(2, H, W)[0]
+    tile_max_last = last.reshape(gy, 16, gx, 16).max(axis=(1, 3)).ravel()
+    r_staged_bwd = int(tile_max_last.sum())                          # entries the backward has to look at
+    r_visited_fwd = int(np.minimum(lens, tile_max_last + 1).sum())   # entries the forward has to look at
+    p_visible = int((res["radii"] > 0).sum().item())
+    passes = (32 + int(np.ceil(np.log2(max(2, gx * gy)))) + 7) // 8
+    alg_bytes = {                                                    # SURVEY.md 8(d) per-unit figures x units
+        "preprocess_fwd": P * (236 + 119),
+        "scan_tiles": 8 * P,
+        "duplicate_keys": 24 * P + 12 * R,
+        "sort_pairs": passes * 24 * R + 12 * R,
+        "tile_ranges": 8 * R + 8 * gx * gy,
+        "blend_forward": 72 * r_visited_fwd + 60 * N,
+        "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,
+        "preprocess_bwd": p_visible * (316 + 232),
+        "backward_memsets": 4 * P * (3 + 3 + 1 + 3 + 6 + 48 + 3 + 4 + 10),
+    }
+    kernels = {}
+    for name, rec in kernel_times.items():
+        avg_ms = rec["total_ms"] / max(1, rec["calls"])
+        ent = {"avg_ms": round(avg_ms, 5), "calls": rec["calls"]}
+        if name in alg_bytes and avg_ms > 0:
+            ent["alg_MB"] = round(alg_bytes[name] / 1e6, 2)
+            ent["GBps"] = round(alg_bytes[name] / (avg_ms * 1e-3) / 1e9, 1)
+        kernels[name] = ent
+    fwd_names = ("preprocess_fwd", "scan_tiles", "duplicate_keys", "sort_pairs", "tile_ranges", "blend_forward")
+    fwd_ms = sum(kernels[k]["avg_ms"] for k in fwd_names if k in kernels)
+    bwd_ms = sum(kernels[k]["avg_ms"] for k in ("backward_memsets", "blend_backward", "preprocess_bwd") if k in kernels)
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["calls"])
+    d = kernels[dom]
+    achieved = d.get("GBps", 0.0)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": None,
+            "avg_ms": d["avg_ms"], "alg_bytes": alg_bytes.get(dom),
+            "note": "dominant kernel by time; the blend kernels are VALU/LDS-bound (SURVEY 8d), the figure is their HBM floor on "
+                    "algorithmic bytes; the HBM-bound stages are listed under 'kernels'",
+            "kernels": kernels,
+            "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd,
+                         "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)}}
+    return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": R, "roofline": roof}
 
 
 def cpu_baseline(args, W, H, focal):

@@ -8,7 +8,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 namespace gof {
 
@@ -63,6 +65,30 @@ void set_error(const char* fmt, ...)
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_error = buf;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+std::mutex g_prof_mutex;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}
+ProfileScope::ProfileScope(const char* name, hipStream_t s) : slot(-1), stream(s)
+{
+    if (!g_prof_on) return;
+    ProfRec r; r.name = name;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    hipEventRecord(r.e0, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+ProfileScope::~ProfileScope()
+{
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    if (slot < (int)g_prof.size()) hipEventRecord(g_prof[slot].e1, stream);
 }
 
 // ---- workspace layouts -------------------------------------------------------------------------------
@@ -169,15 +195,18 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
 {
     const int dbg = a->debug;
     if (R > 0) {
+        { GOF_PROFILE("duplicate_keys", stream);
         hipLaunchKernelGGL(duplicate_keys, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.rec, g.depths, g.point_offsets,
-                           b.keys_unsorted, b.vals_unsorted, radii, d.gx, d.gy);
+                           b.keys_unsorted, b.vals_unsorted, radii, d.gx, d.gy); }
         GOF_LAUNCH_CHECK(stream, dbg);
         const int end_bit = 32 + (int)higher_msb(d.ntiles);
-        GOF_HIP_CHECK(sort_pairs(b.sort_tmp, b.sort_tmp_bytes, b.keys_unsorted, b.keys, b.vals_unsorted, b.vals, R, end_bit, stream));
+        { GOF_PROFILE("sort_pairs", stream);
+        GOF_HIP_CHECK(sort_pairs(b.sort_tmp, b.sort_tmp_bytes, b.keys_unsorted, b.keys, b.vals_unsorted, b.vals, R, end_bit, stream)); }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
+        GOF_PROFILE("tile_ranges", stream);
         hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.keys, im.ranges);
         GOF_LAUNCH_CHECK(stream, dbg);
     }
@@ -216,13 +245,15 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
 
     GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));
+    { GOF_PROFILE("preprocess_fwd", stream);
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic,
-                       g.tiles_touched, g.clamped, g.flags);
+                       g.tiles_touched, g.clamped, g.flags); }
     GOF_LAUNCH_CHECK(stream, a->debug);
-    GOF_HIP_CHECK(scan_tiles(g.scan_tmp, g.scan_tmp_bytes, g.tiles_touched, g.point_offsets, (size_t)a->P, stream));
+    { GOF_PROFILE("scan_tiles", stream);
+    GOF_HIP_CHECK(scan_tiles(g.scan_tmp, g.scan_tmp_bytes, g.tiles_touched, g.point_offsets, (size_t)a->P, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
     uint32_t host_words[2] = { 0, 0 };
@@ -260,9 +291,10 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     const Dims d = dims_of(a);
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
+    { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, d.gx, d.ntiles);
+                       im.final_T, im.n_contrib, out_color, d.gx, d.ntiles); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -291,6 +323,7 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     const Dims d = dims_of(a);
     const size_t P = (size_t)a->P;
     // torch::zeros of the binding (rasterize_points.cu:161-170): required, K8 accumulates and K9 skips culled Gaussians
+    { GOF_PROFILE("backward_memsets", stream);
     GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans2D, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dcolors, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), stream));
@@ -299,15 +332,17 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     if (dL_dsh && a->M > 0) GOF_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, 3 * P * (size_t)a->M * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dscales, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_drotations, 0, 4 * P * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dview2gaussian, 0, 10 * P * sizeof(float), stream));
+    GOF_HIP_CHECK(hipMemsetAsync(dL_dview2gaussian, 0, 10 * P * sizeof(float), stream)); }
 
     if (R > 0) {
+        GOF_PROFILE("blend_backward", stream);
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
                            im.n_contrib, dL_dout, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian, d.gx, d.ntiles);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
+    GOF_PROFILE("preprocess_bwd", stream);
     hipLaunchKernelGGL(preprocess_bwd, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
                        g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales,
                        dL_drotations);
@@ -377,6 +412,7 @@ int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, 
         hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.keys, im.point_ranges);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
+    GOF_PROFILE("integrate_kernel", stream);
     hipLaunchKernelGGL(integrate_kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, a->W, a->H, d.focal_x, d.focal_y, w.points2D, w.depths, w.T_state,
                        a->background, im.final_T, im.n_contrib, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
@@ -393,6 +429,42 @@ int gof_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
     const Cam cam = { viewmatrix, projmatrix, nullptr };
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, cam, present);
     GOF_LAUNCH_CHECK(stream, 0);
+    return GOF_OK;
+}
+
+// ---- per-kernel timing ----------------------------------------------------------------------------------
+int gof_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    g_prof_on = on != 0;
+    return GOF_OK;
+}
+// Synchronises the recorded events, aggregates per kernel name and writes a JSON object
+// {"name": {"calls": n, "total_ms": t}, ...} into buf (NUL-terminated); clears the records.
+int gof_profile_report(char* buf, size_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    struct Agg { const char* name; int calls; double ms; };
+    std::vector<Agg> aggs;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            bool found = false;
+            for (auto& a : aggs) if (!strcmp(a.name, r.name)) { a.calls++; a.ms += ms; found = true; break; }
+            if (!found) aggs.push_back(Agg{ r.name, 1, (double)ms });
+        }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    std::string s = "{";
+    for (size_t i = 0; i < aggs.size(); i++) {
+        char tmp[256];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"calls\": %d, \"total_ms\": %.6f}", i ? ", " : "", aggs[i].name, aggs[i].calls, aggs[i].ms);
+        s += tmp;
+    }
+    s += "}";
+    if (!buf || cap < s.size() + 1) { set_error("profile buffer too small"); return GOF_E_INVALID; }
+    memcpy(buf, s.c_str(), s.size() + 1);
     return GOF_OK;
 }
 

@@ -90,6 +90,15 @@ void set_error(const char* fmt, ...);
     do { GOF_HIP_CHECK(hipGetLastError());                                                    \
          if (debug) GOF_HIP_CHECK(hipStreamSynchronize(stream)); } while (0)
 
+// ---- optional per-kernel timing (gof_profile_enable): HIP events recorded on the launch stream ------
+struct ProfileScope {
+    ProfileScope(const char* name, hipStream_t stream);
+    ~ProfileScope();
+    int slot;
+    hipStream_t stream;
+};
+#define GOF_PROFILE(name, stream) gof::ProfileScope _gof_prof_scope_##__LINE__(name, stream)
+
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (private L2s), so
 // give each XCD a contiguous band of tiles -- neighbouring tiles gather the same splat records.
 __device__ __forceinline__ uint32_t xcd_tile_id(uint32_t bid, uint32_t ntiles)

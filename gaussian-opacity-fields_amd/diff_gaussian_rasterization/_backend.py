@@ -56,7 +56,9 @@ def _load():
     lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.gof_debug_fetch.restype = i64
     lib.gof_debug_fetch.argtypes = [C.c_char_p, A, u32, vp, vp, vp, vp, sz, vp]
-    for name in ("gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
+    lib.gof_profile_enable.argtypes = [C.c_int]
+    lib.gof_profile_report.argtypes = [C.c_char_p, sz]
+    for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
                  "gof_integrate_run", "gof_mark_visible", "gof_mtets_count", "gof_mtets_emit"):
         getattr(lib, name).restype = C.c_int
     return lib
@@ -266,3 +268,16 @@ def debug_fetch(name, view, num_rendered, geom, binning, img):
     if n < 0:
         _check(int(n))
     return out
+
+
+def profile_enable(on=True):
+    """Bracket every kernel launch with HIP events on the launch stream (gof_profile_enable)."""
+    _check(lib.gof_profile_enable(1 if on else 0))
+
+
+def profile_report():
+    """-> {kernel: {"calls": n, "total_ms": t}}; waits for the recorded events and clears them."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    _check(lib.gof_profile_report(buf, len(buf)))
+    return json.loads(buf.value.decode())

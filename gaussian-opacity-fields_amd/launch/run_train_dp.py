@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Data-parallel launcher for the reference's UNCHANGED train.py: one process per GPU, cameras sharded
+across ranks, Gaussian parameter gradients all-reduced over RCCL before every optimizer step.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        gaussian-opacity-fields_amd/launch/run_train_dp.py /path/to/gaussian-opacity-fields/train.py -s <scene> ...
+
+Injection points; NEW behaviour, the reference has no multi-GPU training:
+  * train.py:370 pins cuda:0           -> HIP_VISIBLE_DEVICES=<LOCAL_RANK> is exported before torch initialises HIP
+  * train.py:135-137 camera sampling   -> Scene.getTrainCameras returns this rank's shard cams[rank::world]
+  * gaussian_model.py:342-364          -> training_setup registers an optimizer step pre-hook that all-reduces
+                                          the parameter gradients (the optimizer object survives densification)
+  * gaussian_model.py:709-714          -> add_densification_stats all-reduces its per-step increments
+                                          (SUM for the accumulators / denom, MAX for max_radii2D is done in the hook)
+  * train.py:247-250,276-301           -> only rank 0 writes point clouds / checkpoints / TensorBoard
+Identical seeds on every rank (train.py:367-369) keep densify_and_split's sampling identical.
+"""
+import os
+import sys
+
+local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)       # before importing torch: every rank sees its GPU as cuda:0
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, PKG)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from dp import GradientAllReducer, shard_views
+    from dp.reducer import all_reduce_densification_stats
+
+    script = os.path.abspath(sys.argv[1])
+    sys.path.insert(0, os.path.dirname(script))
+    sys.path.insert(0, PKG)
+    sys.path.append(os.path.join(PKG, "shims"))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    import scene as ref_scene
+    from scene.gaussian_model import GaussianModel
+
+    _get_train = ref_scene.Scene.getTrainCameras
+
+    def get_train_sharded(self, scale=1.0):
+        cams = _get_train(self, scale)
+        return shard_views(cams, rank, world) if world > 1 else cams
+    ref_scene.Scene.getTrainCameras = get_train_sharded
+
+    _setup = GaussianModel.training_setup
+
+    def training_setup(self, training_args):
+        _setup(self, training_args)
+        model = self
+
+        def pre_step(optimizer, args, kwargs):
+            params = [p for g in optimizer.param_groups for p in g["params"]]
+            GradientAllReducer(params).all_reduce()
+            all_reduce_densification_stats(model.xyz_gradient_accum, model.xyz_gradient_accum_abs, model.denom,
+                                           model.max_radii2D, getattr(model, "xyz_gradient_accum_abs_max", None))
+        self.optimizer.register_step_pre_hook(pre_step)
+    GaussianModel.training_setup = training_setup
+
+    if rank != 0:      # only rank 0 writes
+        ref_scene.Scene.save = lambda self, iteration: None
+        _save = torch.save
+        torch.save = lambda *a, **k: None
+
+    import runpy
+    sys.argv = [os.path.join(PKG, "launch", "run_reference_script.py"), script] + sys.argv[2:]
+    runpy.run_path(sys.argv[0], run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

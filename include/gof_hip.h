@@ -188,6 +188,13 @@ int gof_mtets_emit(int64_t num_verts, int64_t num_tets,
                    int64_t* edge_ids, float* edge_pos, float* edge_sdf, float* edge_scales,
                    int64_t* faces, void* stream);
 
+/* ---- per-kernel timing (replaces the reference's torch.cuda.Event pair, train.py:103-104,126,191) ---- */
+/* When enabled, every kernel launch of the library is bracketed by HIP events on the launch stream. */
+int gof_profile_enable(int on);
+/* Waits for the recorded events, writes {"kernel": {"calls": n, "total_ms": t}, ...} (JSON, NUL-terminated)
+ * into buf and clears the records. */
+int gof_profile_report(char* buf, size_t cap);
+
 /* ---- introspection for tests / benchmarks (no reference counterpart) ------------------- */
 /* Copies one named intermediate array out of the workspaces into `dst` (device memory).
  * names: "depths" f32[P], "means2D" f32[P,2], "conic_opacity" f32[P,4], "rgb" f32[P,3],
