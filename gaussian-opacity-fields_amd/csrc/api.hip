@@ -20,7 +20,7 @@ __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const 
                                const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
-                               int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out,
+                               int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out,
                                uint32_t* tiles_touched, uint8_t* clamped, uint32_t* flags);
 __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
@@ -42,10 +42,10 @@ __global__ void point_keys(int PN, const float2* points2D, const float* depths, 
                            const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals, uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint64_t* keys, uint2* ranges);
 
-__global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, int W, int H,
+__global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
                               float* out_color, uint32_t gx, uint32_t ntiles);
-__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic,
+__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const float4* bbox,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity,
                                float* dL_dcolors, float* dL_dv2g, uint32_t gx, uint32_t ntiles);
@@ -107,6 +107,7 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     const size_t n = (size_t)P;
     carve(p, g.rec, n);
     carve(p, g.conic, n);
+    carve(p, g.bbox, n);
     carve(p, g.depths, n);
     carve(p, g.tiles_touched, n);
     carve(p, g.point_offsets, n);
@@ -249,7 +250,7 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
-                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic,
+                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox,
                        g.tiles_touched, g.clamped, g.flags); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     { GOF_PROFILE("scan_tiles", stream);
@@ -293,7 +294,7 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     if (rc) return rc;
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.ranges, b.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background,
                        im.final_T, im.n_contrib, out_color, d.gx, d.ntiles); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
@@ -337,7 +338,7 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                           im.ranges, b.vals, g.rec, g.conic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
+                           im.ranges, b.vals, g.rec, g.conic, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
                            im.n_contrib, dL_dout, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian, d.gx, d.ntiles);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }

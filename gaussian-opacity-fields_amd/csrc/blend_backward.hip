@@ -17,7 +17,9 @@
 //  * Entries behind the last contributor of EVERY pixel of the tile are never staged: the
 //    traversal starts at max-over-tile(last_contributor) (the reference stages the full list and
 //    skips per pixel, backward.cu:763-765).
-//  * Conservative fp32 cull before the exact fp64 division / exp (see pair_certainly_transparent).
+//  * Two conservative culls before the exact fp64 division / exp: the per-Gaussian footprint box
+//    (preprocess_fwd: footprint_bbox; 4 compares, wave-level skip) and the error-bounded fp32 test
+//    (pair_certainly_transparent).
 //  * alpha, T and the contributor bookkeeping use the exact arithmetic of the forward (they decide
 //    WHICH pairs contribute, bit-identically to the forward pass); the gradient formulas downstream
 //    are evaluated in fp32 with hardware rcp/rsq (<= 2 ulp).  The reference itself rounds every
@@ -61,7 +63,7 @@ __device__ __forceinline__ float row_sum(float v)
 
 __global__ void __launch_bounds__(256)
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-               const float4* __restrict__ conic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+               const float4* __restrict__ conic, const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
                float* __restrict__ dL_dv2g, uint32_t gx, uint32_t ntiles)
@@ -84,6 +86,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
 
     __shared__ float4 s_rec[4][BATCH];
     __shared__ float4 s_conic[BATCH];
+    __shared__ float4 s_box[BATCH];
     __shared__ uint32_t s_id[BATCH];
     __shared__ float s_thr[BATCH];
     __shared__ float s_acc[NGRAD][BATCH];
@@ -156,6 +159,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                 if (part == 0) {
                     s_conic[e] = conic[id];
                     s_id[e] = id;
+                    s_box[e] = bbox[id];
                 }
                 if (part == TPE - 1) s_thr[e] = cull_log_threshold(r4[(2 % F4)].z);   // f[10] lives in float4 #2, component z
             }
@@ -167,7 +171,9 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
         const int n = min(BATCH, toDo);
         for (int j = 0; j < n; j++) {
             contributor--;
-            const bool active = inside && (contributor < last_contributor);
+            const float4 bx = s_box[j];
+            const bool active = inside && (contributor < last_contributor) &&
+                                (pxm >= bx.x) & (pxm <= bx.y) & (pym >= bx.z) & (pym <= bx.w);   // conservative footprint box
             if (__ballot(active) == 0ull) continue;
 
             const float4 a = s_rec[0][j], b = s_rec[1][j], c = s_rec[2][j];

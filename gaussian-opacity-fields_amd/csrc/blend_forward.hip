@@ -5,32 +5,59 @@
 // (x = l % 16, y = 4*w + l / 16) -- the same thread_rank -> pixel map as the reference, so
 // per-pixel results do not depend on the decomposition.
 //
-// MI355X design:
-//  * tile-list entries are staged 256 at a time into LDS as whole 64-byte SplatRec lines
-//    (view2gaussian + opacity + colour + 2D mean): one aligned 64-B gather per entry, colour
-//    included (the reference re-reads colour from global memory per contributing pair,
-//    forward.cu:561).  LDS layout is [4][256] float4, so the staging ds_write_b128 of 64
-//    consecutive lanes are contiguous (conflict-free) and the inner-loop reads are wave-uniform
-//    broadcasts.
-//  * per-wave early exit: a wave whose 64 pixels are all saturated skips the batch
-//    (ballot over `done`), the workgroup exits when all 4 waves are done (forward.cu:475-477).
-//  * conservative fp32 cull (pair_certainly_transparent): a wave whose lanes are all CERTAINLY below
-//    alpha = 1/255 for this splat skips the exact fp64 division / exp path entirely; any lane that is
-//    not certainly transparent takes the exact path, so the result is unchanged (bit-exact).
-//  * a wave skips the heavy "contributing" path when no lane passes the alpha test.
-//  * XCD-aware tile order (xcd_tile_id): neighbouring tiles, which gather the same records,
-//    run on the same XCD and share its L2.
+// MI355X design -- the kernel is VALU-issue bound (fp64 division, exp, fp64 sqrt per pair), and a
+// tile list is ~10x longer than the set of splats that actually reach a given pixel (at S1M a pixel
+// looks at ~300 entries, ~25 contribute).  A lock-step loop makes all 64 pixels of a wave pay the
+// exact path whenever ANY of them needs it.  Instead, per staged batch of 256 entries:
 //
-// Arithmetic: identical operation sequence to the oracle (fp32 products/sums in source order,
-// fp64 for AA/BB/min_value, mapped depth, normal length and the final distortion normalisation,
-// as forward.cu:504-557, 589), so every output is expected to be bit-identical to the oracle.
+//   phase 1 (cull scan, wave-uniform over entries): every lane tests its pixel against the entry's
+//     conservative footprint box (4 compares; the box of the alpha >= 1/255 level-set ellipsoid is
+//     computed once per Gaussian in preprocess_fwd, see footprint_bbox) -- if no pixel of the wave is
+//     inside, the entry costs 6 instructions -- then evaluates the fp32 prelude and the error-bounded
+//     cull (pair_certainly_transparent) and records the survivors as a 256-bit mask of ITS pixel in
+//     LDS (s_mask[word][thread]).
+//   phase 2 (per-lane ordered consumption): every lane pops the next set bit of its own mask, reads
+//     that entry's record from LDS with a per-lane address and runs the exact path (fp64 t /
+//     min_value, exp, blend update).  Entries are consumed in ascending list order per pixel, so
+//     the per-pixel operation sequence -- and therefore every output bit -- is unchanged; the number
+//     of heavy iterations of a wave drops from "#entries any pixel passes" to "max #candidates of
+//     one pixel".
+//
+//  * tile-list entries are staged as whole 64-byte SplatRec lines (one aligned gather per entry,
+//    colour included; the reference re-reads colour from global memory per contributing pair,
+//    forward.cu:561).  LDS layout [4][256] float4: staging writes of 64 consecutive lanes are
+//    contiguous (conflict-free), phase-1 reads are wave-uniform broadcasts.  The LDS copy carries the
+//    entry's cull threshold next to view2gaussian (phase 1 reads 3 x 16 B).
+//  * per-wave exit by ballot(done), workgroup exit by __syncthreads_and(done) (forward.cu:475-477).
+//  * XCD-aware tile order (xcd_tile_id): neighbouring tiles, which gather the same records, run on
+//    the same XCD and share its L2.
+//
+// Arithmetic: identical operation sequence to the oracle (fp32 products/sums in source order, fp64
+// for AA/BB/min_value, mapped depth, normal length and the final distortion normalisation, as
+// forward.cu:504-557, 589): every output is bit-identical to the oracle.
 #include "gof_common.h"
 
 namespace gof {
 
+// scan/consume granularity inside a staged batch: smaller = finer early exit once a wave saturates,
+// larger = better lane compaction in phase 2
+#ifndef GOF_FW_CHUNK
+#define GOF_FW_CHUNK 128
+#endif
+constexpr int FW_CHUNK = GOF_FW_CHUNK;
+
+#ifdef GOF_STATS
+// developer-only instrumentation (never in the shipped build): [0] scanned wave-entries, [1] candidate
+// (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active
+__device__ unsigned long long g_fw_stats[8];
+#define STAT_ADD(i, v) atomicAdd(&g_fw_stats[i], (unsigned long long)(v))
+#else
+#define STAT_ADD(i, v)
+#endif
+
 __global__ void __launch_bounds__(256)
 blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-              int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+              const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
               uint32_t gx, uint32_t ntiles)
 {
@@ -49,12 +76,15 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
+    // LDS record: q0 = v0..v3, q1 = v4..v7, q2 = {v8, v9, cull threshold, w}, q3 = {r, g, b, -}
     __shared__ float4 s_rec[4][TILE_PIX];
-    __shared__ float s_thr[TILE_PIX];
+    __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
+    __shared__ float4 s_box[TILE_PIX];
+    const float pxf = (float)px, pyf = (float)py;
 
     bool done = !inside;
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0, max_contributor = (uint32_t)-1;
+    uint32_t last_contributor = 0, max_contributor = (uint32_t)-1;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, Al = 0;
     float dist1 = 0, dist2 = 0, distortion = 0;
 
@@ -65,29 +95,74 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const uint32_t id = point_list[k];
             const float4* src = reinterpret_cast<const float4*>(&rec[id]);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-            s_rec[0][tid] = a; s_rec[1][tid] = b; s_rec[2][tid] = c; s_rec[3][tid] = d;
-            s_thr[tid] = cull_log_threshold(c.z);
+            s_rec[0][tid] = a; s_rec[1][tid] = b;
+            s_rec[2][tid] = make_float4(c.x, c.y, cull_log_threshold(c.z), c.z);
+            s_rec[3][tid] = make_float4(c.w, d.x, d.y, 0.f);
+            s_box[tid] = bbox[id];
         }
         __syncthreads();
-        if (__ballot(!done) == 0ull) continue;   // whole wave saturated: help staging only
+        if (__ballot(!done) == 0ull) continue;   // whole wave saturated: it only helps staging
 
         const int n = min(TILE_PIX, toDo);
-        for (int j = 0; j < n; j++) {
-            if (__ballot(!done) == 0ull) break;      // wave-uniform: every pixel of this wave is saturated
-            if (done) continue;
-            contributor++;
-            const float4 a = s_rec[0][j], b = s_rec[1][j], c = s_rec[2][j];
-            const float v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y };
+        const uint32_t base = (uint32_t)i * TILE_PIX;
+
+        for (int c0 = 0; c0 < n; c0 += FW_CHUNK) {
+        if (__ballot(!done) == 0ull) break;
+        const int cn = min(FW_CHUNK, n - c0);            // entries [c0, c0 + cn) of the staged batch
+        const int w0 = c0 >> 5;
+        const int nw = w0 + ((cn + 31) >> 5);
+
+        // ---- phase 1: cull scan ----
+        for (int w = w0; w < nw; w++) {
+            uint32_t word = 0;
+            const int j0 = w * 32;
+            const int cnt = min(32, n - j0);
+            for (int b = 0; b < cnt; b++) {
+                const int j = j0 + b;
+                const float4 bx = s_box[j];
+                const bool inbox = !done & (pxf >= bx.x) & (pxf <= bx.y) & (pyf >= bx.z) & (pyf <= bx.w);
+                if (__ballot(inbox) == 0ull) continue;          // no pixel of this wave can see the splat
+                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
+                const float v[10] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y };
+                PairEval p;
+                pair_prelude(v, rx, ry, p);
+                const bool pass = inbox && !pair_certainly_transparent(p, q2.y, q2.z);
+                word |= (pass ? 1u : 0u) << b;
+            }
+            s_mask[w][tid] = done ? 0u : word;
+            if ((tid & 63) == 0) STAT_ADD(0, cnt);
+            STAT_ADD(1, done ? 0 : __popc(word));
+        }
+
+        // ---- phase 2: every lane consumes its own candidates in list order ----
+        int w = w0;
+        uint32_t cur = s_mask[w0][tid];
+        for (;;) {
+            const bool more = !done && (cur != 0u || w + 1 < nw);
+            if (__ballot(more) == 0ull) break;
+            if ((tid & 63) == 0) STAT_ADD(2, 1);
+            if (!more) continue;
+            STAT_ADD(5, 1);
+            if (cur == 0u) { w++; cur = s_mask[w][tid]; }
+            if (cur == 0u) continue;
+            const int b = __ffs((int)cur) - 1;
+            cur &= cur - 1u;
+            const int j = w * 32 + b;
+            const uint32_t contributor = base + (uint32_t)j + 1u;   // 1-based list position (forward.cu:497)
+
+            const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
+            const float v[10] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y };
             PairEval p;
             pair_prelude(v, rx, ry, p);
-            if (pair_certainly_transparent(p, c.y, s_thr[j])) continue;
-            pair_exact(v, c.z, p);
+            pair_exact(v, q2.w, p);
             if (p.skip) continue;
+            STAT_ADD(3, 1);
             const float alpha = p.alpha, t = p.t;
             const float test_T = T * (1 - alpha);
             if (test_T < 0.0001f) { done = true; continue; }
+            STAT_ADD(4, 1);
 
-            const float4 d = s_rec[3][j];
+            const float4 q3 = s_rec[3][j];
             const float max_t = t;
             const float mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
             const float length = (float)sqrt((double)(p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2) + 1e-7);
@@ -99,9 +174,9 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             dist1 += mapped_max_t * alpha * T;
             dist2 += mapped_max_t * mapped_max_t * alpha * T;
 
-            C0 += c.w * alpha * T;
-            C1 += d.x * alpha * T;
-            C2 += d.y * alpha * T;
+            C0 += q3.x * alpha * T;
+            C1 += q3.y * alpha * T;
+            C2 += q3.z * alpha * T;
             N0 += nn0 * alpha * T;
             N1 += nn1 * alpha * T;
             N2 += nn2 * alpha * T;
@@ -110,6 +185,7 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             T = test_T;
             last_contributor = contributor;
         }
+        }   // chunk
     }
 
     if (inside) {
@@ -133,5 +209,15 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
         out_color[8 * HW + pix_id] = distortion;
     }
 }
+
+#ifdef GOF_STATS
+extern "C" int gof_debug_fw_stats(unsigned long long* out8, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), sizeof(g_fw_stats));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fw_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 } // namespace gof

@@ -40,6 +40,7 @@ struct GeomWs {
     float* depths;          // [P]
     SplatRec* rec;          // [P]
     float4* conic;          // [P] conic.xyz (2D inverse covariance), w unused -- backward only
+    float4* bbox;           // [P] conservative pixel bounding box {xlo, xhi, ylo, yhi} of the alpha >= 1/255 footprint
     uint32_t* tiles_touched;// [P]
     uint32_t* point_offsets;// [P] inclusive scan
     uint8_t* clamped;       // [P] bit c set when colour channel c was clamped (forward.cu:67-69)

@@ -92,6 +92,82 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
                (float)(I.Sx * Rt.m[2][0]), (float)(I.Sy * Rt.m[2][1]), (float)(I.Sz * Rt.m[2][2]));
 }
 
+// Conservative PIXEL bounding box of the region where this splat can reach alpha >= 1/255, used by the
+// blend kernels to skip (pixel, splat) pairs without touching the per-pair arithmetic.
+//
+// alpha = w * exp(-min_value / 2) >= 1/255  <=>  min_value <= m0 = 2 ln(255 w); min_value(ray) is the
+// minimum of the Mahalanobis distance along the ray, so the candidate rays are those that hit the
+// ellipsoid {x : (x - mu)^T Sigma' (x - mu) <= m0} (view space, Sigma'^-1 = A diag(s^2 + 1e-7) A^T).  The
+// image of an ellipsoid under a pinhole at the origin is a conic with dual C* = mu mu^T - k Cov; the
+// vertical / horizontal tangent lines give the box (valid while the ellipsoid stays in front of the
+// camera plane, otherwise the box is left unbounded).  Everything is evaluated in fp64 from the
+// well-conditioned view-space covariance (no inversion).
+//
+// The blend evaluates min_value from fp32-rounded coefficients with fp32 arithmetic; its absolute error
+// is bounded by ~ c * eps * cond(Sigma') * lambda_max * |mu|^2 (forward error of r^T Sigma' r and b.r with
+// |b| <= lambda_max |mu|, r^T Sigma' r >= lambda_min |r|^2; c ~ 30 covers coefficient rounding too).  The level is
+// therefore raised to k = m0 + Delta with Delta = 3e-5 * cond * lambda_max * |mu|^2 + 0.05, which keeps the box
+// conservative with respect to the arithmetic the blend actually performs (for sub-pixel, far-away
+// splats the box grows accordingly); for cond > 1e4 the box is left unbounded.
+__device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float w, float focal_x, float focal_y, int W, int H)
+{
+    const float4 unbounded = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);
+    const float4 empty = make_float4(1e30f, -1e30f, 1e30f, -1e30f);
+    if (!(w > 0.0f)) return empty;                                  // alpha <= 0 < 1/255 everywhere
+    const double m0 = 2.0 * log(255.0 * (double)w);
+    if (!(m0 > -0.05)) return empty;                                // w < 1/255: can never reach the threshold
+    const double lx = I.Sx, ly = I.Sy, lz = I.Sz;                   // eigenvalues of Sigma' = 1 / (s^2 + 1e-7)
+    const double lmax = fmax(lx, fmax(ly, lz)), lmin = fmin(lx, fmin(ly, lz));
+    const double cond = lmax / lmin;
+    if (!(cond < 1e4)) return unbounded;
+    {   // the closed form below needs an orthonormal frame (unit quaternion, rigid view matrix); otherwise leave it unbounded
+        const M3& R = I.Rt;
+        float dev = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = i; j < 3; j++) {
+                const float d = R.m[i][0] * R.m[j][0] + R.m[i][1] * R.m[j][1] + R.m[i][2] * R.m[j][2] - (i == j ? 1.f : 0.f);
+                dev = fmaxf(dev, fabsf(d));
+            }
+        if (!(dev < 1e-5f)) return unbounded;
+    }
+    const double mx = mu.x, my = mu.y, mz = mu.z;
+    const double mu2 = mx * mx + my * my + mz * mz;
+#ifndef GOF_BOX_C
+#define GOF_BOX_C 6e-6
+#endif
+    const double k = m0 + 0.05 + GOF_BOX_C * lmax * mu2;
+    // view-space covariance Cov = A diag(1/l) A^T with A = Rt^T (rows of Rt are the Gaussian axes in view space):
+    // Cov_ij = sum_c Rt[i][c] * Rt[j][c] / l_c   (Rt.m[col][row] = G2V[row][col])
+    const M3& Rt = I.Rt;
+    const double ix = 1.0 / lx, iy = 1.0 / ly, iz = 1.0 / lz;
+    // A = G2V 3x3 block: A[r][c] = Rt.m[r][c]?  Rt = mk3(G00,G10,G20, G01,G11,G21, G02,G12,G22) -> Rt.m[c][r] = G2V.m[r][c],
+    // and G2V.m[c][r] is row r of the matrix A applied to column c, i.e. A[r][c] = G2V.m[c][r] = Rt.m[r][c].
+    const double a00 = Rt.m[0][0], a01 = Rt.m[0][1], a02 = Rt.m[0][2];
+    const double a10 = Rt.m[1][0], a11 = Rt.m[1][1], a12 = Rt.m[1][2];
+    const double a20 = Rt.m[2][0], a21 = Rt.m[2][1], a22 = Rt.m[2][2];
+    const double Sxx = k * (a00 * a00 * ix + a01 * a01 * iy + a02 * a02 * iz);
+    const double Syy = k * (a10 * a10 * ix + a11 * a11 * iy + a12 * a12 * iz);
+    const double Szz = k * (a20 * a20 * ix + a21 * a21 * iy + a22 * a22 * iz);
+    const double Sxz = k * (a00 * a20 * ix + a01 * a21 * iy + a02 * a22 * iz);
+    const double Syz = k * (a10 * a20 * ix + a11 * a21 * iy + a12 * a22 * iz);
+    const double czz = mz * mz - Szz;
+    // camera inside (or the ellipsoid reaching the camera plane): unbounded
+    if (!(czz > 1e-9 * mz * mz) || !(mz > 0.0)) return unbounded;
+    const double Dx = Sxx * mz * mz - 2.0 * Sxz * mx * mz + Szz * mx * mx - (Sxx * Szz - Sxz * Sxz);
+    const double Dy = Syy * mz * mz - 2.0 * Syz * my * mz + Szz * my * my - (Syy * Szz - Syz * Syz);
+    if (!(Dx >= 0.0) || !(Dy >= 0.0)) return unbounded;
+    const double sx = sqrt(Dx), sy = sqrt(Dy);
+    const double cx = mx * mz - Sxz, cy = my * mz - Syz;
+    const double u0 = (cx - sx) / czz, u1 = (cx + sx) / czz;
+    const double v0 = (cy - sy) / czz, v1 = (cy + sy) / czz;
+    // ray of pixel p: r = (p + 0.5 - W/2) / focal  ->  p = r * focal + W/2 - 0.5; widen by 0.02 px for the fp32 ray
+    const double px0 = u0 * (double)focal_x + W / 2. - 0.5 - 0.02, px1 = u1 * (double)focal_x + W / 2. - 0.5 + 0.02;
+    const double py0 = v0 * (double)focal_y + H / 2. - 0.5 - 0.02, py1 = v1 * (double)focal_y + H / 2. - 0.5 + 0.02;
+    return make_float4((float)fmax(-1e9, ceil(px0)), (float)fmin(1e9, floor(px1)), (float)fmax(-1e9, ceil(py0)), (float)fmin(1e9, floor(py1)));
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_fwd(int P, int D, int M,
                const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
@@ -101,7 +177,7 @@ preprocess_fwd(int P, int D, int M,
                int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                uint32_t gx, uint32_t gy, int prefiltered,
                int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
-               float4* __restrict__ conic_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
+               float4* __restrict__ conic_out, float4* __restrict__ bbox_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
                uint32_t* __restrict__ flags)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -195,11 +271,13 @@ preprocess_fwd(int P, int D, int M,
         }
         clamped[idx] = (uint8_t)cb;
 
+        float4 box = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);     // unbounded unless proven otherwise
         if (v2g_precomp == nullptr) {
             V2GInter I;
             v2g_intermediates(scale, p_orig, rot, cam.view, I);
             const V3 t2 = I.t2;
             const double C = (double)(t2.x * t2.x) * I.Sx + (double)(t2.y * t2.y) * I.Sy + (double)(t2.z * t2.z) * I.Sz;
+            box = footprint_bbox(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H);
             const V3 B = mul(t2, I.SR);
             const M3 Sigma = mul(transpose(I.Rt), I.SR);
             r.f[0] = Sigma.m[0][0]; r.f[1] = Sigma.m[0][1]; r.f[2] = Sigma.m[0][2];
@@ -218,6 +296,7 @@ preprocess_fwd(int P, int D, int M,
         dst[2] = make_float4(r.f[8], r.f[9], r.f[10], r.f[11]);
         dst[3] = make_float4(r.f[12], r.f[13], r.f[14], r.f[15]);
         conic_out[idx] = make_float4(conx, cony, conz, 0.f);
+        bbox_out[idx] = box;
         depths[idx] = p_view.z;
         my_radii = (int32_t)my_radius;
         my_tiles = (maxy - miny) * (maxx - minx);

@@ -21,3 +21,7 @@ def timeit(fn, n=10):
     return np.median(ts)
 for _ in range(3): bwd(); product_forward_raw(sd)
 print("fwd ms", timeit(lambda: product_forward_raw(sd)), "bwd ms", timeit(bwd))
+B.profile_enable(True)
+for _ in range(10): product_forward_raw(sd); bwd()
+rep = B.profile_report(); B.profile_enable(False)
+print({k: round(v["total_ms"] / v["calls"], 4) for k, v in rep.items()})
