@@ -145,12 +145,13 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     r_staged_bwd = int(tile_max_last.sum())                          # entries the backward has to look at
     r_visited_fwd = int(np.minimum(lens, tile_max_last + 1).sum())   # entries the forward has to look at
     p_visible = int((res["radii"] > 0).sum().item())
-    passes = (32 + int(np.ceil(np.log2(max(2, gx * gy)))) + 7) // 8
+    tile_passes = (int(np.ceil(np.log2(max(2, gx * gy)))) + 1 + 7) // 8
     alg_bytes = {                                                    # SURVEY.md 8(d) per-unit figures x units
         "preprocess_fwd": P * (236 + 119),
         "scan_tiles": 8 * P,
-        "duplicate_keys": 24 * P + 12 * R,
-        "sort_pairs": passes * 24 * R + 12 * R,
+        "sort_gaussians_by_depth": 4 * 16 * P + 4 * 4 * P,           # 4 passes: 8 B read + 8 B written, + histogram read
+        "emit_instances": 24 * P + 8 * R,
+        "sort_instances_by_tile": tile_passes * (16 * R + 4 * R),     # per pass: 8 B read + 8 B written, + histogram read
         "tile_ranges": 8 * R + 8 * gx * gy,
         "blend_forward": 72 * r_visited_fwd + 60 * N,
         "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,
@@ -165,7 +166,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
             ent["alg_MB"] = round(alg_bytes[name] / 1e6, 2)
             ent["GBps"] = round(alg_bytes[name] / (avg_ms * 1e-3) / 1e9, 1)
         kernels[name] = ent
-    fwd_names = ("preprocess_fwd", "scan_tiles", "duplicate_keys", "sort_pairs", "tile_ranges", "blend_forward")
+    fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "blend_forward")
     fwd_ms = sum(kernels[k]["avg_ms"] for k in fwd_names if k in kernels)
     bwd_ms = sum(kernels[k]["avg_ms"] for k in ("backward_memsets", "blend_backward", "preprocess_bwd") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["calls"])

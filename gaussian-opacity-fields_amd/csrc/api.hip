@@ -21,7 +21,7 @@ __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const 
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
                                int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out,
-                               uint32_t* tiles_touched, uint8_t* clamped, uint32_t* flags);
+                               uint32_t* tiles_touched, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
 __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
                                const float* dL_dv2g, const float* dL_dcolor, float* dL_dmeans, float* dL_dsh,
@@ -31,16 +31,20 @@ __global__ void preprocess_points(int PN, const float* points3D, Cam cam, int W,
 __global__ void mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present);
 
 uint32_t higher_msb(uint32_t n);
-size_t scan_temp_bytes(size_t n);
-hipError_t scan_tiles(void* tmp, size_t tmp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t stream);
-size_t sort_temp_bytes(size_t n);
-hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
-                      uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream);
-__global__ void duplicate_keys(int P, const SplatRec* rec, const float* depths, const uint32_t* offsets, uint64_t* keys,
-                               uint32_t* vals, const int32_t* radii, uint32_t gx, uint32_t gy);
-__global__ void point_keys(int PN, const float2* points2D, const float* depths, const uint32_t* offsets,
-                           const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals, uint32_t gx, uint32_t gy);
-__global__ void tile_ranges(uint32_t L, const uint64_t* keys, uint2* ranges);
+size_t scan_tmp_words(size_t n);
+hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                           const uint32_t** total_dev_out, hipStream_t stream);
+size_t rs_tmp_words(size_t n);
+hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
+                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream);
+int radix_passes(int end_bit);
+__global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const SplatRec* rec, const int32_t* radii,
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t gy);
+__global__ void point_depth_keys(int PN, const float* depths, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys,
+                                 uint32_t* vals);
+__global__ void point_tile_keys(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, uint32_t* tiles, uint32_t gx, uint32_t gy);
+__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges);
+__global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* gids, const float* depths, uint64_t* keys);
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
@@ -110,11 +114,15 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     carve(p, g.bbox, n);
     carve(p, g.depths, n);
     carve(p, g.tiles_touched, n);
-    carve(p, g.point_offsets, n);
     carve(p, g.clamped, n);
     carve(p, g.flags, 4);
-    g.scan_tmp_bytes = scan_temp_bytes(n);
-    char* st; carve(p, st, g.scan_tmp_bytes); g.scan_tmp = st;
+    carve(p, g.total, 4);
+    carve(p, g.dval_a, n);          // depth-sorted Gaussian ids (kept for the render stage)
+    carve(p, g.order_off, n);
+    carve(p, g.dkey_a, n);
+    carve(p, g.dkey_b, n);
+    carve(p, g.dval_b, n);
+    carve(p, g.sort_tmp, rs_tmp_words(n) + scan_tmp_words(n));
     if (out) *out = g;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -138,11 +146,10 @@ size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out)
     char* p = static_cast<char*>(base);
     const size_t n = (size_t)R;
     carve(p, b.vals, n);            // sorted point_list first: the only part the backward reads
-    carve(p, b.keys, n);
-    carve(p, b.keys_unsorted, n);
-    carve(p, b.vals_unsorted, n);
-    b.sort_tmp_bytes = sort_temp_bytes(n);
-    char* st; carve(p, st, b.sort_tmp_bytes); b.sort_tmp = st;
+    carve(p, b.tiles, n);
+    carve(p, b.vals_alt, n);
+    carve(p, b.tiles_alt, n);
+    carve(p, b.sort_tmp, rs_tmp_words(n));
     if (out) *out = b;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -156,8 +163,7 @@ size_t point_layout(int32_t PN, void* base, PointWs* out)
     carve(p, w.tiles_touched, n);
     carve(p, w.point_offsets, n);
     carve(p, w.T_state, n);
-    w.scan_tmp_bytes = scan_temp_bytes(n);
-    char* st; carve(p, st, w.scan_tmp_bytes); w.scan_tmp = st;
+    carve(p, w.scan_tmp, scan_tmp_words(n));
     if (out) *out = w;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -190,25 +196,41 @@ static inline Dims dims_of(const GofRasterArgs* a)
     return d;
 }
 
-// K4..K6 shared by forward and integrate
+// Sort (tile, id) instances by tile; the instances were emitted into the buffer pair chosen so that the
+// result of the final pass lands in (b.tiles, b.vals).
+static int sort_by_tile(const BinWs& b, uint32_t n, uint32_t* tiles_in, uint32_t* vals_in, int tile_bits, hipStream_t stream)
+{
+    uint32_t* tiles_other = (tiles_in == b.tiles) ? b.tiles_alt : b.tiles;
+    uint32_t* vals_other = (vals_in == b.vals) ? b.vals_alt : b.vals;
+    uint32_t *kr = nullptr, *vr = nullptr;
+    GOF_HIP_CHECK(radix_sort_pairs_u32(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream));
+    if (kr != b.tiles || vr != b.vals) { set_error("internal: sort result in the wrong buffer"); return GOF_E_DEVICE; }
+    return GOF_OK;
+}
+
+// instance emission in depth order + tile sort + tile ranges, shared by forward and integrate
 static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, const GeomWs& g, const BinWs& b, const ImageWs& im,
                          const int32_t* radii, hipStream_t stream)
 {
     const int dbg = a->debug;
+    const int tile_bits = (int)higher_msb(d.ntiles);
     if (R > 0) {
-        { GOF_PROFILE("duplicate_keys", stream);
-        hipLaunchKernelGGL(duplicate_keys, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.rec, g.depths, g.point_offsets,
-                           b.keys_unsorted, b.vals_unsorted, radii, d.gx, d.gy); }
+        const bool odd = radix_passes(tile_bits) & 1;
+        uint32_t* t_in = odd ? b.tiles_alt : b.tiles;
+        uint32_t* v_in = odd ? b.vals_alt : b.vals;
+        { GOF_PROFILE("emit_instances", stream);
+        hipLaunchKernelGGL(emit_instances, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.dval_a, g.order_off, g.rec, radii,
+                           t_in, v_in, d.gx, d.gy); }
         GOF_LAUNCH_CHECK(stream, dbg);
-        const int end_bit = 32 + (int)higher_msb(d.ntiles);
-        { GOF_PROFILE("sort_pairs", stream);
-        GOF_HIP_CHECK(sort_pairs(b.sort_tmp, b.sort_tmp_bytes, b.keys_unsorted, b.keys, b.vals_unsorted, b.vals, R, end_bit, stream)); }
+        { GOF_PROFILE("sort_instances_by_tile", stream);
+        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream);
+        if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
-        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.keys, im.ranges);
+        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges);
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     return GOF_OK;
@@ -251,14 +273,23 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox,
-                       g.tiles_touched, g.clamped, g.flags); }
+                       g.tiles_touched, g.clamped, g.dkey_a, g.dval_a, g.flags); }
     GOF_LAUNCH_CHECK(stream, a->debug);
+    // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
+    { GOF_PROFILE("sort_gaussians_by_depth", stream);
+    uint32_t *kr = nullptr, *vr = nullptr;
+    GOF_HIP_CHECK(radix_sort_pairs_u32(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream));
+    if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)
+    const uint32_t* total_dev = nullptr;
     { GOF_PROFILE("scan_tiles", stream);
-    GOF_HIP_CHECK(scan_tiles(g.scan_tmp, g.scan_tmp_bytes, g.tiles_touched, g.point_offsets, (size_t)a->P, stream)); }
+    GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, g.dval_a, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
+                                  &total_dev, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
     uint32_t host_words[2] = { 0, 0 };
-    GOF_HIP_CHECK(hipMemcpyAsync(&host_words[0], g.point_offsets + a->P - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipMemcpyAsync(&host_words[0], total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (a->prefiltered)
         GOF_HIP_CHECK(hipMemcpyAsync(&host_words[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
@@ -369,7 +400,7 @@ int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float
     hipLaunchKernelGGL(preprocess_points, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, points3D, cam, a->W, a->H,
                        d.focal_x, d.focal_y, w.points2D, w.depths, w.tiles_touched);
     GOF_LAUNCH_CHECK(stream, a->debug);
-    GOF_HIP_CHECK(scan_tiles(w.scan_tmp, w.scan_tmp_bytes, w.tiles_touched, w.point_offsets, (size_t)PN, stream));
+    GOF_HIP_CHECK(device_scan_u32(w.tiles_touched, nullptr, w.point_offsets, (size_t)PN, true, w.scan_tmp, nullptr, stream));
     GOF_LAUNCH_CHECK(stream, a->debug);
     uint32_t n = 0;
     GOF_HIP_CHECK(hipMemcpyAsync(&n, w.point_offsets + PN - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -399,18 +430,29 @@ int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, 
     const Dims d = dims_of(a);
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
-    // points: createWithKeys + sort + ranges (rasterizer_impl.cu:720-752)
+    // points: createWithKeys + sort + ranges (rasterizer_impl.cu:720-752) -- same two-level sort as the Gaussians:
+    // visible points by depth (4 passes), then by tile (2 passes); stable, so ties keep ascending point id
     if (NI > 0) {
-        hipLaunchKernelGGL(point_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.points2D, w.depths, w.point_offsets,
-                           w.tiles_touched, pb.keys_unsorted, pb.vals_unsorted, d.gx, d.gy);
+        const int tile_bits = (int)higher_msb(d.ntiles);
+        hipLaunchKernelGGL(point_depth_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.depths, w.point_offsets,
+                           w.tiles_touched, pb.tiles, pb.vals);
         GOF_LAUNCH_CHECK(stream, a->debug);
-        const int end_bit = 32 + (int)higher_msb(d.ntiles);
-        GOF_HIP_CHECK(sort_pairs(pb.sort_tmp, pb.sort_tmp_bytes, pb.keys_unsorted, pb.keys, pb.vals_unsorted, pb.vals, NI, end_bit, stream));
+        uint32_t *kr = nullptr, *vr = nullptr;
+        GOF_HIP_CHECK(radix_sort_pairs_u32(pb.tiles, pb.vals, pb.tiles_alt, pb.vals_alt, NI, 32, pb.sort_tmp, &kr, &vr, stream));
+        // vr == pb.vals (even number of passes).  Tile keys of the depth-sorted ids go to the pair that makes the final result land in (tiles, vals)
+        const bool odd = radix_passes(tile_bits) & 1;
+        uint32_t* t_in = odd ? pb.tiles_alt : pb.tiles;
+        uint32_t* v_in = odd ? pb.vals_alt : pb.vals;
+        if (v_in != vr) GOF_HIP_CHECK(hipMemcpyAsync(v_in, vr, (size_t)NI * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(point_tile_keys, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, v_in, w.points2D, t_in, d.gx, d.gy);
+        GOF_LAUNCH_CHECK(stream, a->debug);
+        rc = sort_by_tile(pb, NI, t_in, v_in, tile_bits, stream);
+        if (rc) return rc;
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.point_ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (NI > 0) {
-        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.keys, im.point_ranges);
+        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     GOF_PROFILE("integrate_kernel", stream);
@@ -505,14 +547,18 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
     const std::string n(name);
     if (n == "depths" && geom_ws) { src = g.depths; count = P; bytes = P * 4; }
     else if (n == "tiles_touched" && geom_ws) { src = g.tiles_touched; count = P; bytes = P * 4; }
-    else if (n == "point_offsets" && geom_ws) { src = g.point_offsets; count = P; bytes = P * 4; }
     else if (n == "means2D" && geom_ws) { unpack = 0; per = 2; }
     else if (n == "conic_opacity" && geom_ws) { unpack = 1; per = 4; }
     else if (n == "rgb" && geom_ws) { unpack = 2; per = 3; }
     else if (n == "view2gaussian" && geom_ws) { unpack = 3; per = 10; }
     else if (n == "clamped" && geom_ws) { unpack = 4; per = 3; bytes_out = true; }
     else if (n == "point_list" && binning_ws) { src = b.vals; count = R; bytes = (size_t)R * 4; }
-    else if (n == "point_list_keys" && binning_ws) { src = b.keys; count = R; bytes = (size_t)R * 8; }
+    else if (n == "point_list_keys" && binning_ws && geom_ws) {
+        if (dst_bytes < (size_t)R * 8) { set_error("dst too small"); return GOF_E_INVALID; }
+        if (R) hipLaunchKernelGGL(rebuild_keys, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, b.vals, g.depths, static_cast<uint64_t*>(dst));
+        if (hipGetLastError() != hipSuccess) { set_error("rebuild_keys launch failed"); return GOF_E_DEVICE; }
+        return (int64_t)R;
+    }
     else if (n == "ranges" && image_ws) { src = im.ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
     else if (n == "point_ranges" && image_ws) { src = im.point_ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
     else if (n == "final_T" && image_ws) { src = im.final_T; count = 4 * HW; bytes = 4 * HW * 4; }

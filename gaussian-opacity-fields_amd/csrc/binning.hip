@@ -1,17 +1,21 @@
-// binning.hip -- tile binning: scan, key/value emission, stable radix sort, tile ranges.
+// binning.hip -- tile binning: which Gaussians cover which tile, front to back.
 //
-//   scan_tiles        K2  replaces cub::DeviceScan::InclusiveSum          (reference rasterizer_impl.cu:332)
-//   duplicate_keys    K4  replaces duplicateWithKeys                      (reference rasterizer_impl.cu:70-111)
-//   sort_pairs        K5  replaces cub::DeviceRadixSort::SortPairs        (reference rasterizer_impl.cu:355-363)
-//   tile_ranges       K6  replaces cudaMemset + identifyTileRanges        (reference rasterizer_impl.cu:365-373, 149-171)
-//   point_keys        K12 replaces createWithKeys                         (reference rasterizer_impl.cu:113-144)
+// Replaces, with the identical resulting order (reference rasterizer_impl.cu:332-373):
+//   cub InclusiveSum + duplicateWithKeys + cub SortPairs on (tile << 32 | depth) over 32 + log2(T) bits
+//   + cudaMemset + identifyTileRanges.
 //
-// Contract that matters for parity: keys are (tile << 32) | float_bits(depth); tiles of one
-// Gaussian are emitted y-major / x-minor; the sort is STABLE over bits [0, 32 + msb(tiles)), so
-// equal (tile, depth) entries keep ascending Gaussian index.
+// The reference sorts R instances with 64-bit keys (6 radix passes of 12 B/instance at 1600x1063).  The
+// same order -- per tile, ascending depth bits, ties in ascending Gaussian index -- is obtained with far
+// less traffic by sorting where the information lives:
+//   1. stable sort of the P Gaussians by the 32 depth bits (4 passes over P, not R); ties keep ascending id;
+//   2. exclusive scan of tiles_touched in that order -> first instance of every sorted Gaussian;
+//   3. emit instances in depth order: (tile id, Gaussian id), tiles y-major / x-minor as the reference;
+//   4. stable sort of the R instances by tile id only (ceil(log2(T)/8) = 2 passes of 8 B/instance);
+//   5. tile ranges from the boundaries of the sorted tile ids.
+// Equal (tile, depth) entries end up in ascending Gaussian index exactly as with the reference's single
+// stable sort, because both sorts are stable and step 3 preserves the order of step 1.
+// Scan and sort are the hand-written kernels of radix.hip.
 #include "gof_common.h"
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace gof {
 
@@ -28,93 +32,82 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-size_t scan_temp_bytes(size_t n)
-{
-    size_t bytes = 0;
-    uint32_t* p = nullptr;
-    (void)rocprim::inclusive_scan(nullptr, bytes, p, p, n, rocprim::plus<uint32_t>());
-    return bytes;
-}
-
-hipError_t scan_tiles(void* tmp, size_t tmp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t stream)
-{
-    return rocprim::inclusive_scan(tmp, tmp_bytes, in, out, n, rocprim::plus<uint32_t>(), stream);
-}
-
-size_t sort_temp_bytes(size_t n)
-{
-    size_t bytes = 0;
-    uint64_t* k = nullptr; uint32_t* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, n, 0, 64);
-    return bytes;
-}
-
-hipError_t sort_pairs(void* tmp, size_t tmp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
-                      const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit, hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, stream);
-}
-
+// one thread per depth-sorted Gaussian (replaces duplicateWithKeys, rasterizer_impl.cu:70-111)
 __global__ void __launch_bounds__(256)
-duplicate_keys(int P, const SplatRec* __restrict__ rec, const float* __restrict__ depths, const uint32_t* __restrict__ offsets,
-               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, const int32_t* __restrict__ radii, uint32_t gx, uint32_t gy)
+emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const SplatRec* __restrict__ rec,
+               const int32_t* __restrict__ radii, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t gy)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t idx = order[i];
     const int r = radii[idx];
     if (r > 0) {
-        uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
+        uint32_t off = order_off[i];
         const float px = rec[idx].f[REC_XY], py = rec[idx].f[REC_XY + 1];
         uint32_t minx, miny, maxx, maxy;
         get_rect(px, py, r, minx, miny, maxx, maxy, gx, gy);
-        const uint64_t dbits = __float_as_uint(depths[idx]);
         for (uint32_t y = miny; y < maxy; y++)
             for (uint32_t x = minx; x < maxx; x++) {
-                uint64_t key = y * gx + x;
-                key <<= 32;
-                key |= dbits;
-                keys[off] = key;
-                vals[off] = (uint32_t)idx;
+                tiles[off] = y * gx + x;
+                gids[off] = idx;
                 off++;
             }
     }
 }
 
+// query points: one instance per point inside the image (replaces createWithKeys, rasterizer_impl.cu:113-144);
+// emits the depth key and the point id of every visible point, compacted by the inclusive scan `offsets`
 __global__ void __launch_bounds__(256)
-point_keys(int PN, const float2* __restrict__ points2D, const float* __restrict__ depths, const uint32_t* __restrict__ offsets,
-           const uint32_t* __restrict__ tiles_touched, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx, uint32_t gy)
+point_depth_keys(int PN, const float* __restrict__ depths, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
+                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= PN) return;
     if (tiles_touched[idx] > 0) {
         const uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
-        const float2 p = points2D[idx];
-        const int x = (int)min(gx - 1, (uint32_t)max(0, (int)(p.x / TILE_X)));
-        const int y = (int)min(gy - 1, (uint32_t)max(0, (int)(p.y / TILE_Y)));
-        uint64_t key = (uint64_t)(y * gx + x);
-        key <<= 32;
-        key |= (uint64_t)__float_as_uint(depths[idx]);
-        keys[off] = key;
+        keys[off] = __float_as_uint(depths[idx]);
         vals[off] = (uint32_t)idx;
     }
 }
-
+// tile id of every (depth-sorted) visible point
 __global__ void __launch_bounds__(256)
-tile_ranges(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+point_tile_keys(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const float2* __restrict__ points2D, uint32_t* __restrict__ tiles,
+                uint32_t gx, uint32_t gy)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NI) return;
+    const float2 p = points2D[sorted_ids[i]];
+    const int x = (int)min(gx - 1, (uint32_t)max(0, (int)(p.x / TILE_X)));
+    const int y = (int)min(gy - 1, (uint32_t)max(0, (int)(p.y / TILE_Y)));
+    tiles[i] = (uint32_t)(y * gx + x);
+}
+
+// replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before
+__global__ void __launch_bounds__(256)
+tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+    const uint32_t currtile = tiles[idx];
     if (idx == 0) ranges[currtile].x = 0;
     else {
-        const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+        const uint32_t prevtile = tiles[idx - 1];
         if (currtile != prevtile) {
             ranges[prevtile].y = idx;
             ranges[currtile].x = idx;
         }
     }
     if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// debug: the reference's 64-bit sort key of every sorted instance (tile << 32 | depth bits)
+__global__ void __launch_bounds__(256)
+rebuild_keys(uint32_t R, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ gids, const float* __restrict__ depths,
+             uint64_t* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    keys[i] = ((uint64_t)tiles[i] << 32) | (uint64_t)__float_as_uint(depths[gids[i]]);
 }
 
 } // namespace gof

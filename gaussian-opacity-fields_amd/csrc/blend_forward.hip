@@ -32,9 +32,11 @@
 //  * XCD-aware tile order (xcd_tile_id): neighbouring tiles, which gather the same records, run on
 //    the same XCD and share its L2.
 //
-// Arithmetic: identical operation sequence to the oracle (fp32 products/sums in source order, fp64
-// for AA/BB/min_value, mapped depth, normal length and the final distortion normalisation, as
-// forward.cu:504-557, 589): every output is bit-identical to the oracle.
+// Arithmetic: identical operation sequence to the oracle (fp32 products/sums in source order, fp64 for
+// AA/BB/min_value, the mapped depth and the final distortion normalisation, forward.cu:504-557, 589):
+// colour, depth, alpha, distortion, final_T and n_contrib are bit-identical to the oracle.  The one
+// exception is the unit normal (hardware rsq instead of fp64 sqrt + 3 divisions): channels 3-5 agree
+// to ~3e-7.
 #include "gof_common.h"
 
 namespace gof {
@@ -165,8 +167,11 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const float4 q3 = s_rec[3][j];
             const float max_t = t;
             const float mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
-            const float length = (float)sqrt((double)(p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2) + 1e-7);
-            const float nn0 = -p.n0 / length, nn1 = -p.n1 / length, nn2 = -p.n2 / length;
+            // unit normal -n / |n|: the reference takes an fp64 sqrt and three IEEE divisions (forward.cu:548-549);
+            // here one v_rsq_f32 (<= 1 ulp).  Only the normal channels depend on it: they agree with the oracle to
+            // ~3e-7 instead of bit for bit; every other output is unaffected.
+            const float inv_len = __builtin_amdgcn_rsqf(p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2 + 1e-7f);
+            const float nn0 = -p.n0 * inv_len, nn1 = -p.n1 * inv_len, nn2 = -p.n2 * inv_len;
 
             const float A = 1 - T;
             const float error = mapped_max_t * mapped_max_t * A + dist2 - 2 * mapped_max_t * dist1;

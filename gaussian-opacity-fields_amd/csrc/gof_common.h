@@ -42,10 +42,14 @@ struct GeomWs {
     float4* conic;          // [P] conic.xyz (2D inverse covariance), w unused -- backward only
     float4* bbox;           // [P] conservative pixel bounding box {xlo, xhi, ylo, yhi} of the alpha >= 1/255 footprint
     uint32_t* tiles_touched;// [P]
-    uint32_t* point_offsets;// [P] inclusive scan
     uint8_t* clamped;       // [P] bit c set when colour channel c was clamped (forward.cu:67-69)
     uint32_t* flags;        // [4] device-side status words (prefilter violation, ...)
-    void* scan_tmp; size_t scan_tmp_bytes;
+    // depth ordering of the Gaussians (binning.hip): keys = float bits of the view depth (0xFFFFFFFF if culled)
+    uint32_t* dkey_a; uint32_t* dkey_b;   // [P]
+    uint32_t* dval_a; uint32_t* dval_b;   // [P]  dval_a holds the depth-sorted Gaussian ids after the sort
+    uint32_t* order_off;    // [P] exclusive scan of tiles_touched in depth order = first instance of the i-th sorted Gaussian
+    uint32_t* sort_tmp;     // radix / scan scratch (rs_tmp_words(P) + scan_tmp_words(P) words)
+    uint32_t* total;        // [1] device copy of num_rendered
 };
 // Image workspace (replaces ImageState, rasterizer_impl.h:57-67)
 struct ImageWs {
@@ -56,15 +60,15 @@ struct ImageWs {
 };
 // Binning workspace (replaces BinningState, rasterizer_impl.h:69-79)
 struct BinWs {
-    uint64_t* keys_unsorted; uint64_t* keys;      // [R]
-    uint32_t* vals_unsorted; uint32_t* vals;      // [R]  vals = sorted point_list
-    void* sort_tmp; size_t sort_tmp_bytes;
+    uint32_t* vals;  uint32_t* vals_alt;          // [R]  vals = sorted point_list (Gaussian ids, per tile, front to back)
+    uint32_t* tiles; uint32_t* tiles_alt;         // [R]  tiles = tile id of every sorted instance
+    uint32_t* sort_tmp;                           // rs_tmp_words(R) words
 };
 // Point workspace (replaces PointState, rasterizer_impl.h:47-55)
 struct PointWs {
-    float* depths; float2* points2D; uint32_t* tiles_touched; uint32_t* point_offsets;
+    float* depths; float2* points2D; uint32_t* tiles_touched; uint32_t* point_offsets;   // offsets: inclusive scan
     float* T_state;         // [PN] running transmittance of each query point (integrate pass 2)
-    void* scan_tmp; size_t scan_tmp_bytes;
+    uint32_t* scan_tmp;     // scan_tmp_words(PN) words
 };
 
 // camera matrices stay in device memory (no host copy, no sync); the addresses are wave-uniform so

@@ -178,7 +178,7 @@ preprocess_fwd(int P, int D, int M,
                uint32_t gx, uint32_t gy, int prefiltered,
                int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
                float4* __restrict__ conic_out, float4* __restrict__ bbox_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
-               uint32_t* __restrict__ flags)
+               uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -191,6 +191,7 @@ preprocess_fwd(int P, int D, int M,
     if (p_view.z <= 0.2f) {
         if (prefiltered) atomicOr(&flags[0], 1u);
         radii[idx] = 0; tiles_touched[idx] = 0;
+        depth_key[idx] = 0xFFFFFFFFu; depth_val[idx] = (uint32_t)idx;
         return;
     }
     do {
@@ -303,6 +304,9 @@ preprocess_fwd(int P, int D, int M,
     } while (0);
     radii[idx] = my_radii;
     tiles_touched[idx] = my_tiles;
+    // sort key of the binning stage: positive floats order like their bit patterns; culled Gaussians go last
+    depth_key[idx] = my_radii > 0 ? __float_as_uint(p_view.z) : 0xFFFFFFFFu;
+    depth_val[idx] = (uint32_t)idx;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -250,7 +250,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 
 _FETCH = {"depths": (torch.float32, 1), "means2D": (torch.float32, 2), "conic_opacity": (torch.float32, 4), "rgb": (torch.float32, 3),
-          "view2gaussian": (torch.float32, 10), "tiles_touched": (torch.int32, 1), "point_offsets": (torch.int32, 1),
+          "view2gaussian": (torch.float32, 10), "tiles_touched": (torch.int32, 1),
           "clamped": (torch.uint8, 3), "point_list": (torch.int32, 0), "point_list_keys": (torch.int64, 0),
           "ranges": (torch.int32, 0), "point_ranges": (torch.int32, 0), "final_T": (torch.float32, 0), "n_contrib": (torch.int32, 0)}
 

@@ -198,7 +198,7 @@ int gof_profile_report(char* buf, size_t cap);
 /* ---- introspection for tests / benchmarks (no reference counterpart) ------------------- */
 /* Copies one named intermediate array out of the workspaces into `dst` (device memory).
  * names: "depths" f32[P], "means2D" f32[P,2], "conic_opacity" f32[P,4], "rgb" f32[P,3],
- * "view2gaussian" f32[P,10], "tiles_touched" u32[P], "point_offsets" u32[P],
+ * "view2gaussian" f32[P,10], "tiles_touched" u32[P],
  * "clamped" u8[P,3], "point_list" u32[R], "point_list_keys" u64[R], "ranges" u32[T,2],
  * "final_T" f32[4,H,W], "n_contrib" u32[2,H,W].  Returns the element count or <0. */
 int64_t gof_debug_fetch(const char* name, const GofRasterArgs* args, uint32_t num_rendered,

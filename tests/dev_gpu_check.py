@@ -14,7 +14,7 @@ def run(P, W, H, focal, seed=0, ks=0.0):
     torch.cuda.synchronize()
     print(f"P={P} {W}x{H} R oracle={o.num_rendered()} product={res['R']} oracle_fwd={t_or:.2f}s")
     print(" radii equal:", np.array_equal(res["radii"].cpu().numpy(), orad))
-    for name in ["depths", "means2D", "conic_opacity", "rgb", "view2gaussian", "tiles_touched", "point_offsets", "clamped"]:
+    for name in ["depths", "means2D", "conic_opacity", "rgb", "view2gaussian", "tiles_touched", "clamped"]:
         a = fetch(res, name); b = o.fetch(name)
         vis = orad > 0
         if name in ("depths",): a = a[vis]; b = b[vis]

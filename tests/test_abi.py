@@ -37,7 +37,7 @@ def test_size_queries_are_host_only_and_monotone():
     assert L.gof_geom_bytes(1_000_000) >= 1_000_000 * (64 + 16 + 4 + 4 + 4 + 1)
     assert L.gof_image_bytes(1600, 1063) >= 1600 * 1063 * 24
     assert L.gof_binning_bytes(0, 400, 400) > 0
-    assert L.gof_binning_bytes(5_000_000, 1600, 1063) >= 5_000_000 * 24
+    assert L.gof_binning_bytes(5_000_000, 1600, 1063) >= 5_000_000 * 16
     assert L.gof_point_bytes(10) < L.gof_point_bytes(10_000_000)
 
 

@@ -97,7 +97,7 @@ def test_product_vs_reference_default_build_within_the_references_own_fma_band()
     pb, pm = np.percentile(band, qs), np.percentile(mine, qs)
     assert pm[0] < 1e-4, pm
     assert (pm <= 2.0 * pb + 1e-5).all(), (pm, pb)
-    assert np.abs(pc - rc2).max() <= 2e-5 * max(1.0, np.abs(rc2).max())       # vs the nofma build: only exp() differs
+    assert np.abs(pc - rc2).max() <= 2e-5 * max(1.0, np.abs(rc2).max())       # vs the nofma build: only exp() (and the normals' rsq) differ
     # gradients against the default build
     dL = np.random.default_rng(2).normal(size=rc.shape).astype(np.float32)
     gr = ref.backward(dL)
