@@ -7,13 +7,14 @@
 // over 32 + log2(tiles) bits (6 passes at 1600x1063); binning.hip instead sorts the P Gaussians by depth
 // once and then only the tile bits of the R instances (2 passes), which yields the identical order.
 //
-// Sort design: the unit of work is ONE WAVE owning a contiguous chunk of RS_CHUNK items.
-//   rs_hist    -- per-unit digit histogram (wave-level multisplit: 8 ballots give every lane the mask of
+// Sort design: a 256-thread block owns RS_BLOCK consecutive items, each of its 4 waves a contiguous quarter.
+//   rs_hist    -- per-block digit histogram (wave-level multisplit: 8 ballots give every lane the mask of
 //                 lanes holding the same digit; the lowest such lane adds the group size to an LDS counter)
-//   (scan)     -- exclusive scan of the flat [digit][unit] histogram = global offset of every (digit, unit)
-//   rs_scatter -- the wave streams its chunk again in index order; running per-digit cursors live in LDS;
-//                 an item's position is cursor[digit] + (number of same-digit lanes below it), which is a
-//                 STABLE rank because items are visited in ascending index order.
+//   (scan)     -- exclusive scan of the flat [digit][block] histogram = global offset of every (digit, block)
+//   rs_scatter -- keys/values stay in registers; a lane's rank is (per-wave LDS cursor of its digit) + (number
+//                 of same-digit lanes below it) -- a STABLE rank because waves own ascending quarters and visit
+//                 them in index order; the block exchanges the items through LDS into digit-sorted order and
+//                 writes each digit's run contiguously at its global offset (coalesced).
 #include "gof_common.h"
 
 namespace gof {
@@ -158,17 +159,20 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid)
     return peers;
 }
 
+// ---- block kernels: 256 threads, RS_BLOCK items; wave w owns the contiguous quarter [w*RS_BLOCK/4, ...) ----
+constexpr int RS_STEPS = RS_CHUNK / 64;              // steps of 64 items per wave
+constexpr int RS_BLOCK = 4 * RS_CHUNK;               // items per block
+
 __global__ void __launch_bounds__(256)
-rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nunits)
+rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblocks)
 {
     __shared__ uint32_t s_cnt[4][RS_DIGITS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t unit = blockIdx.x * 4 + wave;
 #pragma unroll
     for (int k = 0; k < 4; k++) s_cnt[wave][lane + 64 * k] = 0;
-    if (unit >= nunits) return;
-    const uint32_t begin = unit * RS_CHUNK;
-    for (int s = 0; s < RS_CHUNK / 64; s++) {
+    const uint32_t begin = blockIdx.x * RS_BLOCK + wave * RS_CHUNK;
+#pragma unroll 4
+    for (int s = 0; s < RS_STEPS; s++) {
         const uint32_t i = begin + s * 64 + lane;
         const bool ok = i < n;
         const uint64_t valid = __ballot(ok);
@@ -177,48 +181,88 @@ rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __re
         const uint64_t peers = match_digit(d, valid);
         if (ok && (uint32_t)(__ffsll((long long)peers) - 1) == lane) s_cnt[wave][d] += (uint32_t)__popcll(peers);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t d = lane + 64 * k;
-        hist[(size_t)d * nunits + unit] = s_cnt[wave][d];
-    }
+    __syncthreads();
+    const uint32_t d = threadIdx.x;
+    hist[(size_t)d * nblocks + blockIdx.x] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
+// Stable scatter of one block: keys/values are ranked in registers (wave-level multisplit with per-wave LDS
+// cursors), exchanged through LDS into digit-sorted order and written out as contiguous runs per digit.
 __global__ void __launch_bounds__(256)
 rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-           uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nunits)
+           uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblocks)
 {
-    __shared__ uint32_t s_cur[4][RS_DIGITS];
+    __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
+    __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
+    __shared__ uint32_t s_gbase[RS_DIGITS];      // global start of this block's run of every digit
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_key[RS_BLOCK];
+    __shared__ uint32_t s_val[RS_BLOCK];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t unit = blockIdx.x * 4 + wave;
-    if (unit >= nunits) return;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t d = lane + 64 * k;
-        s_cur[wave][d] = offs[(size_t)d * nunits + unit];
-    }
-    const uint32_t begin = unit * RS_CHUNK;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int s = 0; s < RS_CHUNK / 64; s++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_cur[wave][lane + 64 * k] = 0;
+    const uint32_t blk_begin = blockIdx.x * RS_BLOCK;
+    const uint32_t begin = blk_begin + wave * RS_CHUNK;
+
+    uint32_t key[RS_STEPS], val[RS_STEPS];
+    uint16_t rnk[RS_STEPS], cnt[RS_STEPS];       // rank among same-digit lanes of the step; group size (leader only)
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
+        const uint32_t i = begin + s * 64 + lane;
+        key[s] = 0xFFFFFFFFu; val[s] = 0;
+        if (i < n) { key[s] = keys_in[i]; val[s] = vals_in[i]; }
+    }
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
         const uint32_t i = begin + s * 64 + lane;
         const bool ok = i < n;
         const uint64_t valid = __ballot(ok);
-        if (valid == 0ull) break;
-        uint32_t k = 0, v = 0;
-        if (ok) { k = keys_in[i]; v = vals_in[i]; }
-        const uint32_t d = (k >> shift) & 0xFFu;
+        const uint32_t d = (key[s] >> shift) & 0xFFu;
         const uint64_t peers = match_digit(d, valid);
-        const uint32_t base = s_cur[wave][d];                       // all peers read the same cursor
-        const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        if (ok && rank == 0) s_cur[wave][d] = base + (uint32_t)__popcll(peers);   // lowest peer advances it
-        if (ok) {
-            keys_out[base + rank] = k;
-            vals_out[base + rank] = v;
+        const uint32_t r = (uint32_t)__popcll(peers & lt);
+        const uint32_t c = (uint32_t)__popcll(peers);
+        rnk[s] = (uint16_t)r;
+        cnt[s] = (uint16_t)((ok && r == 0) ? c : 0);
+        if (ok && r == 0) s_cur[wave][d] += c;
+    }
+    __syncthreads();
+    {   // digit d = threadIdx.x: wave bases (exclusive over waves), block start (exclusive over digits), global base
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = s_cur[0][d], c1 = s_cur[1][d], c2 = s_cur[2][d], c3 = s_cur[3][d];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t blk_total;
+        const uint32_t start = block_exclusive_scan(tot, &blk_total, s_scan);
+        s_bstart[d] = start;
+        s_gbase[d] = offs[(size_t)d * nblocks + blockIdx.x];
+        s_cur[0][d] = start; s_cur[1][d] = start + c0; s_cur[2][d] = start + c0 + c1; s_cur[3][d] = start + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
+        const uint32_t i = begin + s * 64 + lane;
+        const bool ok = i < n;
+        const uint32_t d = (key[s] >> shift) & 0xFFu;
+        const uint32_t base = ok ? s_cur[wave][d] : 0u;              // all lanes of a digit group read the same cursor
+        if (cnt[s]) s_cur[wave][d] = base + cnt[s];                 // the group's lowest lane advances it
+        if (ok) { s_key[base + rnk[s]] = key[s]; s_val[base + rnk[s]] = val[s]; }
+    }
+    __syncthreads();
+    const uint32_t blk_n = min((uint32_t)RS_BLOCK, n - blk_begin);
+#pragma unroll
+    for (int j = 0; j < RS_BLOCK / 256; j++) {
+        const uint32_t p = j * 256 + threadIdx.x;
+        if (p < blk_n) {
+            const uint32_t k = s_key[p];
+            const uint32_t d = (k >> shift) & 0xFFu;
+            const uint32_t g = s_gbase[d] + (p - s_bstart[d]);
+            keys_out[g] = k;
+            vals_out[g] = s_val[p];
         }
     }
 }
 
-uint32_t rs_units(size_t n) { return (uint32_t)((n + RS_CHUNK - 1) / RS_CHUNK); }
+uint32_t rs_units(size_t n) { return (uint32_t)((n + RS_BLOCK - 1) / RS_BLOCK); }   // blocks
 // u32 words of scratch: [256 * units] histogram + scan scratch
 size_t rs_tmp_words(size_t n) { const size_t h = (size_t)RS_DIGITS * rs_units(n); return h + scan_tmp_words(h) + 64; }
 
@@ -233,7 +277,7 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
         const size_t hwords = (size_t)RS_DIGITS * nunits;
         uint32_t* hist = tmp;
         uint32_t* scan_tmp = tmp + hwords;
-        const dim3 grid((nunits + 3) / 4), block(256);
+        const dim3 grid(nunits), block(256);
         for (int shift = 0; shift < end_bit; shift += 8) {
             hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits);
             hipError_t e = device_scan_u32(hist, nullptr, hist, hwords, false, scan_tmp, nullptr, stream);
