@@ -73,7 +73,9 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const uint32_t px = tx * TILE_X + (tid % TILE_X), py = ty * TILE_Y + (tid / TILE_X);
+    uint32_t lx, ly;
+    tile_pixel(tid, lx, ly);
+    const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const size_t HW = (size_t)W * H;
@@ -282,10 +284,13 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
             if (__ballot(contrib) == 0ull) continue;
 #pragma unroll
             for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
-            if ((lane & 15u) == 15u) {
+            // rows (16 lanes) in which no pixel contributed hold exact zeros: skip their LDS adds
+            const uint64_t cmask = __ballot(contrib);
+            const bool row_hit = ((cmask >> (lane & 48u)) & 0xFFFFull) != 0ull;
+            if ((lane & 15u) == 15u && row_hit) {
 #pragma unroll
                 for (int k = 0; k < NGRAD; k++) unsafeAtomicAdd(&s_acc[k][j], g[k]);
-                if (lane == 63u) s_touched[j] = 1u;
+                s_touched[j] = 1u;
             }
         }
         __syncthreads();

@@ -67,7 +67,9 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
-    const uint32_t px = tx * TILE_X + (tid % TILE_X), py = ty * TILE_Y + (tid / TILE_X);
+    uint32_t lx, ly;
+    tile_pixel(tid, lx, ly);
+    const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;

@@ -104,6 +104,23 @@ struct ProfileScope {
 };
 #define GOF_PROFILE(name, stream) gof::ProfileScope _gof_prof_scope_##__LINE__(name, stream)
 
+// thread -> pixel map inside a 16x16 tile.  Each wave64 covers an 8x8 pixel quadrant (lane l -> x = l % 8,
+// y = l / 8): a compact footprint intersects fewer splats than the reference's 16x4 strip, and a 16-lane DPP
+// row is an 8x2 pixel block.  Per-pixel results do not depend on the map.
+#ifndef GOF_WAVE_8X8
+#define GOF_WAVE_8X8 1
+#endif
+__device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t& lx, uint32_t& ly)
+{
+#if GOF_WAVE_8X8
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    lx = (lane & 7u) + 8u * (wave & 1u);
+    ly = (lane >> 3) + 8u * (wave >> 1);
+#else
+    lx = tid % TILE_X; ly = tid / TILE_X;
+#endif
+}
+
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (private L2s), so
 // give each XCD a contiguous band of tiles -- neighbouring tiles gather the same splat records.
 __device__ __forceinline__ uint32_t xcd_tile_id(uint32_t bid, uint32_t ntiles)
