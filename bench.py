@@ -172,8 +172,14 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["calls"])
     d = kernels[dom]
     achieved = d.get("GBps", 0.0)
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE): rocprofv3 cannot run
+    # inside this process, so the figure comes from the committed counter pass of the SAME workload (profiles/), or is null
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_s1m.json")
+    if P == 1_000_000 and (W, H) == (1600, 1063) and os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_corrected")
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": None,
+            "frac": round(achieved / 8000.0, 5), "traffic": traffic,
             "avg_ms": d["avg_ms"], "alg_bytes": alg_bytes.get(dom),
             "note": "dominant kernel by time; the blend kernels are VALU/LDS-bound (SURVEY 8d), the figure is their HBM floor on "
                     "algorithmic bytes; the HBM-bound stages are listed under 'kernels'",
