@@ -54,7 +54,7 @@ __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, 
                                const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity,
                                float* dL_dcolors, float* dL_dv2g, uint32_t gx, uint32_t ntiles);
 __global__ void integrate_kernel(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
-                                 const uint32_t* point_list, const SplatRec* rec, int W, int H, float focal_x, float focal_y,
+                                 const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H, float focal_x, float focal_y,
                                  const float2* points2D, const float* point_depths, float* point_T, const float* bg_color, float* final_T,
                                  uint32_t* n_contrib, float* out_color, float* out_alpha_integrated,
                                  float* out_color_integrated, uint32_t gx, uint32_t ntiles);
@@ -457,7 +457,7 @@ int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, 
     }
     GOF_PROFILE("integrate_kernel", stream);
     hipLaunchKernelGGL(integrate_kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, a->W, a->H, d.focal_x, d.focal_y, w.points2D, w.depths, w.T_state,
+                       im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, w.points2D, w.depths, w.T_state,
                        a->background, im.final_T, im.n_contrib, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;

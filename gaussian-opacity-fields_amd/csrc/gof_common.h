@@ -121,6 +121,16 @@ __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t& lx, uint32_t&
 #endif
 }
 
+// inverse of tile_pixel: thread id of the pixel (lx, ly) of a tile
+__device__ __forceinline__ uint32_t tile_thread(uint32_t lx, uint32_t ly)
+{
+#if GOF_WAVE_8X8
+    return (((lx >> 3) + 2u * (ly >> 3)) << 6) + ((ly & 7u) << 3) + (lx & 7u);
+#else
+    return ly * TILE_X + lx;
+#endif
+}
+
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (private L2s), so
 // give each XCD a contiguous band of tiles -- neighbouring tiles gather the same splat records.
 __device__ __forceinline__ uint32_t xcd_tile_id(uint32_t bid, uint32_t ntiles)

@@ -30,7 +30,7 @@ namespace gof {
 __global__ void __launch_bounds__(256)
 integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restrict__ point_ranges,
                  const uint32_t* __restrict__ gaussian_list, const uint32_t* __restrict__ point_list,
-                 const SplatRec* __restrict__ rec, int W, int H, float focal_x, float focal_y,
+                 const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y,
                  const float2* __restrict__ points2D, const float* __restrict__ point_depths, float* __restrict__ point_T,
                  const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  float* __restrict__ out_color, float* __restrict__ out_alpha_integrated, float* __restrict__ out_color_integrated,
@@ -40,7 +40,9 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
-    const uint32_t px = tx * TILE_X + (tid % TILE_X), py = ty * TILE_Y + (tid / TILE_X);
+    uint32_t lx, ly;
+    tile_pixel(tid, lx, ly);
+    const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
     const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const size_t HW = (size_t)W * H;
@@ -54,6 +56,8 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
 
     __shared__ float4 s_rec[4][TILE_PIX];
     __shared__ uint32_t s_used[8][TILE_PIX];
+    __shared__ float4 s_box[TILE_PIX];
+    const float pxf = (float)px, pyf = (float)py;
     __shared__ float s_pixcol[3][TILE_PIX];
     __shared__ uint32_t s_cnt[TILE_PIX];
     __shared__ uint32_t s_iter;
@@ -85,6 +89,7 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             const float4* src = reinterpret_cast<const float4*>(&rec[id]);
             const float4 a4 = src[0], b4 = src[1], c4 = src[2], d4 = src[3];
             s_rec[0][tid] = a4; s_rec[1][tid] = b4; s_rec[2][tid] = c4; s_rec[3][tid] = d4;
+            s_box[tid] = bbox[id];
         }
         __syncthreads();
 
@@ -95,8 +100,15 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             const int j0 = w * 32;
             const int j1 = (j0 + 32 < n) ? j0 + 32 : n;
             for (int j = j0; j < j1; j++) {
-                if (done) continue;
-                contributor++;
+                // conservative footprint box: a wave none of whose pixels can reach alpha >= 1/255 skips the entry (its
+                // list position is still counted below).  The box holds integer-rounded bounds {ceil(lo), floor(hi)} that
+                // are exact for integer pixel positions; the corner sub-rays sit at p +- 0.5, and p + 0.5 >= lo is implied
+                // by p + 1 >= ceil(lo), hence the widening by one full pixel.
+                const float4 bx = s_box[j];
+                const bool inbox = !done & (pxf + 1.0f >= bx.x) & (pxf - 1.0f <= bx.y) & (pyf + 1.0f >= bx.z) & (pyf - 1.0f <= bx.w);
+                if (__ballot(inbox) == 0ull) continue;
+                if (!inbox) continue;
+                contributor = (uint32_t)b * TILE_PIX + (uint32_t)j + 1u;      // 1-based list position
                 const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
                 const float wgt = c4.z;
                 bool used = false;
@@ -153,7 +165,7 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             const uint32_t pid = point_list[pi];
             const float2 xy = points2D[pid];
             const float ray_depth = point_depths[pid];
-            const uint32_t lp = ((uint32_t)xy.y - ty * TILE_Y) * TILE_X + ((uint32_t)xy.x - tx * TILE_X);
+            const uint32_t lp = tile_thread((uint32_t)xy.x - tx * TILE_X, (uint32_t)xy.y - ty * TILE_Y);
             float T, acc;
             if (b == 0) { T = 1.f; acc = 0.f; atomicAdd(&s_cnt[lp], 1u); }
             else { T = point_T[pid]; acc = out_alpha_integrated[pid]; }
@@ -213,7 +225,7 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
         if (n_iter > needed && prange.y > prange.x) {
             const uint32_t lastpid = point_list[prange.y - 1];
             const float2 lxy = points2D[lastpid];
-            const uint32_t llp = ((uint32_t)lxy.y - ty * TILE_Y) * TILE_X + ((uint32_t)lxy.x - tx * TILE_X);
+            const uint32_t llp = tile_thread((uint32_t)lxy.x - tx * TILE_X, (uint32_t)lxy.y - ty * TILE_Y);
             if (llp == tid) total += n_iter - needed;
         }
         out_color[8 * HW + pix_id] = (float)total;

@@ -65,7 +65,25 @@ SCENES = {
     "ragged": lambda: S.scene_frustum(20_000, W=333, H=211, focal=240.0, seed=4, bg=(0.3, 0.6, 0.9)),
     "long_lists": lambda: S.scene_frustum(3000, W=32, H=32, focal=24.0, seed=4, sigma_px=6.0),
     "mid100k": lambda: S.scene_frustum(100_000, W=800, H=528, focal=600.0, seed=5),
+    "stress_box": lambda: stress_scene(),
 }
+
+
+def stress_scene():
+    """Extremes for the culls (footprint box, fp32 cull): sub-pixel far splats (distance/scale ~ 3000), needles
+    (anisotropy up to 1:100), huge near splats that contain the camera plane, opacities around 1/255 and above 1."""
+    sc = S.scene_frustum(6000, W=200, H=136, focal=1200.0 * 200 / 1600, seed=11, sigma_px=1.0)
+    rng = np.random.default_rng(12)
+    P = sc["means3D"].shape[0]
+    z = sc["means3D"][:, 2]
+    k = P // 6
+    sc["scales"][:k] = (z[:k, None] / 150.0 * np.array([[0.35, 0.35, 0.35]])).astype(np.float32)          # sigma ~ 0.35 px: ratio ~ 2800 at full res
+    sc["scales"][k:2 * k] *= np.exp(rng.uniform(-2.3, 2.3, (k, 3))).astype(np.float32)                     # needles / discs
+    sc["scales"][2 * k:3 * k] = (z[2 * k:3 * k, None] * rng.uniform(0.2, 1.5, (k, 3))).astype(np.float32)   # huge: reach the camera plane
+    sc["opacities"][3 * k:4 * k] = rng.uniform(0.0035, 0.0045, (k, 1)).astype(np.float32)                   # around 1/255
+    sc["opacities"][4 * k:4 * k + 50] = 1.5                                                                   # above 1
+    sc["opacities"][4 * k + 50:4 * k + 60] = 0.0
+    return sc
 
 
 @pytest.mark.parametrize("name", list(SCENES))
@@ -230,6 +248,24 @@ def test_integrate_matches_oracle():
     assert np.array_equal(bits(a), bits(oal)), np.abs(a - oal).max()
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
     assert (a[-2:] == 1.0).all()          # points outside the image keep the initial 1.0 (rasterize_points.cu:277)
+
+
+def test_full_size_s1m_against_oracle():
+    """BASELINE config 2 at FULL size (1M Gaussians, 1600x1063) against the oracle on the GPU box's host cores:
+    forward bit-exact (normals 2e-6), blend gradients within 1e-4."""
+    sc = S.scene_frustum(1_000_000, seed=0)
+    o, oc, orad, res = _forward_pair(sc)
+    assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad)
+    assert _same(fetch(res, "point_list"), o.fetch("point_list"))
+    assert _same(fetch(res, "n_contrib"), o.fetch("n_contrib"))
+    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["color"].cpu().numpy(), oc)
+    dL = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
+    go = o.backward(dL)
+    gp = _product_backward(res, dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian"):
+        ref = go[k]; got = gp[k].reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
 
 
 def test_full_size_properties_s1m():
