@@ -48,8 +48,8 @@ __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* 
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
-                              float* out_color, uint32_t gx, uint32_t ntiles);
-__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const float4* bbox,
+                              float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
+__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity,
                                float* dL_dcolors, float* dL_dv2g, uint32_t gx, uint32_t ntiles);
@@ -141,15 +141,16 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
 }
 size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out)
 {
-    (void)W; (void)H;
     BinWs b;
     char* p = static_cast<char*>(base);
     const size_t n = (size_t)R;
+    const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     carve(p, b.vals, n);            // sorted point_list first: the only part the backward reads
     carve(p, b.tiles, n);
     carve(p, b.vals_alt, n);
     carve(p, b.tiles_alt, n);
     carve(p, b.sort_tmp, rs_tmp_words(n));
+    carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
     if (out) *out = b;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -326,7 +327,7 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, d.gx, d.ntiles); }
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -369,7 +370,7 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                           im.ranges, b.vals, g.rec, g.conic, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
+                           im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
                            im.n_contrib, dL_dout, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian, d.gx, d.ntiles);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }

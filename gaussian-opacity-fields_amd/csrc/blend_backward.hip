@@ -17,9 +17,11 @@
 //  * Entries behind the last contributor of EVERY pixel of the tile are never staged: the
 //    traversal starts at max-over-tile(last_contributor) (the reference stages the full list and
 //    skips per pixel, backward.cu:763-765).
-//  * Two conservative culls before the exact fp64 division / exp: the per-Gaussian footprint box
-//    (preprocess_fwd: footprint_bbox; 4 compares, wave-level skip) and the error-bounded fp32 test
-//    (pair_certainly_transparent).
+//  * WHICH (pixel, entry) pairs contribute is not re-derived: blend_forward leaves one bit per pixel and
+//    list position (contributor masks, see cmask_base); a wave visits only the entries in which one of
+//    its pixels has the bit set and recomputes alpha for exactly those lanes with the forward's exact
+//    arithmetic.  (The set is the one the reference's backward re-discovers with its position /
+//    alpha-threshold tests, backward.cu:763-805.)
 //  * alpha, T and the contributor bookkeeping use the exact arithmetic of the forward (they decide
 //    WHICH pairs contribute, bit-identically to the forward pass); the gradient formulas downstream
 //    are evaluated in fp32 with hardware rcp/rsq (<= 2 ulp).  The reference itself rounds every
@@ -63,10 +65,10 @@ __device__ __forceinline__ float row_sum(float v)
 
 __global__ void __launch_bounds__(256)
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-               const float4* __restrict__ conic, const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
-               const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-               float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
-               float* __restrict__ dL_dv2g, uint32_t gx, uint32_t ntiles)
+               const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
+               const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+               const float* __restrict__ dL_dpixels, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
+               float* __restrict__ dL_dcolors, float* __restrict__ dL_dv2g, uint32_t gx, uint32_t ntiles)
 {
     const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -85,14 +87,14 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const float pxm = (float)px, pym = (float)py;   // pixf - 0.5 (backward.cu:770), exact
 
     const uint2 range = ranges[tile];
+    const uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
 
     __shared__ float4 s_rec[4][BATCH];
     __shared__ float4 s_conic[BATCH];
-    __shared__ float4 s_box[BATCH];
     __shared__ uint32_t s_id[BATCH];
-    __shared__ float s_thr[BATCH];
     __shared__ float s_acc[NGRAD][BATCH];
     __shared__ uint32_t s_touched[BATCH];
+    __shared__ uint32_t s_cm[BATCH / 32][TILE_PIX];
     __shared__ uint32_t s_max_last;
 
     const float T_final = inside ? final_Ts[pix_id] : 0;
@@ -126,11 +128,6 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const uint32_t max_last = min(s_max_last, range.y - range.x);
     if (max_last == 0) return;
 
-    int toDo = (int)max_last;
-    const int rounds = (toDo + BATCH - 1) / BATCH;
-    uint32_t contributor = max_last;   // entries [max_last, list length) are skipped by every pixel
-    const uint32_t list_end = range.x + max_last;
-
     float acc0 = 0, acc1 = 0, acc2 = 0;          // accum_rec
     float lc0 = 0, lc1 = 0, lc2 = 0;             // last_color
     float an0 = 0, an1 = 0, an2 = 0;             // accum_normal_rec
@@ -142,59 +139,56 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const float MAP_A = (float)(GOF_FAR_PLANE / (GOF_FAR_PLANE - GOF_NEAR_PLANE));
     const float MAP_B = (float)(GOF_FAR_PLANE * GOF_NEAR_PLANE / (GOF_FAR_PLANE - GOF_NEAR_PLANE));
 
-    for (int i = 0; i < rounds; i++, toDo -= BATCH) {
+    // batches are aligned to the list start (so that they line up with the forward's mask words) and visited from
+    // the back: batch kb covers list positions [kb * BATCH, min((kb + 1) * BATCH, max_last))
+    const int nbatches = (int)((max_last + BATCH - 1) / BATCH);
+    for (int kb = nbatches - 1; kb >= 0; kb--) {
         __syncthreads();
+        const uint32_t p0 = (uint32_t)kb * BATCH;
+        const int n = (int)min((uint32_t)BATCH, max_last - p0);
         {
             // staging: BATCH entries by 256 threads -> (256 / BATCH) threads share one 64-byte record
             constexpr int TPE = TILE_PIX / BATCH;            // threads per entry: 1 or 2
             constexpr int F4 = 4 / TPE;                      // float4 per thread
             const uint32_t e = tid / TPE, part = tid % TPE;
-            const uint32_t progress = (uint32_t)i * BATCH + e;
-            if (range.x + progress < list_end) {
-                const uint32_t id = point_list[list_end - progress - 1];
+            if ((int)e < n) {
+                const uint32_t id = point_list[range.x + p0 + e];
                 const float4* src = reinterpret_cast<const float4*>(&rec[id]) + part * F4;
-                float4 r4[F4];
 #pragma unroll
-                for (int q = 0; q < F4; q++) r4[q] = src[q];
-#pragma unroll
-                for (int q = 0; q < F4; q++) s_rec[part * F4 + q][e] = r4[q];
+                for (int q = 0; q < F4; q++) s_rec[part * F4 + q][e] = src[q];
                 if (part == 0) {
                     s_conic[e] = conic[id];
                     s_id[e] = id;
-                    s_box[e] = bbox[id];
                 }
-                if (part == TPE - 1) s_thr[e] = cull_log_threshold(r4[(2 % F4)].z);   // f[10] lives in float4 #2, component z
             }
+            const int nw = (n + 31) >> 5;
+#pragma unroll
+            for (int q = 0; q < BATCH / 32; q++)
+                s_cm[q][tid] = (q < nw) ? cm_tile[((size_t)(p0 >> 5) + q) * TILE_PIX + tid] : 0u;
             for (int k = tid; k < NGRAD * BATCH; k += TILE_PIX) (&s_acc[0][0])[k] = 0.f;
             if (tid < BATCH) s_touched[tid] = 0;
         }
         __syncthreads();
 
-        const int n = min(BATCH, toDo);
-        for (int j = 0; j < n; j++) {
-            contributor--;
-            const float4 bx = s_box[j];
-            const bool active = inside && (contributor < last_contributor) &&
-                                (pxm >= bx.x) & (pxm <= bx.y) & (pym >= bx.z) & (pym <= bx.w);   // conservative footprint box
-            if (__ballot(active) == 0ull) continue;
+        for (int w = ((n + 31) >> 5) - 1; w >= 0; w--) {
+            const uint32_t word = s_cm[w][tid];
+            if (__ballot(word != 0u) == 0ull) continue;            // no pixel of this wave has a contributor in these 32 entries
+            for (int b = 31; b >= 0; b--) {
+                const bool contrib = (word >> b) & 1u;
+                if (__ballot(contrib) == 0ull) continue;
+                const int j = w * 32 + b;
+                const uint32_t contributor = p0 + (uint32_t)j;       // 0-based list position (backward.cu:763)
 
-            const float4 a = s_rec[0][j], b = s_rec[1][j], c = s_rec[2][j];
-            const float v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y };
-            const float w = c.z;
-            PairEval p;
-            pair_prelude(v, rx, ry, p);
-            const bool maybe = active && !pair_certainly_transparent(p, c.y, s_thr[j]);
-            if (__ballot(maybe) == 0ull) continue;
-
-            float g[NGRAD];
+                float g[NGRAD];
 #pragma unroll
-            for (int k = 0; k < NGRAD; k++) g[k] = 0.f;
-            bool contrib = false;
-            if (maybe) {
-                pair_exact(v, w, p);
-                if (!p.skip) {
-                    contrib = true;
-                    const float4 d = s_rec[3][j];
+                for (int k = 0; k < NGRAD; k++) g[k] = 0.f;
+                if (contrib) {
+                    const float4 a = s_rec[0][j], bq = s_rec[1][j], c = s_rec[2][j], d = s_rec[3][j];
+                    const float v[10] = { a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x, c.y };
+                    const float wgt = c.z;
+                    PairEval p;
+                    pair_prelude(v, rx, ry, p);
+                    pair_exact(v, wgt, p);                          // same arithmetic as the forward: alpha, G, t are bit-identical
                     const float4 con = s_conic[j];
                     const float G = p.G, alpha = p.alpha;
                     const float dx = d.z - pxm, dy = d.w - pym;
@@ -250,7 +244,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     last_alpha = alpha;
                     dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(1.f - alpha)) * bg_dot_dpixel;
 
-                    const float dL_dG = w * dL_dalpha;
+                    const float dL_dG = wgt * dL_dalpha;
                     const float gdx = G * dx;
                     const float gdy = G * dy;
                     const float dG_ddelx = -gdx * con.x - gdy * con.y;
@@ -280,17 +274,16 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     g[15] = dL_dB * 2;
                     g[16] = dL_dmin_value;
                 }
-            }
-            if (__ballot(contrib) == 0ull) continue;
 #pragma unroll
-            for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
-            // rows (16 lanes) in which no pixel contributed hold exact zeros: skip their LDS adds
-            const uint64_t cmask = __ballot(contrib);
-            const bool row_hit = ((cmask >> (lane & 48u)) & 0xFFFFull) != 0ull;
-            if ((lane & 15u) == 15u && row_hit) {
+                for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
+                // rows (16 lanes = 8x2 pixels) in which no pixel contributed hold exact zeros: skip their LDS adds
+                const uint64_t cmask64 = __ballot(contrib);
+                const bool row_hit = ((cmask64 >> (lane & 48u)) & 0xFFFFull) != 0ull;
+                if ((lane & 15u) == 15u && row_hit) {
 #pragma unroll
-                for (int k = 0; k < NGRAD; k++) unsafeAtomicAdd(&s_acc[k][j], g[k]);
-                s_touched[j] = 1u;
+                    for (int k = 0; k < NGRAD; k++) unsafeAtomicAdd(&s_acc[k][j], g[k]);
+                    s_touched[j] = 1u;
+                }
             }
         }
         __syncthreads();

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256)
 blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
               const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-              uint32_t gx, uint32_t ntiles)
+              uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles)
 {
     const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -84,6 +84,7 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     __shared__ float4 s_rec[4][TILE_PIX];
     __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
     __shared__ float4 s_box[TILE_PIX];
+    uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
     const float pxf = (float)px, pyf = (float)py;
 
     bool done = !inside;
@@ -105,11 +106,16 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             s_box[tid] = bbox[id];
         }
         __syncthreads();
-        if (__ballot(!done) == 0ull) continue;   // whole wave saturated: it only helps staging
+        const int nwords_batch = (min(TILE_PIX, toDo) + 31) >> 5;
+        if (__ballot(!done) == 0ull) {             // whole wave saturated: it only helps staging (and reports "no contributors")
+            for (int q = 0; q < nwords_batch; q++) cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = 0u;
+            continue;
+        }
 
         const int n = min(TILE_PIX, toDo);
         const uint32_t base = (uint32_t)i * TILE_PIX;
 
+        int words_valid = 0;                     // mask words of this batch that hold contributor bits (wave-uniform)
         for (int c0 = 0; c0 < n; c0 += FW_CHUNK) {
         if (__ballot(!done) == 0ull) break;
         const int cn = min(FW_CHUNK, n - c0);            // entries [c0, c0 + cn) of the staged batch
@@ -141,13 +147,14 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
         // ---- phase 2: every lane consumes its own candidates in list order ----
         int w = w0;
         uint32_t cur = s_mask[w0][tid];
+        uint32_t cbits = 0;                              // contributor bits of word w (flushed when w advances)
         for (;;) {
             const bool more = !done && (cur != 0u || w + 1 < nw);
             if (__ballot(more) == 0ull) break;
             if ((tid & 63) == 0) STAT_ADD(2, 1);
             if (!more) continue;
             STAT_ADD(5, 1);
-            if (cur == 0u) { w++; cur = s_mask[w][tid]; }
+            if (cur == 0u) { s_mask[w][tid] = cbits; cbits = 0; w++; cur = s_mask[w][tid]; }   // a consumed word becomes its contributor word
             if (cur == 0u) continue;
             const int b = __ffs((int)cur) - 1;
             cur &= cur - 1u;
@@ -191,8 +198,14 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             Al += alpha * T;
             T = test_T;
             last_contributor = contributor;
+            cbits |= 1u << b;
         }
+        s_mask[w][tid] = cbits;
+        for (int q = w + 1; q < nw; q++) s_mask[q][tid] = 0u;       // candidate words this pixel never reached (it saturated)
+        words_valid = nw;
         }   // chunk
+        for (int q = 0; q < nwords_batch; q++)
+            cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = (q < words_valid) ? s_mask[q][tid] : 0u;
     }
 
     if (inside) {

@@ -63,6 +63,7 @@ struct BinWs {
     uint32_t* vals;  uint32_t* vals_alt;          // [R]  vals = sorted point_list (Gaussian ids, per tile, front to back)
     uint32_t* tiles; uint32_t* tiles_alt;         // [R]  tiles = tile id of every sorted instance
     uint32_t* sort_tmp;                           // rs_tmp_words(R) words
+    uint32_t* cmask;                              // [cmask_words(R, T)][256] contributor bit masks written by blend_forward
 };
 // Point workspace (replaces PointState, rasterizer_impl.h:47-55)
 struct PointWs {
@@ -130,6 +131,14 @@ __device__ __forceinline__ uint32_t tile_thread(uint32_t lx, uint32_t ly)
     return ly * TILE_X + lx;
 #endif
 }
+
+// Contributor masks: for every pixel of a tile one bit per tile-list position, set by blend_forward when that
+// entry contributed to the pixel (passed the alpha test before the pixel saturated) -- exactly the set of pairs the
+// backward has to visit (backward.cu:763-805).  Tile t's words start at cmask_base(ranges[t].x, t): since
+// sum_{t' < t} ceil(len_t' / 32) <= ranges[t].x / 32 + t, the bases need no scan and never overlap.
+// Layout [word][thread] (256 threads), so a wave reads / writes 256 contiguous bytes per word.
+__host__ __device__ inline size_t cmask_words(size_t R, size_t ntiles) { return R / 32 + ntiles + 2; }
+__device__ __forceinline__ size_t cmask_base(uint32_t range_start, uint32_t tile) { return (size_t)(range_start >> 5) + tile; }
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (private L2s), so
 // give each XCD a contiguous band of tiles -- neighbouring tiles gather the same splat records.
