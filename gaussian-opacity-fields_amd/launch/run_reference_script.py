@@ -11,7 +11,11 @@ What it does, in this order (nothing in the reference checkout is edited):
      real modules are importable;
   3. rebinds utils.tetmesh.marching_tetrahedra to the HIP implementation BEFORE the script imports it by name
      (extract_mesh.py:14: `from utils.tetmesh import marching_tetrahedra`);
-  4. runs the script with runpy as __main__ with the remaining argv.
+  4. rebinds the per-iteration training epilogue to its HIP implementation (train_epilogue/, include/gof_train_hip.h):
+     utils.loss_utils.ssim (train.py:20), utils.depth_utils.depth_to_normal / depths_to_points (train.py:38) and the
+     optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups).
+     GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations;
+  5. runs the script with runpy as __main__ with the remaining argv.
 """
 import importlib
 import os
@@ -19,6 +23,39 @@ import runpy
 import sys
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rebind_train_epilogue():
+    """Swap the reference's pure-torch loss helpers and optimizer for the HIP ones, by name, before the script's
+    `from ... import` statements run.  Modules that are not importable (a script that does not train) are skipped."""
+    import train_epilogue as T
+    try:
+        import utils.loss_utils as ref_loss
+        ref_loss.ssim = T.ssim
+    except ImportError:
+        pass
+    try:
+        import utils.depth_utils as ref_depth
+        ref_depth.depth_to_normal = T.depth_to_normal
+        ref_depth.depths_to_points = T.depths_to_points
+    except ImportError:
+        pass
+    try:
+        from scene.gaussian_model import GaussianModel
+    except Exception:
+        return
+    _setup = GaussianModel.training_setup
+
+    def training_setup(self, training_args):
+        _setup(self, training_args)
+        groups = self.optimizer.param_groups               # six named groups with their lr (gaussian_model.py:349-358)
+        old = self.optimizer
+        self.optimizer = T.FusedAdam([{"params": g["params"], "lr": g["lr"], "name": g["name"]} for g in groups], lr=0.0, eps=1e-15)
+        for hook in getattr(old, "_optimizer_step_pre_hooks", {}).values():      # e.g. the DP gradient all-reduce (run_train_dp.py)
+            self.optimizer.register_step_pre_hook(hook)
+        for hook in getattr(old, "_optimizer_step_post_hooks", {}).values():
+            self.optimizer.register_step_post_hook(hook)
+    GaussianModel.training_setup = training_setup
 
 
 def main():
@@ -43,6 +80,8 @@ def main():
         ref_tetmesh.marching_tetrahedra = hip_tetmesh.marching_tetrahedra
     except ImportError:
         pass
+    if os.environ.get("GOF_TORCH_EPILOGUE", "0") != "1":
+        rebind_train_epilogue()
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name="__main__")
 

@@ -1,0 +1,80 @@
+/*
+ * gof_train_hip.h -- C ABI of the training-iteration epilogue in libgof_hip.so:
+ * the per-iteration work of the reference's train.py that surrounds the rasterizer and becomes the
+ * dominant cost once the rasterizer takes < 5 ms -- SSIM, the depth->normal map of the depth-normal
+ * consistency loss, and the Adam update of the 59 floats per Gaussian.
+ *
+ * In the reference these are pure-torch functions (no native symbol):
+ *   utils/loss_utils.py:30-63    ssim / _ssim            (5 depthwise 11x11 conv2d + elementwise, autograd)
+ *   utils/depth_utils.py:6-35    depths_to_points / depth_to_normal (meshgrid, 2 matmuls, cross, normalize, autograd)
+ *   scene/gaussian_model.py:360  torch.optim.Adam(l, lr=0.0, eps=1e-15)   (torch 2.x foreach implementation)
+ * The Python mirrors (`loss_utils.ssim`, `depth_utils.depth_to_normal`, `optim.FusedAdam` in the package)
+ * keep the reference's names, arguments and error behaviour and are rebound into the unchanged train.py by
+ * launch/run_reference_script.py.
+ *
+ * Conventions as in gof_hip.h: extern "C", device pointers unless the name ends in `_host`, caller-owned
+ * buffers, asynchronous on `stream` (a hipStream_t passed as void*), 0 = ok / negative GOF_E_* with text
+ * in gof_last_error().
+ */
+#ifndef GOF_TRAIN_HIP_H_INCLUDED
+#define GOF_TRAIN_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOF_SSIM_WINDOW 11   /* utils/loss_utils.py:30 (window_size default; the only value the reference uses) */
+
+/* ---- SSIM (utils/loss_utils.py:43-63) ---------------------------------------------------- */
+/* img1, img2: [planes,H,W] (planes = batch*channels; every plane is convolved with the same window, the
+ * `groups=channel` depthwise conv2d of loss_utils.py:44-52, zero padding 5).  window_host: the 11 fp32
+ * taps of loss_utils.py:22-24 (host memory).  Writes plane_sums[planes] = sum over the plane of ssim_map
+ * (the caller divides: .mean() of loss_utils.py:60-63).  If dmaps != NULL also writes the three partial
+ * derivative maps [3,planes,H,W] (d ssim_map / d mu1, d sigma1_sq, d sigma12) the backward convolves.
+ * scratch: gof_ssim_scratch_bytes(). */
+size_t gof_ssim_scratch_bytes(int32_t planes, int32_t W, int32_t H);
+int gof_ssim_forward(int32_t planes, int32_t W, int32_t H,
+                     const float* img1, const float* img2, const float* window_host,
+                     float* plane_sums, float* dmaps,
+                     void* scratch, size_t scratch_bytes, void* stream);
+/* dL_dimg1[plane] = plane_scale[plane] * (conv(dm_dmu1) + 2 img1 conv(dm_dsigma1_sq) + img2 conv(dm_dsigma12)):
+ * what autograd produces for `ssim(img1, img2)` w.r.t. img1 when d loss / d ssim_map = plane_scale[plane]
+ * for every pixel of the plane.  img2 (the ground-truth image) gets no gradient. */
+int gof_ssim_backward(int32_t planes, int32_t W, int32_t H,
+                      const float* img1, const float* img2, const float* window_host,
+                      const float* dmaps, const float* plane_scale,
+                      float* dL_dimg1, void* stream);
+
+/* ---- depth -> points -> normals (utils/depth_utils.py:6-35) ----------------------------- */
+/* depth [H,W]; world_view_transform [16] as stored by scene/cameras.py:56 (the transposed world-to-camera
+ * matrix; depth_utils.py:7 inverts its transpose); fx, fy as depth_utils.py:9-10 computes them.
+ * Writes points [H,W,3] (depth_utils.py:20) and normals [H,W,3] (zero on the 1-pixel border, depth_utils.py:30-34). */
+int gof_depth_to_normal(int32_t W, int32_t H, const float* depth, const float* world_view_transform,
+                        float fx, float fy, float* normals, float* points, void* stream);
+/* Gradient of the above w.r.t. depth given dL_dnormals [H,W,3] and (nullable) dL_dpoints [H,W,3]. */
+int gof_depth_to_normal_backward(int32_t W, int32_t H, const float* depth, const float* world_view_transform,
+                                 float fx, float fy, const float* dL_dnormals, const float* dL_dpoints,
+                                 float* dL_ddepth, void* stream);
+
+/* ---- Adam (scene/gaussian_model.py:360; torch/optim/adam.py _multi_tensor_adam, no weight decay / amsgrad) */
+typedef struct GofAdamTensor {
+    float* param;             /* [n] updated in place                          */
+    const float* grad;        /* [n]                                           */
+    float* exp_avg;           /* [n] updated in place                          */
+    float* exp_avg_sq;        /* [n] updated in place                          */
+    uint64_t n;
+    float step_size;          /* -lr / (1 - beta1^step)  (host computes, as adam.py does in Python floats) */
+    float bias_correction2_sqrt; /* sqrt(1 - beta2^step)                        */
+} GofAdamTensor;
+#define GOF_ADAM_MAX_TENSORS 16
+/* One launch updates up to GOF_ADAM_MAX_TENSORS tensors (the six parameter groups of the reference). */
+int gof_adam_step(int32_t n_tensors, const GofAdamTensor* tensors_host,
+                  float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""CPU restatement of the training-epilogue functions of the reference (TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product path).
+
+Each function follows the reference file:line it cites and runs on CPU tensors, so that torch autograd of the
+restatement is the gradient oracle.  Pinned against the reference's own Python (executed where it lies, on CPU) by
+tests/golden/make_golden_train.py -> tests/golden/ref_train_epilogue_golden.npz (tests/test_train_epilogue_oracle.py).
+"""
+import math
+from math import exp
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---- utils/loss_utils.py ------------------------------------------------------------------------------
+def l1_loss(network_output, gt):                     # loss_utils.py:17-18
+    return torch.abs((network_output - gt)).mean()
+
+
+def gaussian_window_1d(window_size=11, sigma=1.5):   # loss_utils.py:22-24
+    g = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """loss_utils.py:26-63 (create_window + ssim + _ssim)."""
+    channel = img1.size(-3)
+    w1 = gaussian_window_1d(window_size).unsqueeze(1)                      # :27
+    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)                   # :28
+    window = w2.expand(channel, 1, window_size, window_size).contiguous().type_as(img1)   # :29, :39
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)              # :44-45
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2            # :47-49
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq   # :51-53
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2                                          # :54-55
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))   # :57
+    if size_average:
+        return ssim_map.mean()                                             # :60
+    return ssim_map.mean(1).mean(1).mean(1)                                # :62
+
+
+# ---- utils/depth_utils.py -----------------------------------------------------------------------------
+def depths_to_points(world_view_transform, W, H, FoVx, FoVy, depthmap):
+    """depth_utils.py:6-21 with the camera fields passed explicitly (the reference hard-codes .cuda())."""
+    c2w = (world_view_transform.T).inverse()                               # :7
+    fx = W / (2 * math.tan(FoVx / 2.))                                     # :9-10
+    fy = H / (2 * math.tan(FoVy / 2.))
+    intrins = torch.tensor([[fx, 0., W / 2.], [0., fy, H / 2.], [0., 0., 1.0]]).float()   # :11-15
+    grid_x, grid_y = torch.meshgrid(torch.arange(W).float() + 0.5, torch.arange(H).float() + 0.5, indexing='xy')  # :16
+    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)   # :17
+    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T                  # :18
+    rays_o = c2w[:3, 3]                                                    # :19
+    return depthmap.reshape(-1, 1) * rays_d + rays_o                       # :20
+
+
+def depth_to_normal(world_view_transform, W, H, FoVx, FoVy, depth):
+    """depth_utils.py:24-35."""
+    points = depths_to_points(world_view_transform, W, H, FoVx, FoVy, depth).reshape(*depth.shape[1:], 3)   # :29
+    output = torch.zeros_like(points)                                      # :30
+    dx = torch.cat([points[2:, 1:-1] - points[:-2, 1:-1]], dim=0)          # :31
+    dy = torch.cat([points[1:-1, 2:] - points[1:-1, :-2]], dim=1)          # :32
+    normal_map = F.normalize(torch.cross(dx, dy, dim=-1), dim=-1)          # :33
+    output[1:-1, 1:-1, :] = normal_map                                     # :34
+    return output, points
+
+
+# ---- torch/optim/adam.py (the optimizer scene/gaussian_model.py:360 builds) ----------------------------
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-15):
+    """One step of torch.optim.Adam (no weight decay, no amsgrad) in fp32 numpy, operation order of
+    torch/optim/adam.py::_single_tensor_adam.  `step` is the 1-based step count.  Returns (param, exp_avg, exp_avg_sq)."""
+    f = np.float32
+    p, g, m, v = (np.asarray(a, dtype=f) for a in (param, grad, exp_avg, exp_avg_sq))
+    m = m + f(1 - beta1) * (g - m)                                         # exp_avg.lerp_(grad, 1 - beta1)
+    v = v * f(beta2) + (f(1 - beta2) * g) * g                              # mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    bias_correction1 = 1 - beta1 ** step
+    bias_correction2 = 1 - beta2 ** step
+    step_size = lr / bias_correction1
+    bias_correction2_sqrt = bias_correction2 ** 0.5
+    denom = np.sqrt(v) / f(bias_correction2_sqrt) + f(eps)                 # (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p + (f(-step_size) * m) / denom                                    # param.addcdiv_(exp_avg, denom, value=-step_size)
+    return p.astype(f), m.astype(f), v.astype(f)

@@ -1,4 +1,4 @@
-"""CPU-only: the C-ABI library loads and exports every symbol include/gof_hip.h declares;
+"""CPU-only: the C-ABI library loads and exports every symbol include/*.h declares;
 host-only size queries behave."""
 import ctypes
 import os
@@ -10,7 +10,8 @@ LIB = os.path.join(ROOT, "gaussian-opacity-fields_amd", "lib", "libgof_hip.so")
 
 
 def declared_functions():
-    src = open(HEADER).read()
+    inc = os.path.join(ROOT, "include")
+    src = "\n".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(gof_[a-z0-9_]+)\s*\(", src)))
 
@@ -23,7 +24,7 @@ def test_library_exists_and_loads():
 def test_every_declared_symbol_is_exported():
     lib = ctypes.CDLL(LIB)
     names = declared_functions()
-    assert len(names) >= 15
+    assert len(names) >= 22 and "gof_adam_step" in names and "gof_forward_render" in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
 
@@ -61,3 +62,21 @@ def test_struct_layout_matches_header():
     assert [f[0] for f in B.GofRasterArgs._fields_] == fields
     assert [f[0] for f in ob.GofRasterArgs._fields_] == fields
     assert ctypes.sizeof(B.GofRasterArgs) == ctypes.sizeof(ob.GofRasterArgs) == 11 * 4 + 4 + 13 * 8
+
+
+def test_train_epilogue_struct_and_host_queries():
+    """GofAdamTensor mirror matches include/gof_train_hip.h; host-only queries and argument checks need no GPU."""
+    from train_epilogue import _backend as TB
+    src = open(os.path.join(ROOT, "include", "gof_train_hip.h")).read()
+    body = src[src.index("typedef struct GofAdamTensor {"):src.index("} GofAdamTensor;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [d.strip().replace("*", " ").split()[-1] for d in body.split("{", 1)[1].split(";") if d.strip()]
+    assert [f[0] for f in TB.GofAdamTensor._fields_] == fields
+    assert ctypes.sizeof(TB.GofAdamTensor) == 4 * 8 + 8 + 2 * 4
+    L = TB.lib
+    assert L.gof_ssim_scratch_bytes(3, 1600, 1063) >= 3 * 100 * 67 * 4
+    assert L.gof_adam_step(0, None, 0.9, 0.999, 1e-15, None) == 0
+    assert L.gof_adam_step(17, None, 0.9, 0.999, 1e-15, None) < 0 and b"n_tensors" in L.gof_last_error()
+    assert L.gof_ssim_forward(0, 8, 8, None, None, None, None, None, None, 0, None) < 0
+    assert L.gof_depth_to_normal(8, 8, None, None, 1.0, 1.0, None, None, None) < 0
+    assert len(TB.window_taps()) == 11 and abs(sum(TB.window_taps()) - 1.0) < 1e-6

@@ -1,0 +1,270 @@
+"""GPU parity of the training-epilogue kernels (include/gof_train_hip.h) through their Python mirrors:
+product (HIP) vs the CPU oracle (oracle/train_epilogue_oracle.py) and vs the golden vectors produced by the
+reference's own Python; FusedAdam additionally vs torch.optim.Adam running on the same GPU (the reference's
+actual optimizer).  Tolerances are written at each comparison: these are fp32 stencils / elementwise updates
+whose summation order differs from torch's conv2d / matmul, so the bar is a few fp32 ulps of the largest term."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import train_epilogue_oracle as O   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(ROOT, "tests", "golden", "ref_train_epilogue_golden.npz"))
+DEV = "cuda:0"
+
+
+def _close(a, b, rel_of_max, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= rel_of_max, "%s: max error %.3e of the largest value (tolerance %.1e)" % (what, err, rel_of_max)
+
+
+def _ssim_product(x, y, size_average=True, w=None):
+    import train_epilogue as T
+    xd = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    yd = torch.from_numpy(y).to(DEV)
+    s = T.ssim(xd, yd, size_average=size_average)
+    f = s if w is None else (s * torch.from_numpy(w).to(DEV)).sum()
+    (g,) = torch.autograd.grad(f, xd)
+    return s.detach().cpu().numpy(), g.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_ssim_matches_reference_golden(tag):
+    s, g = _ssim_product(G[f"ssim_{tag}_x"], G[f"ssim_{tag}_y"])
+    assert float(s) == pytest.approx(float(G[f"ssim_{tag}_value"]), rel=5e-6)      # mean of O(1) terms, fp32 sum order
+    _close(g, G[f"ssim_{tag}_grad"], 2e-5, "d ssim / d img1")
+
+
+def test_ssim_batched_per_image_means_match_reference_golden():
+    s, g = _ssim_product(G["ssim_batch_x"], G["ssim_batch_y"], size_average=False, w=G["ssim_batch_w"])
+    np.testing.assert_allclose(s, G["ssim_batch_value"], rtol=5e-6)
+    _close(g, G["ssim_batch_grad"], 2e-5, "d ssim / d img1 (batched)")
+
+
+@pytest.mark.parametrize("shape", [(3, 101, 77), (3, 5, 300), (1, 1, 1), (2, 3, 40, 33), (3, 1063, 1600)])
+def test_ssim_matches_oracle(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(shape, generator=g)
+    y = (x + 0.1 * torch.randn(shape, generator=g)).clamp(0, 1)
+    s, gx = _ssim_product(x.numpy(), y.numpy())
+    xo = x.clone().requires_grad_(True)
+    so = O.ssim(xo, y)
+    (go,) = torch.autograd.grad(so, xo)
+    assert float(s) == pytest.approx(so.item(), rel=5e-6)
+    _close(gx, go.numpy(), 5e-5, "d ssim / d img1 %s" % (shape,))
+
+
+def test_ssim_of_identical_images_is_one_with_zero_gradient_at_full_size():
+    x = torch.rand((3, 1063, 1600), generator=torch.Generator().manual_seed(3)).numpy()
+    s, g = _ssim_product(x, x.copy())
+    assert abs(float(s) - 1.0) < 1e-6
+    assert np.abs(g).max() < 1e-9          # per-pixel derivative / (3*H*W): cancels to rounding
+
+
+def _view(wvt, W, H, fovx, fovy):
+    return types.SimpleNamespace(world_view_transform=torch.from_numpy(np.ascontiguousarray(wvt)).to(DEV), image_width=W, image_height=H,
+                                 FoVx=float(fovx), FoVy=float(fovy))
+
+
+def _dn_product(view, depth, wn, wp):
+    import train_epilogue as T
+    d = torch.from_numpy(depth).to(DEV).requires_grad_(True)
+    normals, points = T.depth_to_normal(view, d)
+    f = (normals * torch.from_numpy(wn).to(DEV)).sum() + (points * torch.from_numpy(wp).to(DEV)).sum()
+    (gd,) = torch.autograd.grad(f, d)
+    flat = T.depths_to_points(view, d.detach())
+    return normals.detach().cpu().numpy(), points.detach().cpu().numpy(), gd.cpu().numpy(), flat.cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_depth_to_normal_matches_reference_golden(tag):
+    W, H, fovx, fovy = G[f"dn_{tag}_cam"]
+    view = _view(G[f"dn_{tag}_wvt"], int(W), int(H), fovx, fovy)
+    n, p, gd, flat = _dn_product(view, G[f"dn_{tag}_depth"], G[f"dn_{tag}_wn"], G[f"dn_{tag}_wp"])
+    assert n.shape == G[f"dn_{tag}_normals"].shape and p.shape == G[f"dn_{tag}_points"].shape
+    _close(p, G[f"dn_{tag}_points"], 2e-6, "points")                      # |P| ~ 5, a handful of fp32 ops
+    np.testing.assert_allclose(n, G[f"dn_{tag}_normals"], atol=2e-5)     # unit vectors from differences of points
+    _close(gd, G[f"dn_{tag}_grad"], 1e-4, "d f / d depth")
+    np.testing.assert_array_equal(flat.reshape(p.shape), p)
+
+
+@pytest.mark.parametrize("W,H", [(130, 67), (2, 9), (1, 1), (1600, 1063)])
+def test_depth_to_normal_matches_oracle(W, H):
+    g = torch.Generator().manual_seed(W * 7 + H)
+    q = torch.randn(4, generator=g); q = q / q.norm()
+    w_, x_, y_, z_ = q.tolist()
+    R = torch.tensor([[1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - w_ * z_), 2 * (x_ * z_ + w_ * y_)],
+                      [2 * (x_ * y_ + w_ * z_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - w_ * x_)],
+                      [2 * (x_ * z_ - w_ * y_), 2 * (y_ * z_ + w_ * x_), 1 - 2 * (x_ * x_ + y_ * y_)]])
+    M = torch.eye(4); M[:3, :3] = R; M[:3, 3] = torch.randn(3, generator=g)
+    wvt = M.T.contiguous()
+    # a smooth surface plus roughness (a pure-noise depth map makes the normals ill-conditioned everywhere)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    depth = (3.0 + 0.5 * torch.sin(xx / 9.0) + 0.3 * torch.cos(yy / 7.0) + 0.02 * torch.rand((H, W), generator=g))[None]
+    wn = torch.randn((H, W, 3), generator=g); wp = torch.randn((H, W, 3), generator=g)
+    n, p, gd, _ = _dn_product(_view(wvt.numpy(), W, H, 0.9, 0.65), depth.numpy(), wn.numpy(), wp.numpy())
+    do = depth.clone().requires_grad_(True)
+    no, po = O.depth_to_normal(wvt, W, H, 0.9, 0.65, do)
+    (go,) = torch.autograd.grad((no * wn).sum() + (po * wp).sum(), do)
+    _close(p, po.detach().numpy(), 2e-6, "points")
+    np.testing.assert_allclose(n, no.detach().numpy(), atol=1e-4)         # cancellation in P[+1]-P[-1]: 1e-7*|P|/|dx|
+    _close(gd, go.numpy(), 5e-4, "d f / d depth")
+    if W >= 3 and H >= 3:
+        assert np.all(n[0] == 0) and np.all(n[-1] == 0) and np.all(n[:, 0] == 0) and np.all(n[:, -1] == 0)
+        assert np.allclose(np.linalg.norm(n[1:-1, 1:-1], axis=-1), 1.0, atol=1e-5)
+    else:
+        assert np.all(n == 0)
+
+
+def test_train_loss_composition_matches_oracle():
+    """train.py:150-186 composed from the product mirrors (GPU) and from the oracle (CPU): loss and d loss / d rendering."""
+    import train_epilogue as T
+    W, H = 203, 131
+    g = torch.Generator().manual_seed(9)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    rendering = torch.rand((9, H, W), generator=g)
+    rendering[3:6] = torch.randn((3, H, W), generator=g)
+    rendering[6] = 2.5 + 0.4 * torch.sin(xx / 11.0) + 0.3 * torch.cos(yy / 5.0)
+    gt = torch.rand((3, H, W), generator=g)
+    wvt = torch.eye(4); wvt[3, :3] = torch.tensor([0.1, -0.2, 0.3])
+    fovx, fovy = 0.8, 0.55
+    lambda_dssim, lambda_dn, lambda_dist = 0.2, 0.05, 100.0
+
+    def compose(r, gt_, ssim_fn, l1_fn, d2n, c2w_src):
+        image = r[:3]
+        rgb_loss = (1.0 - lambda_dssim) * l1_fn(image, gt_) + lambda_dssim * (1.0 - ssim_fn(image, gt_))     # train.py:156-161
+        distortion_loss = r[8].mean()                                                                          # :164-167
+        depth_normal = d2n(r[6][None]).permute(2, 0, 1)                                                        # :170-172
+        render_normal = torch.nn.functional.normalize(r[3:6], p=2, dim=0)                                      # :174-175
+        c2w = (c2w_src.T).inverse()                                                                            # :177
+        world = (c2w[:3, :3] @ render_normal.reshape(3, -1)).reshape(3, *render_normal.shape[1:])              # :178-179
+        depth_normal_loss = (1 - (world * depth_normal).sum(dim=0)).mean()                                     # :181-182
+        return rgb_loss + depth_normal_loss * lambda_dn + distortion_loss * lambda_dist                        # :188
+
+    rd = rendering.to(DEV).requires_grad_(True)
+    view = types.SimpleNamespace(world_view_transform=wvt.to(DEV), image_width=W, image_height=H, FoVx=fovx, FoVy=fovy)
+    loss_p = compose(rd, gt.to(DEV), T.ssim, T.l1_loss, lambda d: T.depth_to_normal(view, d)[0], view.world_view_transform)
+    (gp,) = torch.autograd.grad(loss_p, rd)
+    ro = rendering.clone().requires_grad_(True)
+    loss_o = compose(ro, gt, O.ssim, O.l1_loss, lambda d: O.depth_to_normal(wvt, W, H, fovx, fovy, d)[0], wvt)
+    (go,) = torch.autograd.grad(loss_o, ro)
+    assert loss_p.item() == pytest.approx(loss_o.item(), rel=1e-5)
+    for c in range(9):
+        if go[c].abs().max() == 0:
+            assert gp[c].abs().max().item() == 0
+        else:
+            _close(gp[c].cpu().numpy(), go[c].numpy(), 1e-4, "d loss / d rendering[%d]" % c)
+
+
+# ---- FusedAdam ---------------------------------------------------------------------------------------------
+GROUPS = [("xyz", (3,), 1.6e-4), ("f_dc", (1, 3), 2.5e-3), ("f_rest", (15, 3), 1.25e-4), ("opacity", (1,), 5e-2),
+          ("scaling", (3,), 5e-3), ("rotation", (4,), 1e-3)]          # scene/gaussian_model.py:349-358, arguments/__init__.py
+
+
+def _make(P, seed, cls, **kw):
+    g = torch.Generator().manual_seed(seed)
+    params = [torch.nn.Parameter(torch.randn((P,) + shp, generator=g).to(DEV)) for _, shp, _ in GROUPS]
+    opt = cls([{"params": [p], "lr": lr, "name": name} for p, (name, _, lr) in zip(params, GROUPS)], lr=0.0, eps=1e-15, **kw)
+    return params, opt
+
+
+def _set_grads(params, step, seed):
+    g = torch.Generator().manual_seed(1000 * seed + step)
+    for p in params:
+        gr = torch.randn(p.shape, generator=g) * (10.0 ** ((step % 4) - 3))
+        gr[::7] = 0.0                                     # invisible Gaussians receive exactly zero gradient
+        p.grad = gr.to(DEV)
+
+
+def test_fused_adam_matches_torch_adam_on_the_same_gpu_and_the_oracle():
+    import train_epilogue as T
+    P = 10007
+    pa, oa = _make(P, 1, T.FusedAdam)
+    pb, ob = _make(P, 1, torch.optim.Adam)                # torch's own (foreach) implementation on the GPU
+    p0 = [p.detach().cpu().numpy().copy() for p in pa]
+    mo = [np.zeros_like(a) for a in p0]; vo = [np.zeros_like(a) for a in p0]
+    for step in range(6):
+        _set_grads(pa, step, 2); _set_grads(pb, step, 2)
+        if step == 3:                                     # update_learning_rate (gaussian_model.py:366-372)
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 3.3e-5
+        oa.step(); ob.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            lr = oa.param_groups[i]["lr"]
+            p0[i], mo[i], vo[i] = O.adam_step(p0[i], a.grad.cpu().numpy(), mo[i], vo[i], step + 1, lr)
+            # one Adam step moves a parameter by <= lr; the three implementations agree to 1e-5 of that step
+            assert (a.detach() - b.detach()).abs().max().item() <= 1e-5 * lr + 1e-7 * a.detach().abs().max().item()
+            assert np.abs(a.detach().cpu().numpy() - p0[i]).max() <= 1e-5 * lr + 1e-7 * np.abs(p0[i]).max()
+    for a, b in zip(pa, pb):
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 6.0
+        _close(sa["exp_avg"].cpu().numpy(), sb["exp_avg"].cpu().numpy(), 1e-6, "exp_avg")
+        _close(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy(), 1e-6, "exp_avg_sq")
+
+
+def test_fused_adam_state_survives_the_references_densification_surgery_and_checkpoints():
+    """cat_tensors_to_optimizer / _prune_optimizer edit optimizer.state in place (gaussian_model.py:549-607);
+    state_dict()/load_state_dict() are what train.py checkpoints (gaussian_model.py:130,150)."""
+    import train_epilogue as T
+    pa, oa = _make(501, 4, T.FusedAdam)
+    pb, ob = _make(501, 4, torch.optim.Adam)
+    for step in range(2):
+        _set_grads(pa, step, 5); _set_grads(pb, step, 5)
+        oa.step(); ob.step()
+
+    def cat_and_prune(opt):
+        new = []
+        for group in opt.param_groups:
+            p = group["params"][0]
+            ext = torch.full((10,) + tuple(p.shape[1:]), 0.25, device=DEV)
+            st = opt.state.get(p, None)
+            st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0)
+            st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+            del opt.state[p]
+            q = torch.nn.Parameter(torch.cat((p.detach(), ext), dim=0).requires_grad_(True))
+            mask = torch.ones(q.shape[0], dtype=torch.bool, device=DEV); mask[::5] = False
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+            q = torch.nn.Parameter(q.detach()[mask].requires_grad_(True))
+            group["params"][0] = q
+            opt.state[q] = st
+            new.append(q)
+        return new
+    pa, pb = cat_and_prune(oa), cat_and_prune(ob)
+    sd = ob.state_dict()                                   # a torch.optim.Adam checkpoint ...
+    pc, oc = _make(pa[0].shape[0], 4, T.FusedAdam)
+    for c, b in zip(pc, pb):
+        c.data.copy_(b.data)
+    oc.load_state_dict(sd)                                 # ... resumes under FusedAdam
+    for step in range(2, 4):
+        for ps in (pa, pb, pc):
+            _set_grads(ps, step, 5)
+        oa.step(); ob.step(); oc.step()
+    for a, b, c, (_, _, lr) in zip(pa, pb, pc, GROUPS):
+        tol = 1e-5 * lr + 1e-7 * b.detach().abs().max().item()
+        assert (a.detach() - b.detach()).abs().max().item() <= tol
+        assert (c.detach() - b.detach()).abs().max().item() <= tol
+
+
+def test_fused_adam_unaligned_and_tail_elements():
+    import train_epilogue as T
+    base = torch.randn(3 * 4096 + 5, generator=torch.Generator().manual_seed(8)).to(DEV)
+    for off, n in ((1, 4096 * 2 + 3), (0, 1), (0, 4096), (3, 17)):
+        p = torch.nn.Parameter(base[off:off + n])                 # a view: data_ptr is only 4-byte aligned when off % 4 != 0
+        q = torch.nn.Parameter(p.detach().clone())
+        store = torch.zeros(n + 8, device=DEV)
+        opt, ref = T.FusedAdam([p], lr=1e-2, eps=1e-15), torch.optim.Adam([q], lr=1e-2, eps=1e-15)
+        for step in range(2):
+            gr = torch.randn(n, generator=torch.Generator().manual_seed(step)).to(DEV)
+            store[1:n + 1] = gr
+            p.grad = store[1:n + 1]                           # 4-byte aligned only: the scalar path
+            q.grad = gr.clone()
+            opt.step(); ref.step()
+        assert (p.detach() - q.detach()).abs().max().item() <= 1e-7
