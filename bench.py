@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1063)
     ap.add_argument("--kernel-size", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-loop", action="store_true", help="skip the full training-iteration leg (losses + Adam)")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=100_000)
     return ap.parse_args()
 
@@ -120,6 +121,8 @@ def main():
                 "fwd_ms": round(stage["fwd_ms"], 4), "bwd_ms": round(stage["bwd_ms"], 4), "parallelism": "dp%d (views)" % world},
             "roofline": stage["roofline"],
         }
+        if world == 1 and not args.no_full_loop:
+            out["full_loop"] = full_loop(sd, dev, W, H)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, W, H, focal)
         print(json.dumps(out))
@@ -187,6 +190,70 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
             "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd,
                          "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)}}
     return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": R, "roofline": roof}
+
+
+def full_loop(sd, dev, W, H, steps=10, warmup=3):
+    """SURVEY.md 8(d)(i) "full-loop variant": one complete training iteration of train.py:125-190, 263-265 on the same
+    scene -- parameter activations (torch, as scene/gaussian_model.py:74-112), rasterizer forward, the reference's loss
+    (L1 + D-SSIM + depth-normal consistency + distortion), backward, Adam over the 59 floats per Gaussian -- with the
+    HIP training epilogue (train_epilogue/: ssim, depth_to_normal, FusedAdam).  Reported beside the headline, not as it."""
+    import math
+    import types
+    import train_epilogue as T
+    from gpu_common import settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    raw = {
+        "xyz": sd["means3D"].clone(), "f_dc": sd["shs"][:, :1].clone(), "f_rest": sd["shs"][:, 1:].clone(),
+        "opacity": torch.logit(sd["opacities"].clamp(1e-4, 1 - 1e-4)), "scaling": torch.log(sd["scales"]), "rotation": sd["rotations"].clone(),
+    }
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 5e-2, "scaling": 5e-3, "rotation": 1e-3}
+    params = {k: torch.nn.Parameter(v.contiguous()) for k, v in raw.items()}
+    opt = T.FusedAdam([{"params": [p], "lr": lrs[k], "name": k} for k, p in params.items()], lr=0.0, eps=1e-15)   # gaussian_model.py:349-360
+    rast = GaussianRasterizer(settings_from(sd))
+    means2D = torch.zeros_like(params["xyz"], requires_grad=True)
+    gt = torch.rand((3, H, W), generator=torch.Generator().manual_seed(7)).to(dev)
+    view = types.SimpleNamespace(world_view_transform=sd["viewmatrix"], image_width=W, image_height=H,
+                                 FoVx=2 * math.atan(sd["tanfovx"]), FoVy=2 * math.atan(sd["tanfovy"]))
+    lambda_dssim, lambda_dn, lambda_dist = 0.2, 0.05, 100.0        # arguments/__init__.py defaults
+
+    def iteration():
+        shs = torch.cat((params["f_dc"], params["f_rest"]), dim=1)                           # get_features
+        rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=shs, opacities=torch.sigmoid(params["opacity"]),
+                                scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
+        image = rendering[:3]
+        rgb_loss = (1.0 - lambda_dssim) * T.l1_loss(image, gt) + lambda_dssim * (1.0 - T.ssim(image, gt))   # train.py:156-161
+        distortion_loss = rendering[8].mean()                                                # :164-167
+        depth_normal = T.depth_to_normal(view, rendering[6][None])[0].permute(2, 0, 1)       # :170-172
+        render_normal = torch.nn.functional.normalize(rendering[3:6], p=2, dim=0)            # :174-175
+        c2w = (view.world_view_transform.T).inverse()                                        # :177
+        world = (c2w[:3, :3] @ render_normal.reshape(3, -1)).reshape(3, H, W)                # :178-179
+        depth_normal_loss = (1 - (world * depth_normal).sum(dim=0)).mean()                   # :181-182
+        loss = rgb_loss + depth_normal_loss * lambda_dn + distortion_loss * lambda_dist      # :188
+        loss.backward()                                                                      # :189
+        opt.step()                                                                           # :264
+        opt.zero_grad(set_to_none=True)                                                      # :265
+        return loss
+
+    for _ in range(warmup):
+        iteration()
+    torch.cuda.synchronize()
+    B.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    kt = B.profile_report()
+    B.profile_enable(False)
+    ep = {k: round(v["total_ms"] / max(1, v["calls"]), 5) for k, v in kt.items()
+          if k in ("ssim_forward", "ssim_backward", "depth_to_normal", "depth_to_normal_backward", "adam_step")}
+    n_floats = sum(p.numel() for p in params.values())
+    out = {"ms_per_iter": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps,
+           "includes": "activations (torch) + rasterizer fwd/bwd + L1/D-SSIM/depth-normal/distortion loss + Adam (59 floats/Gaussian)",
+           "epilogue_kernels_ms": ep}
+    if ep.get("adam_step"):
+        out["adam_GBps"] = round(28.0 * n_floats / (ep["adam_step"] * 1e-3) / 1e9, 1)     # p,g,m,v read + p,m,v written
+    return out
 
 
 def cpu_baseline(args, W, H, focal):

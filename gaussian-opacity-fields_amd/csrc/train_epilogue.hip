@@ -283,14 +283,13 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ void __launch_bounds__(256)
-adam_kernel(AdamArgs a, float beta1, float beta2, float eps)
+adam_kernel(AdamArgs a, float w1, float beta2, float w2, float eps)
 {
     int ti = 0;
     while (ti < a.n - 1 && blockIdx.x >= a.block_end[ti]) ti++;
     const GofAdamTensor t = a.t[ti];
     const uint32_t b0 = ti ? a.block_end[ti - 1] : 0u;
     const uint64_t start = (uint64_t)(blockIdx.x - b0) * ADAM_BLOCK_ELEMS;
-    const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
     const bool vec = ((((uintptr_t)t.param) | ((uintptr_t)t.grad) | ((uintptr_t)t.exp_avg) | ((uintptr_t)t.exp_avg_sq)) & 15) == 0;
     if (vec && start + ADAM_BLOCK_ELEMS <= t.n) {
 #pragma unroll
@@ -413,7 +412,7 @@ int gof_depth_to_normal_backward(int32_t W, int32_t H, const float* depth, const
     return GOF_OK;
 }
 
-int gof_adam_step(int32_t n_tensors, const GofAdamTensor* tensors_host, float beta1, float beta2, float eps, void* stream_)
+int gof_adam_step(int32_t n_tensors, const GofAdamTensor* tensors_host, double beta1, double beta2, double eps, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_tensors < 0 || n_tensors > GOF_ADAM_MAX_TENSORS) { set_error("n_tensors %d outside [0, %d]", n_tensors, GOF_ADAM_MAX_TENSORS); return GOF_E_INVALID; }
@@ -435,7 +434,9 @@ int gof_adam_step(int32_t n_tensors, const GofAdamTensor* tensors_host, float be
     a.n = k;
     if (!k) return GOF_OK;
     { GOF_PROFILE("adam_step", stream);
-      hipLaunchKernelGGL(adam_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, beta1, beta2, eps);
+      // torch forms 1 - beta in Python doubles and rounds the scalar to fp32 once (1 - 0.999f would be off by 1.3e-5 relative)
+      hipLaunchKernelGGL(adam_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, (float)(1.0 - beta1), (float)beta2,
+                         (float)(1.0 - beta2), (float)eps);
       GOF_LAUNCH_CHECK(stream, 0); }
     return GOF_OK;
 }

@@ -29,7 +29,7 @@ def _declare():
     lib.gof_ssim_backward.argtypes = [i32, i32, i32, vp, vp, W11, vp, vp, vp, vp]
     lib.gof_depth_to_normal.argtypes = [i32, i32, vp, vp, f32, f32, vp, vp, vp]
     lib.gof_depth_to_normal_backward.argtypes = [i32, i32, vp, vp, f32, f32, vp, vp, vp, vp]
-    lib.gof_adam_step.argtypes = [i32, C.POINTER(GofAdamTensor), f32, f32, f32, vp]
+    lib.gof_adam_step.argtypes = [i32, C.POINTER(GofAdamTensor), C.c_double, C.c_double, C.c_double, vp]
     for n in ("gof_ssim_forward", "gof_ssim_backward", "gof_depth_to_normal", "gof_depth_to_normal_backward", "gof_adam_step"):
         getattr(lib, n).restype = C.c_int
 

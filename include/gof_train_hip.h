@@ -71,8 +71,9 @@ typedef struct GofAdamTensor {
 } GofAdamTensor;
 #define GOF_ADAM_MAX_TENSORS 16
 /* One launch updates up to GOF_ADAM_MAX_TENSORS tensors (the six parameter groups of the reference). */
+/* beta1, beta2, eps are doubles: torch forms (1 - beta) in double and rounds each scalar to fp32 once. */
 int gof_adam_step(int32_t n_tensors, const GofAdamTensor* tensors_host,
-                  float beta1, float beta2, float eps, void* stream);
+                  double beta1, double beta2, double eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,22 +44,24 @@ def ssim(img1, img2, window_size=11, size_average=True):
 
 
 # ---- utils/depth_utils.py -----------------------------------------------------------------------------
-def depths_to_points(world_view_transform, W, H, FoVx, FoVy, depthmap):
-    """depth_utils.py:6-21 with the camera fields passed explicitly (the reference hard-codes .cuda())."""
+def depths_to_points(world_view_transform, W, H, FoVx, FoVy, depthmap, dtype=torch.float32):
+    """depth_utils.py:6-21 with the camera fields passed explicitly (the reference hard-codes .cuda()).
+    dtype=torch.float64 (with float64 inputs) evaluates the same expressions in double: the accuracy yardstick of the
+    GPU tests, not part of the restatement."""
     c2w = (world_view_transform.T).inverse()                               # :7
     fx = W / (2 * math.tan(FoVx / 2.))                                     # :9-10
     fy = H / (2 * math.tan(FoVy / 2.))
-    intrins = torch.tensor([[fx, 0., W / 2.], [0., fy, H / 2.], [0., 0., 1.0]]).float()   # :11-15
-    grid_x, grid_y = torch.meshgrid(torch.arange(W).float() + 0.5, torch.arange(H).float() + 0.5, indexing='xy')  # :16
+    intrins = torch.tensor([[fx, 0., W / 2.], [0., fy, H / 2.], [0., 0., 1.0]], dtype=torch.float64).to(dtype)   # :11-15 (.float())
+    grid_x, grid_y = torch.meshgrid(torch.arange(W).to(dtype) + 0.5, torch.arange(H).to(dtype) + 0.5, indexing='xy')  # :16
     points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)   # :17
     rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T                  # :18
     rays_o = c2w[:3, 3]                                                    # :19
     return depthmap.reshape(-1, 1) * rays_d + rays_o                       # :20
 
 
-def depth_to_normal(world_view_transform, W, H, FoVx, FoVy, depth):
+def depth_to_normal(world_view_transform, W, H, FoVx, FoVy, depth, dtype=torch.float32):
     """depth_utils.py:24-35."""
-    points = depths_to_points(world_view_transform, W, H, FoVx, FoVy, depth).reshape(*depth.shape[1:], 3)   # :29
+    points = depths_to_points(world_view_transform, W, H, FoVx, FoVy, depth, dtype).reshape(*depth.shape[1:], 3)   # :29
     output = torch.zeros_like(points)                                      # :30
     dx = torch.cat([points[2:, 1:-1] - points[:-2, 1:-1]], dim=0)          # :31
     dy = torch.cat([points[1:-1, 2:] - points[1:-1, :-2]], dim=1)          # :32
