@@ -1,0 +1,61 @@
+"""Developer script: turn the rocprofv3 outputs merged under gpurun_out/ into the committed summaries in profiles/.
+usage: python tests/dev_make_profiles.py <tag e.g. v4> <prof dir> <pmc FETCH dir> <pmc WRITE dir> [bench json]"""
+import csv, json, os, re, sys, shutil
+from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, prof, pf, pw = sys.argv[1:5]
+bench = sys.argv[5] if len(sys.argv) > 5 else None
+
+
+def short(name):
+    m = re.match(r"(?:void )?(?:gof::)?([A-Za-z0-9_]+)", name)
+    n = m.group(1) if m else name
+    return {"__amd_rocclr_fillBufferAligned": "hipMemsetAsync (fillBufferAligned)", "__amd_rocclr_copyBuffer": "hipMemcpyAsync (copyBuffer)"}.get(n, n)
+
+
+stats = list(csv.DictReader(open([os.path.join(prof, f) for f in os.listdir(prof) if f.endswith("kernel_stats.csv")][0])))
+shutil.copy([os.path.join(prof, f) for f in os.listdir(prof) if f.endswith("kernel_stats.csv")][0],
+            os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.csv" % tag))
+agg = defaultdict(lambda: [0, 0.0])
+for r in stats:
+    k = short(r["Name"])
+    if k.startswith("at") or "elementwise" in r["Name"]:
+        k = "torch elementwise (zeros/fill)"
+    agg[k][0] += int(r["Calls"]); agg[k][1] += float(r["TotalDurationNs"])
+tot = sum(v[1] for v in agg.values())
+
+
+def pmc(d, counter):
+    f = [os.path.join(d, x) for x in os.listdir(d) if x.endswith("counter_collection.csv")][0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch, write = pmc(pf, "FETCH_SIZE"), pmc(pw, "WRITE_SIZE")
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    if k.startswith("hipMem") or k.startswith("torch") or k.startswith("at"):
+        continue
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    traffic[k] = {"fetch_KiB_raw": f, "write_KiB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024}
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_s1m.json"), "w"), indent=1)
+with open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % tag), "w") as o:
+    o.write("# rocprofv3 summaries, round 1, kernels of commit-state '%s'\n\n" % tag)
+    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline`\n"
+            "(S1M: 1M Gaussians, 1600x1063, R = 8 837 593; 12 fwd+bwd iterations + 1 stage-statistics forward)\n\n")
+    o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        o.write("| %s | %d | %.3f | %.1f | %.2f |\n" % (k, c, t / 1e6, t / c / 1e3, 100 * t / tot))
+    o.write("\n## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, tests/dev_pmc.py)\n\n"
+            "FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; per the MI355X guide, on gfx950 FETCH_SIZE counts wide coalesced\n"
+            "reads at 1/2 (64 B per 128-B request), so the read column is given raw and doubled; WRITE_SIZE is uncalibrated.\n"
+            "The 64 MB record table and the tile lists stay resident in the 256 MiB Infinity Cache, whose hits the counter includes.\n\n")
+    o.write("| kernel | FETCH_SIZE KiB (raw) | read MB (x2 corrected) | WRITE_SIZE KiB | write MB |\n|---|---|---|---|---|\n")
+    for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
+        o.write("| %s | %.0f | %.1f | %.0f | %.1f |\n" % (k, v["fetch_KiB_raw"], 2 * v["fetch_KiB_raw"] * 1024 / 1e6, v["write_KiB"], v["write_KiB"] * 1024 / 1e6))
+if bench:
+    shutil.copy(bench, os.path.join(ROOT, "profiles", "r01_bench_s1m_%s.json" % tag))
+print(open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % tag)).read())
