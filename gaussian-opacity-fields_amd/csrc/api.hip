@@ -20,7 +20,7 @@ __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const 
                                const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
-                               int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out,
+                               int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out, float4* fconic_out,
                                uint32_t* tiles_touched, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
 __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
@@ -53,11 +53,14 @@ __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, 
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity,
                                float* dL_dcolors, float* dL_dv2g, uint32_t gx, uint32_t ntiles);
-__global__ void integrate_kernel(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
-                                 const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H, float focal_x, float focal_y,
-                                 const float2* points2D, const float* point_depths, float* point_T, const float* bg_color, float* final_T,
-                                 uint32_t* n_contrib, float* out_color, float* out_alpha_integrated,
-                                 float* out_color_integrated, uint32_t gx, uint32_t ntiles);
+__global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
+                                 const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
+                                 uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
+__global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
+                                 const uint32_t* point_list, const SplatRec* rec, const float4* fconic, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
+                                 const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
+                                 float* out_alpha_integrated, float* out_color_integrated, uint32_t gx, uint32_t ntiles);
+__global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
 static thread_local std::string g_error;
@@ -112,6 +115,7 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     carve(p, g.rec, n);
     carve(p, g.conic, n);
     carve(p, g.bbox, n);
+    carve(p, g.fconic, 2 * n);
     carve(p, g.depths, n);
     carve(p, g.tiles_touched, n);
     carve(p, g.clamped, n);
@@ -139,7 +143,7 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
     if (out) *out = im;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
-size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out)
+size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool with_masks)
 {
     BinWs b;
     char* p = static_cast<char*>(base);
@@ -150,7 +154,9 @@ size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out)
     carve(p, b.vals_alt, n);
     carve(p, b.tiles_alt, n);
     carve(p, b.sort_tmp, rs_tmp_words(n));
-    carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
+    b.cmask = nullptr; b.pt_xy = nullptr; b.pt_depth = nullptr; b.pt_T = nullptr; b.pt_acc = nullptr;
+    if (with_masks) carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
+    else { carve(p, b.pt_xy, n); carve(p, b.pt_depth, n); carve(p, b.pt_T, n); carve(p, b.pt_acc, n); }
     if (out) *out = b;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -248,7 +254,8 @@ int gof_abi_version(void) { return 1; }
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
-size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H) { return bin_layout(R, W, H, nullptr, nullptr) + ALIGN; }
+size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H) { return bin_layout(R, W, H, nullptr, nullptr, true) + ALIGN; }
+size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_layout(NI, W, H, nullptr, nullptr, false) + ALIGN; }
 size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
 
 int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
@@ -273,7 +280,7 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
-                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox,
+                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox, g.fconic,
                        g.tiles_touched, g.clamped, g.dkey_a, g.dval_a, g.flags); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
@@ -320,7 +327,7 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
     const Dims d = dims_of(a);
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
@@ -352,7 +359,7 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
     const Dims d = dims_of(a);
     const size_t P = (size_t)a->P;
     // torch::zeros of the binding (rasterize_points.cu:161-170): required, K8 accumulates and K9 skips culled Gaussians
@@ -410,29 +417,56 @@ int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float
     return GOF_OK;
 }
 
-int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, int32_t PN, uint32_t NI,
-                      void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
-                      void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
-                      float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
+// ---- integrate, Gaussian side of one view: binning + pixel pass.  Leaves in the three workspaces everything
+// gof_integrate_points needs (records, sorted list, ranges, contributor masks) and in out_color the base image.
+int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
+                       void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                       float* out_color, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (a->P == 0) return GOF_OK;
+    if (!radii || !out_color) { set_error("an output / radii pointer is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
+        set_error("workspace too small"); return GOF_E_WORKSPACE; }
+    GeomWs g; ImageWs im; BinWs b;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    image_layout(a->W, a->H, aligned_base(image_ws), &im);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
+    const Dims d = dims_of(a);
+    rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
+    if (rc) return rc;
+    GOF_PROFILE("integrate_pixels", stream);
+    hipLaunchKernelGGL(integrate_pixels, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                       im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
+                       out_color, b.cmask, d.gx, d.ntiles);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    return GOF_OK;
+}
+
+// ---- integrate, point side: point binning (createWithKeys + sort + ranges, rasterizer_impl.cu:720-752) + point pass ----
+int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI,
+                         const void* geom_ws, size_t geom_bytes, const void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                         void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                         const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
     if (rc) return rc;
     if (a->P == 0 || PN <= 0) return GOF_OK;     // rasterize_points.cu:301
-    if (!radii || !out_color || !out_alpha_integrated || !out_color_integrated) { set_error("an output / radii pointer is NULL"); return GOF_E_INVALID; }
+    if (!base_color || !out_color || !out_alpha_integrated || !out_color_integrated) { set_error("an output pointer is NULL"); return GOF_E_INVALID; }
     if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H) ||
-        point_bytes < gof_point_bytes(PN) || point_binning_bytes < gof_binning_bytes(NI, a->W, a->H)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
+        point_bytes < gof_point_bytes(PN) || point_binning_bytes < gof_point_binning_bytes(NI, a->W, a->H)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b, pb; PointWs w;
-    geom_layout(a->P, aligned_base(geom_ws), &g);
+    geom_layout(a->P, aligned_base(const_cast<void*>(geom_ws)), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    bin_layout(R, a->W, a->H, aligned_base(const_cast<void*>(binning_ws)), &b, true);
     point_layout(PN, aligned_base(point_ws), &w);
-    bin_layout(NI, a->W, a->H, aligned_base(point_binning_ws), &pb);
+    bin_layout(NI, a->W, a->H, aligned_base(point_binning_ws), &pb, false);
     const Dims d = dims_of(a);
-    rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
-    if (rc) return rc;
-    // points: createWithKeys + sort + ranges (rasterizer_impl.cu:720-752) -- same two-level sort as the Gaussians:
-    // visible points by depth (4 passes), then by tile (2 passes); stable, so ties keep ascending point id
+    // same two-level sort as the Gaussians: visible points by depth (4 passes), then by tile (2 passes); stable, so ties keep ascending point id
+    { GOF_PROFILE("bin_points", stream);
     if (NI > 0) {
         const int tile_bits = (int)higher_msb(d.ntiles);
         hipLaunchKernelGGL(point_depth_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.depths, w.point_offsets,
@@ -455,13 +489,27 @@ int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, 
     if (NI > 0) {
         hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges);
         GOF_LAUNCH_CHECK(stream, a->debug);
-    }
-    GOF_PROFILE("integrate_kernel", stream);
-    hipLaunchKernelGGL(integrate_kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, w.points2D, w.depths, w.T_state,
-                       a->background, im.final_T, im.n_contrib, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
+        hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.points2D, w.depths, pb.pt_xy, pb.pt_depth);
+        GOF_LAUNCH_CHECK(stream, a->debug);
+    } }
+    GOF_PROFILE("integrate_points", stream);
+    hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                       im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, g.fconic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
+                       base_color, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
+}
+
+int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, int32_t PN, uint32_t NI,
+                      void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                      void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                      float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
+{
+    if (a && (a->P == 0 || PN <= 0)) { int rc = validate(a); return rc; }     // rasterize_points.cu:301: nothing is launched
+    int rc = gof_integrate_view(a, R, radii, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, out_color, stream_);
+    if (rc) return rc;
+    return gof_integrate_points(a, R, PN, NI, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
+                                point_binning_ws, point_binning_bytes, out_color, out_color, out_alpha_integrated, out_color_integrated, stream_);
 }
 
 int gof_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_)
@@ -542,7 +590,7 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
     const Dims d = dims_of(a);
     if (geom_ws) geom_layout(a->P, aligned_base(geom_ws), &g);
     if (image_ws) image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    if (binning_ws) bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b);
+    if (binning_ws) bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
     const void* src = nullptr; size_t bytes = 0; int64_t count = 0;
     int unpack = -1; size_t per = 0; bool bytes_out = false;
     const std::string n(name);

@@ -82,6 +82,19 @@ point_tile_keys(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const floa
     tiles[i] = (uint32_t)(y * gx + x);
 }
 
+// per-point data in LIST order (tile-major, depth within the tile): the point pass of integrate reads it once per staged batch,
+// a gather by point id there would touch a different DRAM sector per point per batch
+__global__ void __launch_bounds__(256)
+gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const float2* __restrict__ points2D, const float* __restrict__ depths,
+                     float2* __restrict__ pt_xy, float* __restrict__ pt_depth)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NI) return;
+    const uint32_t id = sorted_ids[i];
+    pt_xy[i] = points2D[id];
+    pt_depth[i] = depths[id];
+}
+
 // replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before
 __global__ void __launch_bounds__(256)
 tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges)

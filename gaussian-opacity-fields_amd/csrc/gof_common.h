@@ -41,6 +41,7 @@ struct GeomWs {
     SplatRec* rec;          // [P]
     float4* conic;          // [P] conic.xyz (2D inverse covariance), w unused -- backward only
     float4* bbox;           // [P] conservative pixel bounding box {xlo, xhi, ylo, yhi} of the alpha >= 1/255 footprint
+    float4* fconic;         // [2P] footprint conic in ray space, unit-normalised: {m00, m01, m11, m02}, {m12, m22, q, -} (preprocess.hip)
     uint32_t* tiles_touched;// [P]
     uint8_t* clamped;       // [P] bit c set when colour channel c was clamped (forward.cu:67-69)
     uint32_t* flags;        // [4] device-side status words (prefilter violation, ...)
@@ -64,6 +65,8 @@ struct BinWs {
     uint32_t* tiles; uint32_t* tiles_alt;         // [R]  tiles = tile id of every sorted instance
     uint32_t* sort_tmp;                           // rs_tmp_words(R) words
     uint32_t* cmask;                              // [cmask_words(R, T)][256] contributor bit masks written by blend_forward
+    // query-point variant (integrate): per-point data gathered into LIST order, so the point pass streams it
+    float2* pt_xy; float* pt_depth; float* pt_T; float* pt_acc;   // [NI]
 };
 // Point workspace (replaces PointState, rasterizer_impl.h:47-55)
 struct PointWs {
@@ -82,7 +85,7 @@ struct Cam {
 
 size_t geom_layout(int32_t P, void* base, GeomWs* out);
 size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out);
-size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out);
+size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool with_masks);
 size_t point_layout(int32_t PN, void* base, PointWs* out);
 
 // ---- error handling ----------------------------------------------------------------------------

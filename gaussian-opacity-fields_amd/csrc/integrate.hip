@@ -23,18 +23,21 @@
 // points (:1025-1096, see oracle/gof_oracle_integrate.inc).
 // Documented deviation: contributor ids are not truncated to uint16 (:983); identical as long as
 // a tile list has at most 65535 entries.
+//
+// Two launches: integrate_pixels (phase A; depends on the Gaussians and the camera only -- writes the contributor
+// masks into the binning workspace, layout of cmask_base, and the pixel channels 0-2, 6, 7) and integrate_points
+// (phase B; reads masks + records).  The split costs one round trip of the masks (32 B per instance) and lets a
+// mesh-extraction driver run phase A ONCE per view for the 9-10 point sets it queries (extract_mesh.py:23-31, 88-100;
+// gof_integrate_view / gof_integrate_points).
 #include "gof_common.h"
 
 namespace gof {
 
 __global__ void __launch_bounds__(256)
-integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restrict__ point_ranges,
-                 const uint32_t* __restrict__ gaussian_list, const uint32_t* __restrict__ point_list,
-                 const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y,
-                 const float2* __restrict__ points2D, const float* __restrict__ point_depths, float* __restrict__ point_T,
-                 const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 float* __restrict__ out_color, float* __restrict__ out_alpha_integrated, float* __restrict__ out_color_integrated,
-                 uint32_t gx, uint32_t ntiles)
+integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
+                 const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
+                 float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles)
 {
     const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -49,18 +52,15 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
     const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
 
     const uint2 range = gaussian_ranges[tile];
-    const uint2 prange = point_ranges[tile];
     int toDo = (int)(range.y - range.x);
-    const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
-    const int nbatches = rounds > 0 ? rounds : 1;
+    const int nbatches = (toDo + TILE_PIX - 1) / TILE_PIX;
 
     __shared__ float4 s_rec[4][TILE_PIX];
     __shared__ uint32_t s_used[8][TILE_PIX];
     __shared__ float4 s_box[TILE_PIX];
+    __shared__ float4 s_con[2][TILE_PIX];
     const float pxf = (float)px, pyf = (float)py;
-    __shared__ float s_pixcol[3][TILE_PIX];
-    __shared__ uint32_t s_cnt[TILE_PIX];
-    __shared__ uint32_t s_iter;
+    uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
 
     // the 5 sub-rays: centre + 4 half-pixel corners (forward.cu:881-883, 920)
     float srx[5], sry[5];
@@ -73,16 +73,18 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             sry[c] = (float)(((double)(pixfy + offy[c]) - H / 2.) / (double)focal_y);
         }
     }
+    // footprint-conic cull: centre ray, the half-pixel steps in ray units, and the evaluation-error margin of the
+    // unit-normalised conic (sum |M_ij| = 1): 8 fp32 roundings of terms bounded by max(1, |r|^2) -> 3e-6 * that bound
+    const float crx = srx[0], cry = sry[0];
+    const float two_hx = 2.0f * (0.5f / focal_x), two_hy = 2.0f * (0.5f / focal_y);
+    const float cone_margin = 3e-6f * fmaxf(1.0f, fmaxf((fabsf(crx) + two_hx) * (fabsf(crx) + two_hx), (fabsf(cry) + two_hy) * (fabsf(cry) + two_hy)));
     float cT[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
     float C0 = 0, C1 = 0, C2 = 0, Cdepth = 0, Calpha = 0;
     uint32_t contributor = 0, last_contributor = 0, n_local = 0;
     bool done = !inside;
 
-    s_cnt[tid] = 0;
-    if (tid == 0) s_iter = 1;
-
     for (int b = 0; b < nbatches; b++, toDo -= TILE_PIX) {
-        __syncthreads();   // previous phase B finished with s_rec / s_used
+        __syncthreads();   // previous batch finished with s_rec
         const uint32_t k = range.x + (uint32_t)b * TILE_PIX + tid;
         if (k < range.y) {
             const uint32_t id = gaussian_list[k];
@@ -90,27 +92,49 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             const float4 a4 = src[0], b4 = src[1], c4 = src[2], d4 = src[3];
             s_rec[0][tid] = a4; s_rec[1][tid] = b4; s_rec[2][tid] = c4; s_rec[3][tid] = d4;
             s_box[tid] = bbox[id];
+            s_con[0][tid] = fconic[2 * (size_t)id];
+            s_con[1][tid] = fconic[2 * (size_t)id + 1];
         }
         __syncthreads();
 
-        // ---- phase A: pixel-centric pass 1 over this batch ----
+        // ---- phase A1: cull scan (wave-uniform over entries): footprint box, then the footprint conic bounded over the
+        // pixel's 5 sub-rays; survivors are recorded per pixel as candidate bits in s_used ----
         const int n = toDo < 0 ? 0 : (toDo < TILE_PIX ? toDo : TILE_PIX);
         for (int w = 0; w < 8; w++) {
             uint32_t word = 0;
             const int j0 = w * 32;
             const int j1 = (j0 + 32 < n) ? j0 + 32 : n;
             for (int j = j0; j < j1; j++) {
-                // conservative footprint box: a wave none of whose pixels can reach alpha >= 1/255 skips the entry (its
-                // list position is still counted below).  The box holds integer-rounded bounds {ceil(lo), floor(hi)} that
-                // are exact for integer pixel positions; the corner sub-rays sit at p +- 0.5, and p + 0.5 >= lo is implied
-                // by p + 1 >= ceil(lo), hence the widening by one full pixel.
+                // conservative footprint box: integer-rounded bounds {ceil(lo), floor(hi)}, exact for integer pixel positions; the
+                // corner sub-rays sit at p +- 0.5, and p + 0.5 >= lo is implied by p + 1 >= ceil(lo): widened by one full pixel.
                 const float4 bx = s_box[j];
                 const bool inbox = !done & (pxf + 1.0f >= bx.x) & (pxf - 1.0f <= bx.y) & (pyf + 1.0f >= bx.z) & (pyf - 1.0f <= bx.w);
                 if (__ballot(inbox) == 0ull) continue;
-                if (!inbox) continue;
+                // footprint conic g(r) = r^T M r (> 0 outside the alpha >= 1/255 level set, preprocess.hip): lower bound over the
+                // centre and the 4 corner sub-rays, against the fp32 evaluation error of the unit-normalised form
+                const float4 m0 = s_con[0][j], m1 = s_con[1][j];
+                const float tx_ = fmaf(m0.x, crx, fmaf(m0.y, cry, m0.w));          // (M r)_x
+                const float ty_ = fmaf(m0.y, crx, fmaf(m0.z, cry, m1.x));          // (M r)_y
+                const float g0 = fmaf(crx, tx_, fmaf(cry, ty_, fmaf(m0.w, crx, fmaf(m1.x, cry, m1.y))));
+                const float gc = g0 - fabsf(tx_) * two_hx - fabsf(ty_) * two_hy + m1.z;
+                const bool outside = fminf(g0, gc) > cone_margin;
+                if (inbox & !outside) word |= 1u << (j - j0);
+            }
+            s_used[w][tid] = word;
+        }
+        // ---- phase A2: per-lane ordered consumption of the candidates: the 5-sub-ray state machine of forward.cu:886-993;
+        // s_used is rewritten in place with the entries that contributed ----
+        for (int w = 0; w < 8; w++) {
+            uint32_t cand = s_used[w][tid];
+            uint32_t word = 0;
+            while (cand && !done) {
+                const int bit = __ffs((int)cand) - 1;
+                cand &= cand - 1;
+                const int j = w * 32 + bit;
                 contributor = (uint32_t)b * TILE_PIX + (uint32_t)j + 1u;      // 1-based list position
                 const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
                 const float wgt = c4.z;
+                const float log_thr = cull_log_threshold(wgt);
                 bool used = false;
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
@@ -121,11 +145,14 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                     const float AA = rx * n0 + ry * n1 + n2;
                     const float BB = 2 * (b4.z * rx + b4.w * ry + c4.x);
                     const float CC = c4.y;
-                    const float t = -BB / (2 * AA);
+                    // one IEEE division: -BB/(2*AA) == -(BB/AA)/2 and BB/4 are exact power-of-two scalings (forward.cu:927-931)
+                    const float q = BB / AA;
+                    const float t = -q * 0.5f;
                     if ((double)t <= GOF_NEAR_PLANE) continue;
-                    const double min_value = (double)(-(BB / AA)) * ((double)BB / 4.) + (double)CC;
+                    const double min_value = (double)(-q) * (double)(BB * 0.25f) + (double)CC;
                     float power = (float)(-0.5 * min_value);
                     if (power > 0.0f) power = 0.0f;
+                    if (power < log_thr) continue;                           // w * exp(power) < 0.999/255: below the threshold for sure
                     const float alpha = fminf(0.99f, wgt * gexpf(power));
                     if (alpha < 1.0f / 255.0f) continue;
                     const float test_T = cT[c] * (1 - alpha);
@@ -143,63 +170,150 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                 }
                 if (used) {
                     last_contributor = contributor;
-                    word |= 1u << (j - j0);
+                    word |= 1u << bit;
                     n_local += 1;
                     if (n_local >= (uint32_t)MAX_NUM_CONTRIBUTORS * 4) done = true;
                 }
             }
             s_used[w][tid] = word;
         }
-        const bool last_batch = (b == nbatches - 1);
-        if (last_batch) {
-            s_pixcol[0][tid] = C0 + cT[0] * bg_color[0];
-            s_pixcol[1][tid] = C1 + cT[0] * bg_color[1];
-            s_pixcol[2][tid] = C2 + cT[0] * bg_color[2];
+        // contributor words of this batch -> binning workspace (only the words the list covers)
+        const int nwords = (n + 31) >> 5;
+        for (int w = 0; w < nwords; w++)
+            cm_tile[((size_t)b * 8 + w) * TILE_PIX + tid] = s_used[w][tid];
+    }
+
+    if (inside) {
+        final_T[pix_id] = cT[0];
+        n_contrib[pix_id] = last_contributor;
+        out_color[0 * HW + pix_id] = C0 + cT[0] * bg_color[0];
+        out_color[1 * HW + pix_id] = C1 + cT[0] * bg_color[1];
+        out_color[2 * HW + pix_id] = C2 + cT[0] * bg_color[2];
+        out_color[6 * HW + pix_id] = Cdepth;
+        out_color[7 * HW + pix_id] = Calpha;
+    }
+}
+
+// Phase B.  base_color: the [9,H,W] image integrate_pixels wrote (channels 0-2 = the pixel colour every point of the
+// pixel receives, forward.cu:1207-1208); out_color may alias it.
+__global__ void __launch_bounds__(256)
+integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restrict__ point_ranges,
+                 const uint32_t* __restrict__ gaussian_list, const uint32_t* __restrict__ point_list,
+                 const SplatRec* __restrict__ rec, const float4* __restrict__ fconic, const uint32_t* __restrict__ cmask, int W, int H,
+                 float focal_x, float focal_y, const float2* __restrict__ pt_xy, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
+                 float* __restrict__ pt_acc, const float* __restrict__ base_color, float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
+                 float* __restrict__ out_color_integrated, uint32_t gx, uint32_t ntiles)
+{
+    const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const uint32_t tid = threadIdx.x;
+    uint32_t lx, ly;
+    tile_pixel(tid, lx, ly);
+    const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const uint32_t pix_id = (uint32_t)W * py + px;
+    const size_t HW = (size_t)W * H;
+
+    const uint2 range = gaussian_ranges[tile];
+    const uint2 prange = point_ranges[tile];
+    if (base_color != out_color && inside) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) out_color[c * HW + pix_id] = base_color[c * HW + pix_id];
+    }
+    if (prange.y <= prange.x) {                        // no query point in this tile: channel 8 = 0
+        if (inside) out_color[8 * HW + pix_id] = 0.0f;
+        return;
+    }
+    const int toDo0 = (int)(range.y - range.x);
+    const int rounds = (toDo0 + TILE_PIX - 1) / TILE_PIX;
+    const int nbatches = rounds > 0 ? rounds : 1;      // a tile without Gaussians still writes alpha = 0 for its points
+
+    __shared__ float4 s_rec[3][TILE_PIX];
+    __shared__ float s_zfront[TILE_PIX];
+    __shared__ uint32_t s_used[8][TILE_PIX];
+    __shared__ uint32_t s_cnt[TILE_PIX];
+    __shared__ uint32_t s_iter;
+    const uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
+
+    s_cnt[tid] = 0;
+    if (tid == 0) s_iter = 1;
+
+    int toDo = toDo0;
+    for (int b = 0; b < nbatches; b++, toDo -= TILE_PIX) {
+        __syncthreads();   // previous batch finished with s_rec / s_used
+        const uint32_t k = range.x + (uint32_t)b * TILE_PIX + tid;
+        if (k < range.y) {
+            const uint32_t id = gaussian_list[k];
+            const float4* src = reinterpret_cast<const float4*>(&rec[id]);
+            s_rec[0][tid] = src[0]; s_rec[1][tid] = src[1]; s_rec[2][tid] = src[2];
+            s_zfront[tid] = fconic[2 * (size_t)id + 1].w;
         }
+        const int n = toDo < 0 ? 0 : (toDo < TILE_PIX ? toDo : TILE_PIX);
+        const int nwords = (n + 31) >> 5;
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+            s_used[w][tid] = (w < nwords) ? cm_tile[((size_t)b * 8 + w) * TILE_PIX + tid] : 0u;
+        const bool last_batch = (b == nbatches - 1);
         __syncthreads();
 
-        // ---- phase B: point-centric pass 2 over this batch ----
         for (uint32_t base = prange.x; base < prange.y; base += TILE_PIX) {
             const uint32_t pi = base + tid;
             if (pi >= prange.y) continue;
-            const uint32_t pid = point_list[pi];
-            const float2 xy = points2D[pid];
-            const float ray_depth = point_depths[pid];
+            const float2 xy = pt_xy[pi];               // list order: coalesced, L2-resident across the batches of the tile
+            const float ray_depth = pt_depth[pi];
             const uint32_t lp = tile_thread((uint32_t)xy.x - tx * TILE_X, (uint32_t)xy.y - ty * TILE_Y);
             float T, acc;
             if (b == 0) { T = 1.f; acc = 0.f; atomicAdd(&s_cnt[lp], 1u); }
-            else { T = point_T[pid]; acc = out_alpha_integrated[pid]; }
+            else { T = pt_T[pi]; acc = pt_acc[pi]; }
             const float rx = (float)(((double)xy.x - W / 2.) / (double)focal_x);
             const float ry = (float)(((double)xy.y - H / 2.) / (double)focal_y);
-            for (int w = 0; w < 8; w++) {
-                uint32_t mask = s_used[w][lp];
-                while (mask) {
-                    const int bit = __ffs((int)mask) - 1;
-                    mask &= mask - 1;
-                    const int j = w * 32 + bit;
-                    const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
-                    const float n0 = a4.x * rx + a4.y * ry + a4.z;
-                    const float n1 = a4.y * rx + a4.w * ry + b4.x;
-                    const float n2 = a4.z * rx + b4.x * ry + b4.y;
-                    const float AA = rx * n0 + ry * n1 + n2;
-                    const float BB = 2 * (b4.z * rx + b4.w * ry + c4.x);
-                    const float CC = c4.y;
-                    float t = -BB / (2 * AA);
-                    if (t > ray_depth) t = ray_depth;
-                    const float power = -0.5f * (AA * t * t + BB * t + CC);
-                    const float alpha = fminf(0.99f, c4.z * gexpf(power));
-                    if (alpha < 1.0f / 255.0f) continue;
-                    const float test_T = T * (1 - alpha);
-                    acc += alpha * T;
-                    T = test_T;
-                }
+            // one flat loop over the set bits of the pixel's 8 mask words: lanes advance through their own words independently,
+            // so a wave iterates max-over-lanes(total bits), not sum-over-words(max-over-lanes(bits of the word))
+#ifndef GOF_POINT_LOOP_FLAT
+#define GOF_POINT_LOOP_FLAT 0     // measured: word-synchronous 12.3 ms vs flat 12.8 ms (S5M, 45M points)
+#endif
+            int w = 0;
+            uint32_t mask = s_used[0][lp];
+            while (true) {
+#if GOF_POINT_LOOP_FLAT
+                while (mask == 0u && w < 7) { w++; mask = s_used[w][lp]; }
+                if (mask == 0u) break;
+#else
+                if (__ballot(mask != 0u) == 0ull) { if (++w >= 8) break; mask = s_used[w][lp]; continue; }
+                if (mask == 0u) continue;
+#endif
+                const int bit = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                const int j = w * 32 + bit;
+                // the query point lies in front of everything this Gaussian can reach with alpha >= 1/255 (t is clamped
+                // to the point's depth below): certainly skipped by the alpha test
+                if (ray_depth < s_zfront[j]) continue;
+                const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
+                const float n0 = a4.x * rx + a4.y * ry + a4.z;
+                const float n1 = a4.y * rx + a4.w * ry + b4.x;
+                const float n2 = a4.z * rx + b4.x * ry + b4.y;
+                const float AA = rx * n0 + ry * n1 + n2;
+                const float BB = 2 * (b4.z * rx + b4.w * ry + c4.x);
+                const float CC = c4.y;
+                float t = -BB / (2 * AA);
+                if (t > ray_depth) t = ray_depth;
+                const float power = -0.5f * (AA * t * t + BB * t + CC);
+                const float alpha = fminf(0.99f, c4.z * gexpf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1 - alpha);
+                acc += alpha * T;
+                T = test_T;
             }
-            out_alpha_integrated[pid] = acc;
-            if (!last_batch) point_T[pid] = T;
+            if (!last_batch) { pt_T[pi] = T; pt_acc[pi] = acc; }
             else {
-                out_color_integrated[3 * (size_t)pid + 0] = s_pixcol[0][lp];
-                out_color_integrated[3 * (size_t)pid + 1] = s_pixcol[1][lp];
-                out_color_integrated[3 * (size_t)pid + 2] = s_pixcol[2][lp];
+                const uint32_t pid = point_list[pi];
+                out_alpha_integrated[pid] = acc;
+                const uint32_t ppx = (uint32_t)xy.x, ppy = (uint32_t)xy.y;
+                const size_t ppix = (size_t)W * ppy + ppx;
+                out_color_integrated[3 * (size_t)pid + 0] = base_color[0 * HW + ppix];
+                out_color_integrated[3 * (size_t)pid + 1] = base_color[1 * HW + ppix];
+                out_color_integrated[3 * (size_t)pid + 2] = base_color[2 * HW + ppix];
             }
         }
     }
@@ -213,18 +327,10 @@ integrate_kernel(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
     __syncthreads();
 
     if (inside) {
-        final_T[pix_id] = cT[0];
-        n_contrib[pix_id] = last_contributor;
-        out_color[0 * HW + pix_id] = C0 + cT[0] * bg_color[0];
-        out_color[1 * HW + pix_id] = C1 + cT[0] * bg_color[1];
-        out_color[2 * HW + pix_id] = C2 + cT[0] * bg_color[2];
-        out_color[6 * HW + pix_id] = Cdepth;
-        out_color[7 * HW + pix_id] = Calpha;
         uint32_t total = m;
         const uint32_t n_iter = s_iter;
-        if (n_iter > needed && prange.y > prange.x) {
-            const uint32_t lastpid = point_list[prange.y - 1];
-            const float2 lxy = points2D[lastpid];
+        if (n_iter > needed) {
+            const float2 lxy = pt_xy[prange.y - 1];
             const uint32_t llp = tile_thread((uint32_t)lxy.x - tx * TILE_X, (uint32_t)lxy.y - ty * TILE_Y);
             if (llp == tid) total += n_iter - needed;
         }

@@ -109,8 +109,20 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
 // therefore raised to k = m0 + Delta with Delta = 3e-5 * cond * lambda_max * |mu|^2 + 0.05, which keeps the box
 // conservative with respect to the arithmetic the blend actually performs (for sub-pixel, far-away
 // splats the box grows accordingly); for cond > 1e4 the box is left unbounded.
-__device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float w, float focal_x, float focal_y, int W, int H)
+// Also emits the footprint CONIC in ray space (fc[0..1]): a ray r = (rx, ry, 1) meets the level-set ellipsoid iff
+// g(r) = r^T M r <= 0 with M = (C - k) Sigma' - b b^T, b = Sigma' mu, C = mu^T Sigma' mu (min over t of the quadratic
+// along the ray is C - (b.r)^2 / (r^T Sigma' r)).  M is evaluated in fp64 from the same well-conditioned factors as the
+// box, then scaled to sum |M_ij| = 1 so that an fp32 evaluation of g carries an absolute error below ~1e-6 * max(1, |r|^2):
+//   fc[0] = {m00, m01, m11, m02}, fc[1] = {m12, m22, q, zfront},  q = m00 hx^2 + m11 hy^2 - 2 |m01| hx hy  (hx, hy = half a pixel in
+// ray units: the lower bound of g over the +-0.5 px corner sub-rays of integrate is g - |g_x| hx - |g_y| hy + q).
+// All-zero coefficients mean "no statement" (never culls): unbounded / degenerate cases.
+// zfront: a point of the level-set ellipsoid has view depth >= mu_z - sqrt(k / l_min) (Mahalanobis^2 >= l_min * dz^2), so a
+// query point whose depth (the clamp of t in integrate's point pass, forward.cu:1172-1178) is below zfront cannot reach
+// alpha >= 1/255 from this Gaussian; -1e30 = no statement.
+__device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float w, float focal_x, float focal_y, int W, int H, float4* fc)
 {
+    fc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    fc[1] = make_float4(0.f, 0.f, 0.f, -1e30f);
     const float4 unbounded = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);
     const float4 empty = make_float4(1e30f, -1e30f, 1e30f, -1e30f);
     if (!(w > 0.0f)) return empty;                                  // alpha <= 0 < 1/255 everywhere
@@ -152,6 +164,25 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     const double Szz = k * (a20 * a20 * ix + a21 * a21 * iy + a22 * a22 * iz);
     const double Sxz = k * (a00 * a20 * ix + a01 * a21 * iy + a02 * a22 * iz);
     const double Syz = k * (a10 * a20 * ix + a11 * a21 * iy + a12 * a22 * iz);
+    {   // footprint conic (see the header comment): Sigma'_ij = sum_c a_ic a_jc l_c
+        const double pxx = a00 * a00 * lx + a01 * a01 * ly + a02 * a02 * lz, pxy = a00 * a10 * lx + a01 * a11 * ly + a02 * a12 * lz;
+        const double pyy = a10 * a10 * lx + a11 * a11 * ly + a12 * a12 * lz, pxz = a00 * a20 * lx + a01 * a21 * ly + a02 * a22 * lz;
+        const double pyz = a10 * a20 * lx + a11 * a21 * ly + a12 * a22 * lz, pzz = a20 * a20 * lx + a21 * a21 * ly + a22 * a22 * lz;
+        const double bx = pxx * mx + pxy * my + pxz * mz, by = pxy * mx + pyy * my + pyz * mz, bz = pxz * mx + pyz * my + pzz * mz;
+        const double Kp = (mx * bx + my * by + mz * bz) - k;
+        const double m00 = Kp * pxx - bx * bx, m01 = Kp * pxy - bx * by, m11 = Kp * pyy - by * by;
+        const double m02 = Kp * pxz - bx * bz, m12 = Kp * pyz - by * bz, m22 = Kp * pzz - bz * bz;
+        const double Sm = fabs(m00) + 2.0 * fabs(m01) + fabs(m11) + 2.0 * fabs(m02) + 2.0 * fabs(m12) + fabs(m22);
+        if (Sm > 0.0 && Sm < 1e300) {
+            const double is = 1.0 / Sm;
+            const double hx = 0.5 / (double)focal_x, hy = 0.5 / (double)focal_y;
+            const double q = (m00 * hx * hx + m11 * hy * hy - 2.0 * fabs(m01) * hx * hy) * is;
+            fc[0] = make_float4((float)(m00 * is), (float)(m01 * is), (float)(m11 * is), (float)(m02 * is));
+            fc[1] = make_float4((float)(m12 * is), (float)(m22 * is), (float)q, -1e30f);
+        }
+        const double zf = mz - sqrt(k / lmin) * (1.0 + 1e-5) - 1e-5 * fabs(mz);
+        if (zf == zf) fc[1].w = (float)(zf - 1e-6 * fabs(zf));               // rounded down
+    }
     const double czz = mz * mz - Szz;
     // camera inside (or the ellipsoid reaching the camera plane): unbounded
     if (!(czz > 1e-9 * mz * mz) || !(mz > 0.0)) return unbounded;
@@ -177,7 +208,7 @@ preprocess_fwd(int P, int D, int M,
                int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                uint32_t gx, uint32_t gy, int prefiltered,
                int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
-               float4* __restrict__ conic_out, float4* __restrict__ bbox_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
+               float4* __restrict__ conic_out, float4* __restrict__ bbox_out, float4* __restrict__ fconic_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
                uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -273,12 +304,13 @@ preprocess_fwd(int P, int D, int M,
         clamped[idx] = (uint8_t)cb;
 
         float4 box = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);     // unbounded unless proven otherwise
+        float4 fc[2] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, -1e30f) };
         if (v2g_precomp == nullptr) {
             V2GInter I;
             v2g_intermediates(scale, p_orig, rot, cam.view, I);
             const V3 t2 = I.t2;
             const double C = (double)(t2.x * t2.x) * I.Sx + (double)(t2.y * t2.y) * I.Sy + (double)(t2.z * t2.z) * I.Sz;
-            box = footprint_bbox(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H);
+            box = footprint_bbox(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H, fc);
             const V3 B = mul(t2, I.SR);
             const M3 Sigma = mul(transpose(I.Rt), I.SR);
             r.f[0] = Sigma.m[0][0]; r.f[1] = Sigma.m[0][1]; r.f[2] = Sigma.m[0][2];
@@ -298,6 +330,8 @@ preprocess_fwd(int P, int D, int M,
         dst[3] = make_float4(r.f[12], r.f[13], r.f[14], r.f[15]);
         conic_out[idx] = make_float4(conx, cony, conz, 0.f);
         bbox_out[idx] = box;
+        fconic_out[2 * (size_t)idx] = fc[0];
+        fconic_out[2 * (size_t)idx + 1] = fc[1];
         depths[idx] = p_view.z;
         my_radii = (int32_t)my_radius;
         my_tiles = (maxy - miny) * (maxx - minx);

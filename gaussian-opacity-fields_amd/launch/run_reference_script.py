@@ -15,7 +15,10 @@ What it does, in this order (nothing in the reference checkout is edited):
      utils.loss_utils.ssim (train.py:20), utils.depth_utils.depth_to_normal / depths_to_points (train.py:38) and the
      optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups).
      GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations;
-  5. runs the script with runpy as __main__ with the remaining argv.
+  5. wraps gaussian_renderer.integrate (imported by name at extract_mesh.py:5) so that the Gaussian side of the opacity-field
+     query (binning + pixel pass) runs once per view for the ~10 point sets extract_mesh.py queries against the unchanged model
+     (diff_gaussian_rasterization.integrate_view_key; GOF_INTEGRATE_CACHE_GB bounds the HBM it may keep, 0 disables);
+  6. runs the script with runpy as __main__ with the remaining argv.
 """
 import importlib
 import os
@@ -58,6 +61,34 @@ def rebind_train_epilogue():
     GaussianModel.training_setup = training_setup
 
 
+def rebind_integrate_with_view_cache():
+    """extract_mesh.py:23-31 calls integrate(points, view, gaussians, ...) for every view, once per bisection step, with the
+    same Gaussians.  The wrapper announces a key made of the identities + version counters of everything but the points."""
+    import torch
+    import diff_gaussian_rasterization as DGR
+    try:
+        import gaussian_renderer as GR
+    except Exception:
+        return
+    orig = GR.integrate
+
+    def stamp(t):
+        return (t.data_ptr(), t._version, tuple(t.shape)) if isinstance(t, torch.Tensor) else t
+
+    def integrate(points3D, viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier=1.0, override_color=None, subpixel_offset=None):
+        if override_color is not None or subpixel_offset is not None or torch.is_grad_enabled():
+            return orig(points3D, viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, override_color, subpixel_offset)
+        cam = viewpoint_camera
+        key = (id(cam), getattr(cam, "uid", None), stamp(cam.world_view_transform), stamp(cam.full_proj_transform),
+               int(cam.image_width), int(cam.image_height), float(cam.FoVx), float(cam.FoVy), id(pc), int(pc.active_sh_degree),
+               tuple(stamp(getattr(pc, n, None)) for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "filter_3D")),
+               stamp(bg_color), float(kernel_size), float(scaling_modifier),
+               bool(getattr(pipe, "compute_cov3D_python", False)), bool(getattr(pipe, "convert_SHs_python", False)), bool(getattr(pipe, "debug", False)))
+        with DGR.integrate_view_key(key):
+            return orig(points3D, viewpoint_camera, pc, pipe, bg_color, kernel_size, scaling_modifier, override_color, subpixel_offset)
+    GR.integrate = integrate
+
+
 def main():
     if len(sys.argv) < 2:
         print(__doc__)
@@ -82,6 +113,8 @@ def main():
         pass
     if os.environ.get("GOF_TORCH_EPILOGUE", "0") != "1":
         rebind_train_epilogue()
+    if os.environ.get("GOF_INTEGRATE_CACHE_GB", "") not in ("0", "0.0"):
+        rebind_integrate_with_view_cache()
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name="__main__")
 

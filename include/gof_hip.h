@@ -85,6 +85,9 @@ size_t gof_image_bytes(int32_t W, int32_t H);
 size_t gof_binning_bytes(uint32_t num_rendered, int32_t W, int32_t H);
 /* replaces required<PointState>(PN)    (rasterizer_impl.cu:676, 206-216) */
 size_t gof_point_bytes(int32_t PN);
+/* replaces required<BinningState>(num_integrated) for the query points (rasterizer_impl.cu:706): the sort state only,
+ * without the contributor masks of gof_binning_bytes (a gof_binning_bytes-sized buffer is accepted too) */
+size_t gof_point_binning_bytes(uint32_t num_integrated, int32_t W, int32_t H);
 
 /* ---- forward (replaces _C.rasterize_gaussians, rasterize_points.cu:36-122) ------------- */
 /* Stage 1: preprocess (forward.cu:283-404) + inclusive scan of tiles_touched
@@ -162,6 +165,26 @@ int gof_integrate_run(const GofRasterArgs* args,
                       float* out_alpha_integrated,
                       float* out_color_integrated,
                       void* stream);
+
+/* The two halves of gof_integrate_run, exposed so that a mesh-extraction driver runs the Gaussian side ONCE per view
+ * for the 9-10 point sets it queries against unchanged Gaussians (extract_mesh.py:23-31, 88-100: evaluage_alpha is called
+ * once per bisection step and loops over all views):
+ *   gof_integrate_view:   Gaussian binning + the pixel pass (5 sub-rays per pixel, forward.cu:886-1007).  Leaves records,
+ *                         sorted list, tile ranges and per-pixel contributor masks in the three workspaces and the base
+ *                         image (channels 0-2, 6, 7; zero-filled by the caller beforehand) in out_color.
+ *   gof_integrate_points: point binning + the point pass (forward.cu:1138-1217) for one point set, after
+ *                         gof_integrate_prepare_points.  Reads the workspaces a previous gof_integrate_view of the SAME
+ *                         args filled (they are not modified except image_ws's point ranges); base_color is that call's
+ *                         image, out_color [9,H,W] receives it plus channel 8 (points per pixel) and may alias it. */
+int gof_integrate_view(const GofRasterArgs* args, uint32_t num_rendered, const int32_t* radii,
+                       void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes,
+                       void* image_ws, size_t image_bytes, float* out_color, void* stream);
+int gof_integrate_points(const GofRasterArgs* args, uint32_t num_rendered, int32_t PN, uint32_t num_integrated,
+                         const void* geom_ws, size_t geom_bytes, const void* binning_ws, size_t binning_bytes,
+                         void* image_ws, size_t image_bytes,
+                         void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                         const float* base_color, float* out_color,
+                         float* out_alpha_integrated, float* out_color_integrated, void* stream);
 
 /* ---- mark_visible (replaces _C.mark_visible, rasterize_points.cu:213-232) -------------- */
 int gof_mark_visible(int32_t P, const float* means3D,

@@ -250,6 +250,81 @@ def test_integrate_matches_oracle():
     assert (a[-2:] == 1.0).all()          # points outside the image keep the initial 1.0 (rasterize_points.cu:277)
 
 
+@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k"])
+def test_integrate_bit_exact_on_scene(name):
+    """The opacity-field query on the forward's scene table (incl. the cull stress scene: sub-pixel far splats, needles,
+    splats containing the camera plane, opacities around 1/255): every output bit-identical to the oracle.  Query points =
+    the 9 tetra points per Gaussian of scene/gaussian_model.py:432-463 (centre + scaled box corners)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = SCENES[name]()
+    pts = S.tetra_points(sc)
+    if len(pts) > 400_000:
+        pts = pts[np.random.default_rng(3).choice(len(pts), 400_000, replace=False)]
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    o = ob.OracleScene(sc)
+    oc, oal, ocol, orad = o.integrate(pts)
+    sd = to_dev(sc)
+    r = GaussianRasterizer(settings_from(sd))
+    color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
+                                            opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), orad)
+    c = color.cpu().numpy()
+    assert np.array_equal(bits(c), bits(oc)), [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)]
+    a = alpha.cpu().numpy()
+    assert np.array_equal(bits(a), bits(oal)), (int((bits(a) != bits(oal)).sum()), np.abs(a - oal).max())
+    assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
+
+
+def test_integrate_view_cache_reuses_the_gaussian_side_bit_exactly():
+    """Mesh-extraction driver fusion: under an announced view key the binning + pixel pass runs once; later
+    point sets reuse it.  Outputs must be bit-identical to uncached calls, a new key (changed Gaussians) must recompute."""
+    import diff_gaussian_rasterization as DGR
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = SCENES["ragged"]()
+    sd = to_dev(sc)
+    r = GaussianRasterizer(settings_from(sd))
+    rng = np.random.default_rng(5)
+    allpts = S.tetra_points(sc)
+    sets = [torch.from_numpy(np.ascontiguousarray(allpts[rng.choice(len(allpts), n, replace=False)])).cuda() for n in (50_000, 7, 120_000)]
+
+    def call(p, opac=None):
+        return r.integrate(points3D=p, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"] if opac is None else opac,
+                           shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    plain = [call(p) for p in sets]
+    cache = DGR.integrate_view_cache()
+    cache.clear()
+    h0, m0 = cache.hits, cache.misses
+    for p, ref in zip(sets, plain):
+        with DGR.integrate_view_key(("view", 1)):
+            got = call(p)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    assert cache.misses - m0 == 1 and cache.hits - h0 == 2 and len(cache.entries) == 1 and cache.bytes > 0
+    # the model changed -> the driver announces another key -> recomputed, and differs where it should
+    opac2 = (sd["opacities"] * 0.5).contiguous()
+    with DGR.integrate_view_key(("view", 2)):
+        got2 = call(sets[0], opac2)
+    ref2 = call(sets[0], opac2)
+    for a, b in zip(got2, ref2):
+        assert torch.equal(a, b)
+    assert not torch.equal(got2[1], plain[0][1])
+    # a zero budget stores nothing and still answers correctly
+    small = DGR.IntegrateViewCache(max_bytes=0)
+    from diff_gaussian_rasterization import _backend as B
+    old = B._view_cache
+    B._view_cache = small
+    try:
+        with DGR.integrate_view_key(("view", 3)):
+            got3 = call(sets[2])
+        assert small.rejected == 1 and not small.entries
+        for a, b in zip(got3, plain[2]):
+            assert torch.equal(a, b)
+    finally:
+        B._view_cache = old
+        cache.clear()
+
+
 def test_full_size_s1m_against_oracle():
     """BASELINE config 2 at FULL size (1M Gaussians, 1600x1063) against the oracle on the GPU box's host cores:
     forward bit-exact (normals 2e-6), blend gradients within 1e-4."""
