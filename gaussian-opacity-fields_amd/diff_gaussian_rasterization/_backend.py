@@ -191,9 +191,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
               viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, H, W, sh, degree, campos, False, debug)
     P, M, dev = v.P, v.M, v.device
     f = dict(dtype=torch.float32, device=dev)
-    g_means3D = torch.empty((P, 3), **f); g_means2D = torch.empty((P, 3), **f); g_colors = torch.empty((P, 3), **f)
-    g_opacity = torch.empty((P, 1), **f); g_cov3D = torch.empty((P, 6), **f); g_sh = torch.empty((P, M, 3), **f)
-    g_scales = torch.empty((P, 3), **f); g_rot = torch.empty((P, 4), **f); g_v2g = torch.empty((P, 10), **f)
+    # The gradients of the Gaussian PARAMETERS (means3D, sh, opacity, scales, rotations: 59 floats per Gaussian at SH degree 3)
+    # are carved from ONE allocation in that order, 16-byte aligned segments: a data-parallel trainer can all-reduce the
+    # bucket in place (dp/reducer.py) instead of packing 236 B per Gaussian into a bucket and back.
+    sizes = [3 * P, 3 * M * P, P, 3 * P, 4 * P]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) & ~3
+    bucket = torch.empty(tot, **f)
+    g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_sh = bucket[offs[1]:offs[1] + sizes[1]].view(P, M, 3)
+    g_opacity = bucket[offs[2]:offs[2] + sizes[2]].view(P, 1); g_scales = bucket[offs[3]:offs[3] + sizes[3]].view(P, 3)
+    g_rot = bucket[offs[4]:offs[4] + sizes[4]].view(P, 4)
+    g_means2D = torch.empty((P, 3), **f); g_colors = torch.empty((P, 3), **f)
+    g_cov3D = torch.empty((P, 6), **f); g_v2g = torch.empty((P, 10), **f)
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):

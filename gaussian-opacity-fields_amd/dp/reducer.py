@@ -30,10 +30,33 @@ class GradientAllReducer:
             self._flat = torch.empty(n, device=device, dtype=dtype)
         return self._flat
 
+    @staticmethod
+    def _shared_bucket(grads):
+        """If the gradients are contiguous, ascending, non-overlapping views of ONE storage with < 16 B of padding between them
+        (diff_gaussian_rasterization's backward allocates them that way), return the covering 1-D view, else None."""
+        g0 = grads[0]
+        if any((not g.is_contiguous()) or g.dtype != g0.dtype or g.device != g0.device or
+               g.untyped_storage().data_ptr() != g0.untyped_storage().data_ptr() for g in grads):
+            return None
+        end = g0.storage_offset()
+        for g in grads:
+            gap = g.storage_offset() - end
+            if gap < 0 or gap > 3:
+                return None
+            end = g.storage_offset() + g.numel()
+        start = g0.storage_offset()
+        return torch.as_strided(g0, (end - start,), (1,), start)      # padding floats are reduced too (harmless, uninitialised)
+
     @torch.no_grad()
     def all_reduce(self):
         ps = [p for p in self.params if p.grad is not None]
         if not ps or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        bucket = self._shared_bucket([p.grad for p in ps])
+        if bucket is not None:                       # the rasterizer's backward carved them from one allocation: reduce in place
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                bucket.div_(dist.get_world_size(self.group))
             return
         grads = [p.grad.reshape(-1) for p in ps]
         n = sum(g.numel() for g in grads)

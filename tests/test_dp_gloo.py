@@ -47,6 +47,24 @@ def _worker(rank, world, port, ret):
     params[1].grad = None
     GradientAllReducer(params, average=True).all_reduce()
     ok = ok and params[1].grad is None and torch.allclose(params[0].grad, expect[0] / world, atol=1e-6)
+    # gradients carved from ONE allocation in parameter order (as diff_gaussian_rasterization's backward does): reduced in place
+    sizes = [int(torch.tensor(s_).prod()) for s_ in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot); tot += (n + 3) & ~3
+    bucket = torch.full((tot,), float("nan"))
+    for p, l, o, n in zip(params, local, offs, sizes):
+        v = bucket[o:o + n].view(l.shape)
+        v.copy_(l)
+        p.grad = v
+    red2 = GradientAllReducer(params)
+    ok = ok and red2._shared_bucket([p.grad for p in params]) is not None
+    red2.all_reduce()
+    ok = ok and red2._flat is None                       # the pack/unpack bucket was never needed
+    ok = ok and all(torch.allclose(p.grad, e, atol=1e-6) for p, e in zip(params, expect))
+    ok = ok and all(p.grad.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr() for p in params)
+    # ... and a set that is NOT one ascending allocation falls back to pack / reduce / unpack
+    ok = ok and GradientAllReducer._shared_bucket([params[1].grad, params[0].grad]) is None
     # densification statistics
     acc = torch.full((P, 1), float(rank + 1)); acc_abs = acc.clone(); denom = torch.ones(P, 1)
     radii = torch.full((P,), float(rank)); absmax = torch.full((P, 1), float(10 - rank))
