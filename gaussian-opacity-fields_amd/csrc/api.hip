@@ -40,10 +40,9 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
 int radix_passes(int end_bit);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const SplatRec* rec, const int32_t* radii,
                                uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t gy);
-__global__ void point_depth_keys(int PN, const float* depths, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys,
-                                 uint32_t* vals);
-__global__ void point_tile_keys(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, uint32_t* tiles, uint32_t gx, uint32_t gy);
-__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges);
+__global__ void point_keys(int PN, const float2* points2D, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
+                           uint32_t gx, uint32_t gy);
+__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift);
 __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* gids, const float* depths, uint64_t* keys);
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H,
@@ -237,7 +236,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
-        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges);
+        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0);
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     return GOF_OK;
@@ -465,29 +464,23 @@ int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_
     point_layout(PN, aligned_base(point_ws), &w);
     bin_layout(NI, a->W, a->H, aligned_base(point_binning_ws), &pb, false);
     const Dims d = dims_of(a);
-    // same two-level sort as the Gaussians: visible points by depth (4 passes), then by tile (2 passes); stable, so ties keep ascending point id
+    // one stable sort of the visible points by (tile, pixel of the tile): 3 radix passes (see point_keys)
     { GOF_PROFILE("bin_points", stream);
     if (NI > 0) {
-        const int tile_bits = (int)higher_msb(d.ntiles);
-        hipLaunchKernelGGL(point_depth_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.depths, w.point_offsets,
-                           w.tiles_touched, pb.tiles, pb.vals);
-        GOF_LAUNCH_CHECK(stream, a->debug);
-        uint32_t *kr = nullptr, *vr = nullptr;
-        GOF_HIP_CHECK(radix_sort_pairs_u32(pb.tiles, pb.vals, pb.tiles_alt, pb.vals_alt, NI, 32, pb.sort_tmp, &kr, &vr, stream));
-        // vr == pb.vals (even number of passes).  Tile keys of the depth-sorted ids go to the pair that makes the final result land in (tiles, vals)
-        const bool odd = radix_passes(tile_bits) & 1;
+        const int key_bits = (int)higher_msb(d.ntiles) + 8;
+        const bool odd = radix_passes(key_bits) & 1;
         uint32_t* t_in = odd ? pb.tiles_alt : pb.tiles;
         uint32_t* v_in = odd ? pb.vals_alt : pb.vals;
-        if (v_in != vr) GOF_HIP_CHECK(hipMemcpyAsync(v_in, vr, (size_t)NI * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(point_tile_keys, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, v_in, w.points2D, t_in, d.gx, d.gy);
+        hipLaunchKernelGGL(point_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.points2D, w.point_offsets, w.tiles_touched,
+                           t_in, v_in, d.gx, d.gy);
         GOF_LAUNCH_CHECK(stream, a->debug);
-        rc = sort_by_tile(pb, NI, t_in, v_in, tile_bits, stream);
+        rc = sort_by_tile(pb, NI, t_in, v_in, key_bits, stream);
         if (rc) return rc;
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.point_ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (NI > 0) {
-        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges);
+        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8);
         GOF_LAUNCH_CHECK(stream, a->debug);
         hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.points2D, w.depths, pb.pt_xy, pb.pt_depth);
         GOF_LAUNCH_CHECK(stream, a->debug);

@@ -55,31 +55,26 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     }
 }
 
-// query points: one instance per point inside the image (replaces createWithKeys, rasterizer_impl.cu:113-144);
-// emits the depth key and the point id of every visible point, compacted by the inclusive scan `offsets`
+// Query points: one instance per point inside the image (replaces createWithKeys, rasterizer_impl.cu:113-144), compacted by the
+// inclusive scan `offsets`.  Sort key: tile id in the high bits, pixel of the tile (wave-quadrant order of tile_thread) in the
+// low 8.  The reference sorts its points by (tile, depth); no output depends on the order of a tile's points except channel 8's
+// re-count of the tile's deepest point, which integrate_points finds explicitly -- so the 4 depth passes are dropped, and
+// grouping by pixel lets neighbouring lanes of integrate_points walk the SAME contributor mask.
 __global__ void __launch_bounds__(256)
-point_depth_keys(int PN, const float* __restrict__ depths, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
-                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+point_keys(int PN, const float2* __restrict__ points2D, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
+           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx, uint32_t gy)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= PN) return;
     if (tiles_touched[idx] > 0) {
         const uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
-        keys[off] = __float_as_uint(depths[idx]);
+        const float2 p = points2D[idx];
+        const int x = (int)min(gx - 1, (uint32_t)max(0, (int)(p.x / TILE_X)));
+        const int y = (int)min(gy - 1, (uint32_t)max(0, (int)(p.y / TILE_Y)));
+        const uint32_t lx = ((uint32_t)p.x - (uint32_t)x * TILE_X) & (TILE_X - 1), ly = ((uint32_t)p.y - (uint32_t)y * TILE_Y) & (TILE_Y - 1);
+        keys[off] = ((uint32_t)(y * gx + x) << 8) | tile_thread(lx, ly);
         vals[off] = (uint32_t)idx;
     }
-}
-// tile id of every (depth-sorted) visible point
-__global__ void __launch_bounds__(256)
-point_tile_keys(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const float2* __restrict__ points2D, uint32_t* __restrict__ tiles,
-                uint32_t gx, uint32_t gy)
-{
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NI) return;
-    const float2 p = points2D[sorted_ids[i]];
-    const int x = (int)min(gx - 1, (uint32_t)max(0, (int)(p.x / TILE_X)));
-    const int y = (int)min(gy - 1, (uint32_t)max(0, (int)(p.y / TILE_Y)));
-    tiles[i] = (uint32_t)(y * gx + x);
 }
 
 // per-point data in LIST order (tile-major, depth within the tile): the point pass of integrate reads it once per staged batch,
@@ -97,14 +92,14 @@ gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const
 
 // replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before
 __global__ void __launch_bounds__(256)
-tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges)
+tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges, int shift)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t currtile = tiles[idx];
+    const uint32_t currtile = tiles[idx] >> shift;
     if (idx == 0) ranges[currtile].x = 0;
     else {
-        const uint32_t prevtile = tiles[idx - 1];
+        const uint32_t prevtile = tiles[idx - 1] >> shift;
         if (currtile != prevtile) {
             ranges[prevtile].y = idx;
             ranges[currtile].x = idx;

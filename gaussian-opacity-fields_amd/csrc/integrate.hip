@@ -326,14 +326,35 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
     if (inside && needed > 1) atomicMax(&s_iter, needed);
     __syncthreads();
 
+    // The reference re-counts the tile's LAST point in its (tile, depth) order -- the deepest point, ties to the highest id --
+    // once per extra outer iteration (forward.cu:1025-1096).  The list here is grouped by pixel, so find that point explicitly;
+    // only tiles in which some pixel holds > 256 points get here.
+    const uint32_t n_iter = s_iter;
+    __shared__ unsigned long long s_deepest;
+    __shared__ uint32_t s_deepest_lp;
+    if (n_iter > 1) {                                   // block-uniform
+        if (tid == 0) s_deepest = 0ull;
+        __syncthreads();
+        unsigned long long best = 0ull;
+        for (uint32_t pi = prange.x + tid; pi < prange.y; pi += TILE_PIX) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(pt_depth[pi]) << 32) | point_list[pi];
+            best = key > best ? key : best;
+        }
+        atomicMax(&s_deepest, best);
+        __syncthreads();
+        const unsigned long long top = s_deepest;
+        for (uint32_t pi = prange.x + tid; pi < prange.y; pi += TILE_PIX) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(pt_depth[pi]) << 32) | point_list[pi];
+            if (key == top) {
+                const float2 lxy = pt_xy[pi];
+                s_deepest_lp = tile_thread((uint32_t)lxy.x - tx * TILE_X, (uint32_t)lxy.y - ty * TILE_Y);
+            }
+        }
+        __syncthreads();
+    }
     if (inside) {
         uint32_t total = m;
-        const uint32_t n_iter = s_iter;
-        if (n_iter > needed) {
-            const float2 lxy = pt_xy[prange.y - 1];
-            const uint32_t llp = tile_thread((uint32_t)lxy.x - tx * TILE_X, (uint32_t)lxy.y - ty * TILE_Y);
-            if (llp == tid) total += n_iter - needed;
-        }
+        if (n_iter > needed && s_deepest_lp == tid) total += n_iter - needed;
         out_color[8 * HW + pix_id] = (float)total;
     }
 }
