@@ -1,7 +1,7 @@
 """Developer script: time the HIP training epilogue against the reference's torch implementation on the GPU
 (1600x1063 image, 1M Gaussians x 59 floats for Adam).  Prints a JSON dict of ms per call."""
 import json, os, sys, time, types
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gpu_common import *   # noqa
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

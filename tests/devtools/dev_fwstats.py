@@ -1,5 +1,5 @@
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S

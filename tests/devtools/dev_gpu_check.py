@@ -1,6 +1,6 @@
 """Developer script (not a test): first contact of the kernels with the oracle on a GPU."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S, oracle_binding as ob

@@ -1,6 +1,6 @@
 """Developer script: a few fwd+bwd iterations at S1M for PMC collection."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gpu_common import *
 import synthetic_scenes as S

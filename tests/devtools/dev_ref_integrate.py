@@ -2,7 +2,7 @@
 (oracle/_ref, hipcc build), meant to be run under rocprofv3 --kernel-trace --stats; also a phase-A-only product call
 (9 query points) to split the kernel time."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S, reference_binding as rb

@@ -1,7 +1,7 @@
 """Developer script: the REFERENCE's own kernels (oracle/_ref, hipcc build of the CUDA sources, default contraction)
 timed on this GPU at S1M, next to the product."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S, reference_binding as rb

@@ -1,6 +1,6 @@
 """Developer script: workload statistics of S1M on the GPU (list lengths, walked entries, contributors)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S

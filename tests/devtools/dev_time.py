@@ -1,6 +1,6 @@
 """Developer script: per-call timing of forward / backward at S1M with HIP events."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S
