@@ -85,7 +85,7 @@ ProfileScope::ProfileScope(const char* name, hipStream_t s) : slot(-1), stream(s
     if (!g_prof_on) return;
     ProfRec r; r.name = name;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-    hipEventRecord(r.e0, stream);
+    (void)hipEventRecord(r.e0, stream);      // profiling is best effort: a failed record shows up as a missing sample
     std::lock_guard<std::mutex> lk(g_prof_mutex);
     g_prof.push_back(r);
     slot = (int)g_prof.size() - 1;
@@ -94,7 +94,7 @@ ProfileScope::~ProfileScope()
 {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mutex);
-    if (slot < (int)g_prof.size()) hipEventRecord(g_prof[slot].e1, stream);
+    if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
 }
 
 // ---- workspace layouts -------------------------------------------------------------------------------
@@ -538,7 +538,7 @@ int gof_profile_report(char* buf, size_t cap)
             for (auto& a : aggs) if (!strcmp(a.name, r.name)) { a.calls++; a.ms += ms; found = true; break; }
             if (!found) aggs.push_back(Agg{ r.name, 1, (double)ms });
         }
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_prof.clear();
     std::string s = "{";
