@@ -63,6 +63,39 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Transposed ("butterfly") row reduction of 16 values: each exchange step halves the number of live values instead of summing
+// every value at every step.  After the two quad steps lane (b1 b0) holds, for m = 0..3, the quad sum of value 4m + 2 b1 + b0;
+// two row rotations complete the sum over the row's four quads.  44 VALU instead of 64, and the 16 results sit in 4 lanes
+// (4 each) instead of 16 values in one lane: 4 LDS adds instead of 16.
+__device__ __forceinline__ void row_sum16_transposed(const float* g, bool b0, bool b1, float w4[4])
+{
+    float u[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const float keep = b0 ? g[2 * m + 1] : g[2 * m];
+        const float send = b0 ? g[2 * m] : g[2 * m + 1];
+        u[m] = keep + dpp_get<0xB1>(send);          // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const float keep = b1 ? u[2 * m + 1] : u[2 * m];
+        const float send = b1 ? u[2 * m] : u[2 * m + 1];
+        float w = keep + dpp_get<0x4E>(send);       // quad_perm [2,3,0,1]
+        w = w + dpp_get<0x124>(w);                  // row_ror:4
+        w = w + dpp_get<0x128>(w);                  // row_ror:8
+        w4[m] = w;
+    }
+}
+
+#ifndef GOF_BW_BUTTERFLY
+#define GOF_BW_BUTTERFLY 1
+#endif
+
 __global__ void __launch_bounds__(256)
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
@@ -274,16 +307,31 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     g[15] = dL_dB * 2;
                     g[16] = dL_dmin_value;
                 }
-#pragma unroll
-                for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
                 // rows (16 lanes = 8x2 pixels) in which no pixel contributed hold exact zeros: skip their LDS adds
                 const uint64_t cmask64 = __ballot(contrib);
                 const bool row_hit = ((cmask64 >> (lane & 48u)) & 0xFFFFull) != 0ull;
+#if GOF_BW_BUTTERFLY
+                float w4[4];
+                row_sum16_transposed(g, (lane & 1u) != 0u, (lane & 2u) != 0u, w4);
+                const float g16 = row_sum(g[16]);
+                if ((lane & 12u) == 0u && row_hit) {            // lanes 0..3 of the row: values 4m + (lane & 3)
+                    float* dst = &s_acc[lane & 3u][j];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) unsafeAtomicAdd(dst + (size_t)m * 4 * BATCH, w4[m]);
+                }
+                if ((lane & 15u) == 15u && row_hit) {
+                    unsafeAtomicAdd(&s_acc[16][j], g16);
+                    s_touched[j] = 1u;
+                }
+#else
+#pragma unroll
+                for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
                 if ((lane & 15u) == 15u && row_hit) {
 #pragma unroll
                     for (int k = 0; k < NGRAD; k++) unsafeAtomicAdd(&s_acc[k][j], g[k]);
                     s_touched[j] = 1u;
                 }
+#endif
             }
         }
         __syncthreads();
