@@ -8,9 +8,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
+# GOF_BUILD_TAG=<tag> builds an experimental variant next to the product (build_<tag>/, lib/libgof_hip_<tag>.so; select it at run
+# time with GOF_HIP_LIB) -- used to time compiler-flag / macro variants in one GPU session
+_TAG = os.environ.get("GOF_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + _TAG if _TAG else ""))
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libgof_hip.so")
+LIB = os.path.join(LIBDIR, "libgof_hip%s.so" % ("_" + _TAG if _TAG else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the arithmetic contract -- fused multiply-adds only where fmaf() is written
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -86,6 +86,10 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     __shared__ float4 s_box[TILE_PIX];
     uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
     const float pxf = (float)px, pyf = (float)py;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // pixel rectangle of this wave (tile_pixel: wave w covers the 8x8 quadrant (w & 1, w >> 1)), inclusive bounds
+    const float wave_x0 = (float)(tx * TILE_X + 8u * (wave & 1u)), wave_x1 = wave_x0 + 7.0f;
+    const float wave_y0 = (float)(ty * TILE_Y + 8u * (wave >> 1)), wave_y1 = wave_y0 + 7.0f;
 
     bool done = !inside;
     float T = 1.0f;
@@ -123,25 +127,36 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
         const int nw = w0 + ((cn + 31) >> 5);
 
         // ---- phase 1: cull scan ----
-        for (int w = w0; w < nw; w++) {
-            uint32_t word = 0;
-            const int j0 = w * 32;
-            const int cnt = min(32, n - j0);
-            for (int b = 0; b < cnt; b++) {
-                const int j = j0 + b;
+        // (a) lane = ENTRY: 64 entries at a time against the wave's 8x8 pixel rectangle -> a wave-uniform 64-bit mask of the
+        //     entries whose footprint box touches the wave at all (the others cost 1/64 instruction each instead of ~8);
+        // (b) lane = PIXEL, scalar loop over the set bits: the pixel's own box test, the fp32 prelude and the error-bounded cull.
+        for (int w = w0; w < nw; w += 2) {
+            const int je = w * 32 + (int)lane;
+            bool touch = false;
+            if (je < n) {
+                const float4 bx = s_box[je];
+                touch = (wave_x1 >= bx.x) & (wave_x0 <= bx.y) & (wave_y1 >= bx.z) & (wave_y0 <= bx.w);
+            }
+            uint64_t m = __ballot(touch);
+            uint32_t word_lo = 0, word_hi = 0;
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const int j = w * 32 + b;
                 const float4 bx = s_box[j];
                 const bool inbox = !done & (pxf >= bx.x) & (pxf <= bx.y) & (pyf >= bx.z) & (pyf <= bx.w);
-                if (__ballot(inbox) == 0ull) continue;          // no pixel of this wave can see the splat
+                if (__ballot(inbox) == 0ull) continue;          // only saturated pixels of the wave lie inside
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
                 const float v[10] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y };
                 PairEval p;
                 pair_prelude(v, rx, ry, p);
-                const bool pass = inbox && !pair_certainly_transparent(p, q2.y, q2.z);
-                word |= (pass ? 1u : 0u) << b;
+                const uint32_t pass = (inbox && !pair_certainly_transparent(p, q2.y, q2.z)) ? 1u : 0u;
+                if (b < 32) word_lo |= pass << b; else word_hi |= pass << (b - 32);
             }
-            s_mask[w][tid] = done ? 0u : word;
-            if ((tid & 63) == 0) STAT_ADD(0, cnt);
-            STAT_ADD(1, done ? 0 : __popc(word));
+            s_mask[w][tid] = done ? 0u : word_lo;
+            if (w + 1 < nw) s_mask[w + 1][tid] = done ? 0u : word_hi;
+            if ((tid & 63) == 0) STAT_ADD(0, min(64, n - w * 32));
+            STAT_ADD(1, done ? 0 : __popc(word_lo) + __popc(word_hi));
         }
 
         // ---- phase 2: every lane consumes its own candidates in list order ----
