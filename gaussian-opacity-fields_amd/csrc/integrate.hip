@@ -60,6 +60,10 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
     __shared__ float4 s_box[TILE_PIX];
     __shared__ float4 s_con[2][TILE_PIX];
     const float pxf = (float)px, pyf = (float)py;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // pixel rectangle of this wave (tile_pixel: wave w covers the 8x8 quadrant (w & 1, w >> 1)), inclusive bounds
+    const float wave_x0 = (float)(tx * TILE_X + 8u * (wave & 1u)), wave_x1 = wave_x0 + 7.0f;
+    const float wave_y0 = (float)(ty * TILE_Y + 8u * (wave >> 1)), wave_y1 = wave_y0 + 7.0f;
     uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
 
     // the 5 sub-rays: centre + 4 half-pixel corners (forward.cu:881-883, 920)
@@ -100,11 +104,21 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
         // ---- phase A1: cull scan (wave-uniform over entries): footprint box, then the footprint conic bounded over the
         // pixel's 5 sub-rays; survivors are recorded per pixel as candidate bits in s_used ----
         const int n = toDo < 0 ? 0 : (toDo < TILE_PIX ? toDo : TILE_PIX);
-        for (int w = 0; w < 8; w++) {
-            uint32_t word = 0;
-            const int j0 = w * 32;
-            const int j1 = (j0 + 32 < n) ? j0 + 32 : n;
-            for (int j = j0; j < j1; j++) {
+        // (a) lane = ENTRY: 64 entries at a time against the wave's 8x8 pixel rectangle (widened by the same pixel as below);
+        // (b) lane = PIXEL over the entries that touch the wave.
+        for (int w = 0; w < 8; w += 2) {
+            const int je = w * 32 + (int)lane;
+            bool touch = false;
+            if (je < n) {
+                const float4 bx = s_box[je];
+                touch = (wave_x1 + 1.0f >= bx.x) & (wave_x0 - 1.0f <= bx.y) & (wave_y1 + 1.0f >= bx.z) & (wave_y0 - 1.0f <= bx.w);
+            }
+            uint64_t m = __ballot(touch);
+            uint32_t word_lo = 0, word_hi = 0;
+            while (m) {
+                const int bb = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const int j = w * 32 + bb;
                 // conservative footprint box: integer-rounded bounds {ceil(lo), floor(hi)}, exact for integer pixel positions; the
                 // corner sub-rays sit at p +- 0.5, and p + 0.5 >= lo is implied by p + 1 >= ceil(lo): widened by one full pixel.
                 const float4 bx = s_box[j];
@@ -117,10 +131,11 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                 const float ty_ = fmaf(m0.y, crx, fmaf(m0.z, cry, m1.x));          // (M r)_y
                 const float g0 = fmaf(crx, tx_, fmaf(cry, ty_, fmaf(m0.w, crx, fmaf(m1.x, cry, m1.y))));
                 const float gc = g0 - fabsf(tx_) * two_hx - fabsf(ty_) * two_hy + m1.z;
-                const bool outside = fminf(g0, gc) > cone_margin;
-                if (inbox & !outside) word |= 1u << (j - j0);
+                const uint32_t cand = (inbox & !(fminf(g0, gc) > cone_margin)) ? 1u : 0u;
+                if (bb < 32) word_lo |= cand << bb; else word_hi |= cand << (bb - 32);
             }
-            s_used[w][tid] = word;
+            s_used[w][tid] = word_lo;
+            s_used[w + 1][tid] = word_hi;
         }
         // ---- phase A2: per-lane ordered consumption of the candidates: the 5-sub-ray state machine of forward.cu:886-993;
         // s_used is rewritten in place with the entries that contributed ----
