@@ -325,6 +325,43 @@ def test_integrate_view_cache_reuses_the_gaussian_side_bit_exactly():
         cache.clear()
 
 
+def test_integrate_full_size_properties_config5():
+    """BASELINE config 5 shape at FULL size (5M Gaussians, 45M query points, 1600x1063): size-independent properties of the
+    opacity-field query instead of an oracle run -- range, untouched points, channel-8 checksum, idempotence, cache equivalence,
+    and linearity in the query set (a point's result does not depend on which other points are queried with it)."""
+    import diff_gaussian_rasterization as DGR
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = S.scene_frustum(5_000_000, seed=0, sigma_px=1.5)
+    pts = torch.from_numpy(S.tetra_points(sc)).cuda()
+    assert pts.shape[0] == 45_000_000
+    sd = to_dev(sc)
+    r = GaussianRasterizer(settings_from(sd))
+
+    def call(p):
+        return r.integrate(points3D=p, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"],
+                           scales=sd["scales"], rotations=sd["rotations"])
+    color, alpha, colp, radii = call(pts)
+    assert torch.isfinite(alpha).all() and alpha.min().item() >= 0.0 and alpha.max().item() <= 1.0 + 1e-5   # sum of alpha*T in fp32
+    n_in = int(color[8].sum().item())                         # channel 8 counts the points of every pixel
+    written = int((alpha != 1.0).sum().item())
+    assert 30_000_000 < n_in <= 45_000_000 and written <= n_in
+    assert int((colp != 0).any(dim=1).sum().item()) <= n_in   # only points inside the image receive a colour
+    c2, a2, p2, _ = call(pts)
+    assert torch.equal(a2, alpha) and torch.equal(c2, color) and torch.equal(p2, colp)      # deterministic
+    cache = DGR.integrate_view_cache(); cache.clear()
+    with DGR.integrate_view_key(("cfg5", 0)):
+        call(pts[:9])
+    with DGR.integrate_view_key(("cfg5", 0)):
+        c3, a3, p3, _ = call(pts)
+    assert torch.equal(a3, alpha) and torch.equal(c3, color) and torch.equal(p3, colp)      # cached == uncached
+    sub = torch.arange(0, pts.shape[0], 7, device="cuda")
+    with DGR.integrate_view_key(("cfg5", 0)):
+        c4, a4, p4, _ = call(pts[sub].contiguous())
+    assert torch.equal(a4, alpha[sub]) and torch.equal(p4, colp[sub])                      # per-point results are independent
+    assert torch.equal(c4[:8], color[:8])
+    cache.clear()
+
+
 def test_full_size_s1m_against_oracle():
     """BASELINE config 2 at FULL size (1M Gaussians, 1600x1063) against the oracle on the GPU box's host cores:
     forward bit-exact (normals 2e-6), blend gradients within 1e-4."""
