@@ -93,10 +93,12 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if rank == 0:
-        B.profile_enable(True)      # HIP events around every kernel launch, on the launch stream, over the timed region
+    # HIP events around every kernel launch, recorded by the library on its launch stream INSIDE the timed region, on every 4th
+    # step: each event pair drains the queue between two kernels (measured: 0.085 ms per fully instrumented step, 2.3 %)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if rank == 0:
+            B.profile_enable(i % 4 == 0)
         step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -243,12 +245,14 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     for _ in range(warmup):
         iteration()
     torch.cuda.synchronize()
-    B.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         iteration()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    B.profile_enable(True)                    # epilogue kernel durations: three more iterations with the library's HIP events
+    for _ in range(3):
+        iteration()
     kt = B.profile_report()
     B.profile_enable(False)
     ep = {k: round(v["total_ms"] / max(1, v["calls"]), 5) for k, v in kt.items()
