@@ -7,7 +7,8 @@ MI355X backend.
 What it does, in this order (nothing in the reference checkout is edited):
   1. puts this package first on sys.path so `import diff_gaussian_rasterization` resolves to the gfx950
      backend, and the reference checkout second so its own packages (scene, utils, gaussian_renderer) import;
-  2. puts the import shims for the out-of-scope native submodules (simple_knn, tetranerf) on sys.path unless the
+  2. `simple_knn._C.distCUDA2` resolves to the HIP implementation in this package (simple_knn/, include/gof_knn_hip.h); puts the
+     import shim for the out-of-scope native submodule (tetranerf: CGAL Delaunay) on sys.path unless the
      real modules are importable;
   3. rebinds utils.tetmesh.marching_tetrahedra to the HIP implementation BEFORE the script imports it by name
      (extract_mesh.py:14: `from utils.tetmesh import marching_tetrahedra`);
@@ -97,7 +98,7 @@ def main():
     ref_root = os.path.dirname(script)
     sys.path.insert(0, ref_root)
     sys.path.insert(0, PKG)
-    for mod in ("simple_knn._C", "tetranerf.utils.extension"):
+    for mod in ("tetranerf.utils.extension",):
         try:
             importlib.import_module(mod)
         except Exception:

@@ -13,7 +13,7 @@ REF=/root/reference/submodules/diff-gaussian-rasterization
 OUT="$HERE/_ref"
 [ -d "$REF" ] || { echo "build_ref.sh: $REF not present, skipping"; exit 0; }
 mkdir -p "$OUT"
-if [ -f "$OUT/libgof_cudaref.so" ] && [ -f "$OUT/libgof_cudaref_nofma.so" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/ref_capi.cpp" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/build_ref.sh" ]; then
+if [ -f "$OUT/libgof_cudaref.so" ] && [ -f "$OUT/libgof_cudaref_nofma.so" ] && [ -f "$OUT/libgof_knnref_nofma.so" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/ref_capi.cpp" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/build_ref.sh" ] && [ "$OUT/libgof_knnref.so" -nt "$HERE/ref_knn_capi.cpp" ]; then
   echo "oracle/_ref up to date"; exit 0
 fi
 TMP="$(mktemp -d "$OUT/tmp.XXXXXX")"
@@ -37,3 +37,16 @@ build() {   # $1 = suffix, $2... = extra flags
 build "" 
 build "_nofma" -ffp-contract=off
 echo "built $OUT/libgof_cudaref.so and $OUT/libgof_cudaref_nofma.so"
+# the reference's simple-knn (submodules/simple-knn/simple_knn.cu: Morton sort + 1024-point boxes + exact 3-NN), same treatment:
+# compiled where it lies, behind the shim headers, with a one-function C wrapper (ref_knn_capi.cpp)
+KNN=/root/reference/submodules/simple-knn
+if [ -d "$KNN" ]; then
+  sed -e 's/<< *</<<</g' -e 's/>> *>/>>>/g' "$KNN/simple_knn.cu" > "$TMP/simple_knn.cu"
+  for sfx in "" "_nofma"; do
+    fl=(); [ "$sfx" = "_nofma" ] && fl=(-ffp-contract=off)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w "${fl[@]}" -x hip -include cfloat -I "$HERE/ref_shim" -I "$KNN" -c "$TMP/simple_knn.cu" -o "$TMP/simple_knn$sfx.o"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -x hip -I "$HERE/ref_shim" -I "$KNN" -c "$HERE/ref_knn_capi.cpp" -o "$TMP/knn_capi$sfx.o"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgof_knnref$sfx.so" "$TMP/simple_knn$sfx.o" "$TMP/knn_capi$sfx.o"
+  done
+  echo "built $OUT/libgof_knnref.so and $OUT/libgof_knnref_nofma.so"
+fi

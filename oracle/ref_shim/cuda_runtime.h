@@ -7,6 +7,8 @@
 #define cudaMemcpy hipMemcpy
 #define cudaMemcpyDeviceToHost hipMemcpyDeviceToHost
 #define cudaMemset hipMemset
+#define cudaMalloc hipMalloc
+#define cudaFree hipFree
 #define cudaDeviceSynchronize hipDeviceSynchronize
 #define cudaSuccess hipSuccess
 #define cudaGetErrorString hipGetErrorString
