@@ -186,12 +186,17 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE): rocprofv3 cannot run
     # inside this process, so the figure comes from the committed counter pass of the SAME workload (profiles/), or is null
     traffic = None
+    valu_issue_frac = None
     tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_s1m.json")
     if P == 1_000_000 and (W, H) == (1600, 1063) and os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_corrected")
+        pmc = json.load(open(tfile)).get(dom, {})
+        traffic = pmc.get("hbm_bytes_corrected")
+        valu_issue_frac = pmc.get("valu_issue_frac")
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 5), "traffic": traffic,
             "avg_ms": d["avg_ms"], "alg_bytes": alg_bytes.get(dom),
+            # what actually bounds the blend kernels: VALU issue slots (committed PMC pass, profiles/): insts x 4 cycles / (SIMDs x cycles)
+            "valu_issue_frac": None if valu_issue_frac is None else round(valu_issue_frac, 3),
             "note": "dominant kernel by time; the blend kernels are VALU/LDS-bound (SURVEY 8d), the figure is their HBM floor on "
                     "algorithmic bytes; the HBM-bound stages are listed under 'kernels'",
             "kernels": kernels,

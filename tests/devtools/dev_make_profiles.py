@@ -1,10 +1,13 @@
 """Developer script: turn the rocprofv3 outputs merged under gpurun_out/ into the committed summaries in profiles/.
-usage: python tests/devtools/dev_make_profiles.py <tag e.g. v4> <prof dir> <pmc FETCH dir> <pmc WRITE dir> [bench json]"""
+usage: python tests/devtools/dev_make_profiles.py <tag e.g. v4> <prof dir> <pmc FETCH dir> <pmc WRITE dir> [bench json] [pmc VALU dir]
+The optional VALU pass (--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE) adds, per kernel, the VALU issue
+utilisation = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
 import csv, json, os, re, sys, shutil
 from collections import defaultdict
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag, prof, pf, pw = sys.argv[1:5]
 bench = sys.argv[5] if len(sys.argv) > 5 else None
+pv = sys.argv[6] if len(sys.argv) > 6 else None
 
 
 def short(name):
@@ -41,6 +44,18 @@ for k in sorted(set(fetch) | set(write)):
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     traffic[k] = {"fetch_KiB_raw": f, "write_KiB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024}
+valu = {}
+if pv:
+    insts, salu, ldsi, gui = pmc(pv, "SQ_INSTS_VALU"), pmc(pv, "SQ_INSTS_SALU"), pmc(pv, "SQ_INSTS_LDS"), pmc(pv, "GRBM_GUI_ACTIVE")
+    for k in traffic:
+        if k in insts and gui.get(k):
+            cycles = gui[k] / 8.0                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            traffic[k]["valu_insts"] = insts[k]
+            traffic[k]["salu_insts"] = salu.get(k, 0.0)
+            traffic[k]["lds_insts"] = ldsi.get(k, 0.0)
+            traffic[k]["gpu_cycles"] = cycles
+            traffic[k]["valu_issue_frac"] = insts[k] * 4.0 / (1024.0 * cycles)
+            valu[k] = traffic[k]["valu_issue_frac"]
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_s1m.json"), "w"), indent=1)
 with open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % tag), "w") as o:
     o.write("# rocprofv3 summaries, round 1, kernels of commit-state '%s'\n\n" % tag)
@@ -56,6 +71,14 @@ with open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % ta
     o.write("| kernel | FETCH_SIZE KiB (raw) | read MB (x2 corrected) | WRITE_SIZE KiB | write MB |\n|---|---|---|---|---|\n")
     for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
         o.write("| %s | %.0f | %.1f | %.0f | %.1f |\n" % (k, v["fetch_KiB_raw"], 2 * v["fetch_KiB_raw"] * 1024 / 1e6, v["write_KiB"], v["write_KiB"] * 1024 / 1e6))
+    if valu:
+        o.write("\n## VALU issue utilisation (separate `--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE` pass)\n\n"
+                "wave-level VALU instructions x 4 cycles (a wave64 instruction occupies a 16-lane SIMD for 4 cycles; fp64 and transcendental\n"
+                "instructions take longer, so the figure is a lower bound of the VALU busy time) / (1024 SIMDs x kernel cycles).\n\n"
+                "| kernel | VALU insts / launch | SALU | LDS | kernel cycles | VALU issue fraction |\n|---|---|---|---|---|---|\n")
+        for k, f in sorted(valu.items(), key=lambda kv: -traffic[kv[0]]["valu_insts"]):
+            t = traffic[k]
+            o.write("| %s | %.3e | %.2e | %.2e | %.3e | %.2f |\n" % (k, t["valu_insts"], t["salu_insts"], t["lds_insts"], t["gpu_cycles"], f))
 if bench:
     shutil.copy(bench, os.path.join(ROOT, "profiles", "r01_bench_s1m_%s.json" % tag))
 print(open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % tag)).read())

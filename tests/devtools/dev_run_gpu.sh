@@ -1,2 +1,16 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tests/devtools/dev_knn_time.py 2>&1 | tail -3
+mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT
+timeout 600 python bench.py --steps 30 --warmup 5 > gpurun_out/bench5.json 2> gpurun_out/bench5.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof5 -o r5 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-loop > $R/gpurun_out/prof5.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc5_$c -o p -- python $R/tests/devtools/dev_pmc.py > $R/gpurun_out/pmc5_$c.log 2>&1
+done
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc5_valu -o p -- python $R/tests/devtools/dev_pmc.py > $R/gpurun_out/pmc5_valu.log 2>&1
+cd $R; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench5.json'))
+print(d["value"], d["ms_per_step"], d["full_loop"]["ms_per_iter"], d["cpu_baseline"]["value"])
+PY
+ls gpurun_out/pmc5_valu gpurun_out/prof5
