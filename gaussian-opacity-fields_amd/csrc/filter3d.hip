@@ -1,0 +1,131 @@
+// filter3d.hip -- GaussianModel.compute_3D_filter (reference scene/gaussian_model.py:262-311) as two launches instead of
+// ~25 torch kernels + two host-synchronising boolean-mask index ops PER CAMERA.  C ABI in include/gof_train_hip.h.
+//
+//   filter3d_min_depth: thread = point, the camera table streams through LDS in chunks of 128; per camera the arithmetic of
+//                       :279-302 in source order (row-vector product xyz @ R + T, depth test on the UNclamped z, projection with
+//                       the clamped z, 15 % screen margin); running min of the clamped z over the cameras that see the point;
+//                       block-wide max of the seen points' depths -> one ordered-integer atomicMax.
+//   filter3d_finish:    unseen points take that maximum (:304), then / max focal_x * sqrt(0.2) (:308).
+// HBM-bound on 12 B read + 8 B written per point; the camera loop is ~25 flops per (point, camera) out of LDS.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/gof_hip.h"
+#include "../../include/gof_train_hip.h"
+#include "gof_common.h"
+
+namespace gof {
+
+constexpr int F3_CHUNK = 128;
+
+__device__ __forceinline__ uint32_t f3_ordered(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float f3_unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+// state[0] = ordered max depth of the seen points, state[1] = any seen, state[2] = ordered max focal_x
+__global__ void filter3d_init(uint32_t* state)
+{
+    if (threadIdx.x == 0) { state[0] = 0u; state[1] = 0u; state[2] = f3_ordered(0.0f); }
+}
+
+__global__ void __launch_bounds__(256)
+filter3d_min_depth(int64_t P, const float* __restrict__ xyz, int num_cams, const float* __restrict__ cams,
+                   float* __restrict__ distance, uint8_t* __restrict__ seen, uint32_t* __restrict__ state)
+{
+    __shared__ float s_cam[F3_CHUNK][GOF_FILTER_CAM_FLOATS];
+    __shared__ float s_red[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < P;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (live) { px = xyz[3 * i]; py = xyz[3 * i + 1]; pz = xyz[3 * i + 2]; }
+    float dist = 100000.0f;                                   // :267
+    bool any = false;
+    float fmax_ = 0.0f;                                       // :271
+    for (int c0 = 0; c0 < num_cams; c0 += F3_CHUNK) {
+        const int cn = min(F3_CHUNK, num_cams - c0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cn * GOF_FILTER_CAM_FLOATS; k += 256)
+            (&s_cam[0][0])[k] = cams[(size_t)c0 * GOF_FILTER_CAM_FLOATS + k];
+        __syncthreads();
+        for (int c = 0; c < cn; c++) {
+            const float* m = s_cam[c];
+            // xyz @ R + T (:278): out_j = x R0j + y R1j + z R2j
+            const float cx = px * m[0] + py * m[3] + pz * m[6] + m[9];
+            const float cy = px * m[1] + py * m[4] + pz * m[7] + m[10];
+            const float cz = px * m[2] + py * m[5] + pz * m[8] + m[11];
+            const bool valid_depth = cz > 0.2f;               // :283
+            const float z = fmaxf(cz, 0.001f);                // :287
+            const float fx = m[12], fy = m[13], w = m[14], h = m[15];
+            const float sx = cx / z * fx + w / 2.0f;          // :289-290
+            const float sy = cy / z * fy + h / 2.0f;
+            const bool in_screen = (sx >= -0.15f * w) & (sx <= w * 1.15f) & (sy >= -0.15f * h) & (sy <= 1.15f * h);   // :295
+            if (valid_depth & in_screen) { dist = fminf(dist, z); any = true; }     // :298-302
+            fmax_ = fmaxf(fmax_, fx);                         // :303-304
+        }
+    }
+    if (live) { distance[i] = dist; seen[i] = any ? 1 : 0; }
+    // max depth over the seen points of the block -> global
+    float v = (live && any) ? dist : -3.0e38f;
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    const bool block_any = __syncthreads_or(live && any);
+    if (threadIdx.x == 0) {
+        if (block_any) {
+            atomicMax(&state[0], f3_ordered(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))));
+            atomicOr(&state[1], 1u);
+        }
+        if (blockIdx.x == 0) state[2] = f3_ordered(fmax_);   // identical in every thread
+    }
+}
+
+__global__ void __launch_bounds__(256)
+filter3d_finish(int64_t P, const float* __restrict__ distance, const uint8_t* __restrict__ seen, const uint32_t* __restrict__ state,
+                float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float dmax = f3_unordered(state[0]);
+    const float focal = f3_unordered(state[2]);
+    const float d = seen[i] ? distance[i] : dmax;             // :306
+    out[i] = d / focal * (float)0.4472135954999579;           // :310: distance / focal_length * (0.2 ** 0.5)
+}
+
+} // namespace gof
+
+using namespace gof;
+
+extern "C" {
+
+size_t gof_filter3d_ws_bytes(int64_t P)
+{
+    const size_t n = (size_t)(P < 1 ? 1 : P);
+    return 256 + ((n * 4 + 255) & ~(size_t)255) + ((n + 255) & ~(size_t)255) + 256;
+}
+
+int gof_compute_3d_filter(int64_t P, const float* xyz, int32_t num_cams, const float* cameras, float* filter_3D, void* ws, size_t ws_bytes,
+                          int32_t* any_valid_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (any_valid_host) *any_valid_host = 0;
+    if (P < 0 || num_cams < 0) { set_error("bad sizes (%lld points, %d cameras)", (long long)P, num_cams); return GOF_E_INVALID; }
+    if (P == 0) return GOF_OK;
+    if (!xyz || !filter_3D || !ws || (num_cams > 0 && !cameras)) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    if (ws_bytes < gof_filter3d_ws_bytes(P)) { set_error("filter workspace too small"); return GOF_E_WORKSPACE; }
+    char* base = reinterpret_cast<char*>((reinterpret_cast<size_t>(ws) + 255) & ~(size_t)255);
+    uint32_t* state = reinterpret_cast<uint32_t*>(base);
+    float* distance = reinterpret_cast<float*>(base + 256);
+    uint8_t* seen = reinterpret_cast<uint8_t*>(base + 256 + (((size_t)P * 4 + 255) & ~(size_t)255));
+    const unsigned blocks = (unsigned)((P + 255) / 256);
+    { GOF_PROFILE("compute_3d_filter", stream);
+      hipLaunchKernelGGL(filter3d_init, dim3(1), dim3(64), 0, stream, state);
+      hipLaunchKernelGGL(filter3d_min_depth, dim3(blocks), dim3(256), 0, stream, P, xyz, (int)num_cams, cameras, distance, seen, state);
+      hipLaunchKernelGGL(filter3d_finish, dim3(blocks), dim3(256), 0, stream, P, distance, seen, state, filter_3D);
+      GOF_LAUNCH_CHECK(stream, 0); }
+    if (any_valid_host) {
+        uint32_t flag = 0;
+        GOF_HIP_CHECK(hipMemcpyAsync(&flag, state + 1, sizeof(flag), hipMemcpyDeviceToHost, stream));
+        GOF_HIP_CHECK(hipStreamSynchronize(stream));
+        *any_valid_host = (int32_t)flag;
+    }
+    return GOF_OK;
+}
+
+} // extern "C"

@@ -14,7 +14,8 @@ What it does, in this order (nothing in the reference checkout is edited):
      (extract_mesh.py:14: `from utils.tetmesh import marching_tetrahedra`);
   4. rebinds the per-iteration training epilogue to its HIP implementation (train_epilogue/, include/gof_train_hip.h):
      utils.loss_utils.ssim (train.py:20), utils.depth_utils.depth_to_normal / depths_to_points (train.py:38) and the
-     optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups).
+     optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups) and
+     GaussianModel.compute_3D_filter (scene/gaussian_model.py:262-311, one launch over points x cameras).
      GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations;
   5. wraps gaussian_renderer.integrate (imported by name at extract_mesh.py:5) so that the Gaussian side of the opacity-field
      query (binning + pixel pass) runs once per view for the ~10 point sets extract_mesh.py queries against the unchanged model
@@ -60,6 +61,7 @@ def rebind_train_epilogue():
         for hook in getattr(old, "_optimizer_step_post_hooks", {}).values():
             self.optimizer.register_step_post_hook(hook)
     GaussianModel.training_setup = training_setup
+    GaussianModel.compute_3D_filter = T.compute_3D_filter      # train.py:118,261,269: after every densification
 
 
 def rebind_integrate_with_view_cache():

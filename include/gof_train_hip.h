@@ -75,6 +75,20 @@ typedef struct GofAdamTensor {
 int gof_adam_step(int32_t n_tensors, const GofAdamTensor* tensors_host,
                   double beta1, double beta2, double eps, void* stream);
 
+/* ---- 3D smoothing filter (scene/gaussian_model.py:262-311, GaussianModel.compute_3D_filter) ------
+ * For every Gaussian centre: the smallest camera-space depth over all training cameras that see it (depth > 0.2 and inside the
+ * image enlarged by 15 % per side), divided by the largest focal length and scaled by sqrt(0.2); centres no camera sees get the
+ * largest such depth.  The reference runs ~25 torch kernels and two boolean-mask index ops (host syncs) PER CAMERA, after every
+ * densification (train.py:118,261,269); here: one launch over (points x all cameras) + one finishing launch.
+ * cameras: [num_cams][GOF_FILTER_CAM_FLOATS] fp32 in DEVICE memory: R (9, row-major, used as xyz @ R exactly like the reference's
+ * `xyz @ R`), T (3), focal_x, focal_y, image_width, image_height.
+ * any_valid_host (host, nullable): receives 1 if at least one point is seen by a camera, else 0 (the reference raises on the
+ * empty `distance[valid_points].max()`); when non-NULL the call SYNCHRONISES `stream`. */
+#define GOF_FILTER_CAM_FLOATS 16
+size_t gof_filter3d_ws_bytes(int64_t num_points);
+int gof_compute_3d_filter(int64_t num_points, const float* xyz, int32_t num_cams, const float* cameras,
+                          float* filter_3D /* [num_points] */, void* ws, size_t ws_bytes, int32_t* any_valid_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,34 @@ def depth_to_normal(world_view_transform, W, H, FoVx, FoVy, depth, dtype=torch.f
     return output, points
 
 
+# ---- scene/gaussian_model.py: compute_3D_filter ------------------------------------------------------------
+def compute_3d_filter(xyz, cameras):
+    """GaussianModel.compute_3D_filter (gaussian_model.py:262-311) on CPU tensors; cameras: objects with R, T (numpy), focal_x,
+    focal_y, image_width, image_height.  Returns filter_3D (P,1)."""
+    distance = torch.ones((xyz.shape[0])) * 100000.0                                      # :267
+    valid_points = torch.zeros((xyz.shape[0]), dtype=torch.bool)                          # :268
+    focal_length = 0.                                                                     # :271
+    for camera in cameras:
+        R = torch.tensor(camera.R, dtype=torch.float32)                                   # :275-276
+        T = torch.tensor(camera.T, dtype=torch.float32)
+        xyz_cam = xyz @ R + T[None, :]                                                    # :278
+        valid_depth = xyz_cam[:, 2] > 0.2                                                 # :283
+        x, y, z = xyz_cam[:, 0], xyz_cam[:, 1], xyz_cam[:, 2]
+        z = torch.clamp(z, min=0.001)                                                     # :287
+        x = x / z * camera.focal_x + camera.image_width / 2.0                             # :289-290
+        y = y / z * camera.focal_y + camera.image_height / 2.0
+        in_screen = torch.logical_and(torch.logical_and(x >= -0.15 * camera.image_width, x <= camera.image_width * 1.15),
+                                      torch.logical_and(y >= -0.15 * camera.image_height, y <= 1.15 * camera.image_height))   # :295
+        valid = torch.logical_and(valid_depth, in_screen)                                 # :298
+        distance[valid] = torch.min(distance[valid], z[valid])                            # :301
+        valid_points = torch.logical_or(valid_points, valid)                              # :302
+        if focal_length < camera.focal_x:                                                 # :303-304
+            focal_length = camera.focal_x
+    distance[~valid_points] = distance[valid_points].max()                                # :306
+    filter_3D = distance / focal_length * (0.2 ** 0.5)                                    # :310
+    return filter_3D[..., None]
+
+
 # ---- torch/optim/adam.py (the optimizer scene/gaussian_model.py:360 builds) ----------------------------
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-15):
     """One step of torch.optim.Adam (no weight decay, no amsgrad) in fp32 numpy, operation order of

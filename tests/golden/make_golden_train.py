@@ -104,6 +104,33 @@ for step in range(3):
 out["adam_m3"] = np.concatenate([opt.state[p]["exp_avg"].numpy() for p in ps])
 out["adam_v3"] = np.concatenate([opt.state[p]["exp_avg_sq"].numpy() for p in ps])
 
+# ---- GaussianModel.compute_3D_filter (scene/gaussian_model.py:262-311), the reference's own method, run on CPU tensors ----
+for name in ("plyfile", "trimesh", "simple_knn", "simple_knn._C", "open3d", "cv2"):
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules["plyfile"].PlyData = object
+sys.modules["plyfile"].PlyElement = object
+sys.modules["simple_knn._C"].distCUDA2 = lambda *a, **k: None
+from scene.gaussian_model import GaussianModel                   # noqa: E402
+
+rng = np.random.default_rng(77)
+P3 = 4000
+xyz3 = rng.uniform(-1.5, 1.5, (P3, 3)).astype(np.float32)
+xyz3[-60:] *= 300.0                                # far-away centres: most of them are seen by no camera (gaussian_model.py:306)
+xyz3 = torch.from_numpy(xyz3)
+cams3 = []
+for i in range(7):
+    M = rigid(100 + i).T.numpy()                   # world-to-camera [R|t]
+    Rw2c, t = M[:3, :3].astype(np.float64), M[:3, 3].astype(np.float64)
+    t = t * 0.3 + np.array([0, 0, 3.0])            # keep most of the cloud in front of the camera
+    W3, H3 = (640, 480) if i % 2 else (800, 528)
+    cams3.append(types.SimpleNamespace(R=Rw2c.T.copy(), T=t.copy(), focal_x=500.0 + 40 * i, focal_y=480.0 + 35 * i, image_width=W3, image_height=H3))
+fake = types.SimpleNamespace(get_xyz=xyz3)
+GaussianModel.compute_3D_filter(fake, cams3)
+out["f3d_xyz"] = xyz3.numpy()
+out["f3d_cams"] = np.stack([np.concatenate([c.R.reshape(9), c.T.reshape(3), [c.focal_x, c.focal_y, c.image_width, c.image_height]]) for c in cams3])
+out["f3d_filter"] = fake.filter_3D.numpy()
+
 path = os.path.join(HERE, "ref_train_epilogue_golden.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -174,6 +174,65 @@ def test_train_loss_composition_matches_oracle():
             _close(gp[c].cpu().numpy(), go[c].numpy(), 1e-4, "d loss / d rendering[%d]" % c)
 
 
+# ---- compute_3D_filter ---------------------------------------------------------------------------------------
+def _cams_from_table(tab):
+    return [types.SimpleNamespace(R=r[0:9].reshape(3, 3), T=r[9:12], focal_x=float(r[12]), focal_y=float(r[13]),
+                                  image_width=int(r[14]), image_height=int(r[15])) for r in np.asarray(tab, dtype=np.float64)]
+
+
+def _filter_close(got, ref, what):
+    """The matmul `xyz @ R` may be evaluated with another fp32 association than the kernel's source-order sums, so a point
+    sitting exactly on a threshold (depth 0.2, screen margin) can flip for one camera: allow 1e-4 of the points to differ,
+    the rest must agree to 2e-6 relative."""
+    got, ref = np.asarray(got).ravel(), np.asarray(ref).ravel()
+    bad = np.abs(got - ref) > 2e-6 * np.abs(ref)
+    assert bad.mean() <= 1e-4, "%s: %d of %d points differ" % (what, bad.sum(), bad.size)
+
+
+def test_compute_3d_filter_matches_reference_golden_and_method_rebinding():
+    import train_epilogue as T
+    cams = _cams_from_table(G["f3d_cams"])
+    xyz = torch.from_numpy(G["f3d_xyz"]).to(DEV)
+    model = types.SimpleNamespace(get_xyz=xyz)
+    T.compute_3D_filter(model, cams)                         # the method replacement of GaussianModel.compute_3D_filter
+    assert model.filter_3D.shape == (xyz.shape[0], 1)
+    _filter_close(model.filter_3D.cpu().numpy(), G["f3d_filter"], "golden")
+    tab1 = model._gof_cam_table[1]
+    T.compute_3D_filter(model, cams)                         # same camera list -> the device table is reused
+    assert model._gof_cam_table[1] is tab1
+
+
+@pytest.mark.parametrize("P,ncam", [(1, 1), (1000, 3), (300_000, 40), (1_000_000, 24)])
+def test_compute_3d_filter_matches_oracle(P, ncam):
+    import train_epilogue as T
+    rng = np.random.default_rng(P + ncam)
+    xyz = rng.uniform(-2.0, 2.0, (P, 3)).astype(np.float32)
+    if P == 1:
+        xyz[:] = 0.0
+    cams = []
+    for i in range(ncam):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        cams.append(types.SimpleNamespace(R=R, T=np.array([0.0, 0.0, 4.0]) + rng.normal(0, 0.2, 3), focal_x=float(rng.uniform(400, 1300)),
+                                          focal_y=float(rng.uniform(400, 1300)), image_width=int(rng.integers(300, 1700)), image_height=int(rng.integers(300, 1100))))
+    got = T.filter_3d(torch.from_numpy(xyz).to(DEV), T.camera_table(cams, DEV)).cpu().numpy()
+    ref = O.compute_3d_filter(torch.from_numpy(xyz), cams).numpy()
+    _filter_close(got, ref, "P=%d cams=%d" % (P, ncam))
+
+
+def test_compute_3d_filter_raises_like_the_reference_when_nothing_is_seen():
+    import train_epilogue as T
+    cam = types.SimpleNamespace(R=np.eye(3), T=np.array([0.0, 0.0, -10.0]), focal_x=500.0, focal_y=500.0, image_width=640, image_height=480)
+    xyz = torch.zeros((10, 3), device=DEV)
+    with pytest.raises(RuntimeError):
+        T.filter_3d(xyz, T.camera_table([cam], DEV))
+    with pytest.raises(RuntimeError):
+        O.compute_3d_filter(xyz.cpu(), [cam])                # the reference's own failure mode (max of an empty tensor)
+
+
 # ---- FusedAdam ---------------------------------------------------------------------------------------------
 GROUPS = [("xyz", (3,), 1.6e-4), ("f_dc", (1, 3), 2.5e-3), ("f_rest", (15, 3), 1.25e-4), ("opacity", (1,), 5e-2),
           ("scaling", (3,), 5e-3), ("rotation", (4,), 1e-3)]          # scene/gaussian_model.py:349-358, arguments/__init__.py

@@ -67,6 +67,20 @@ def test_adam_oracle_matches_torch_adam():
     np.testing.assert_allclose(v, G["adam_v3"], rtol=2e-6, atol=1e-20)
 
 
+def _cams_from_table(tab):
+    return [types.SimpleNamespace(R=r[0:9].reshape(3, 3), T=r[9:12], focal_x=float(r[12]), focal_y=float(r[13]),
+                                  image_width=int(r[14]), image_height=int(r[15])) for r in np.asarray(tab, dtype=np.float64)]
+
+
+def test_compute_3d_filter_oracle_matches_reference_python():
+    """GaussianModel.compute_3D_filter executed by the reference itself (golden) vs the restatement: same torch ops -> bit-equal."""
+    got = O.compute_3d_filter(torch.from_numpy(G["f3d_xyz"]), _cams_from_table(G["f3d_cams"]))
+    assert got.shape == G["f3d_filter"].shape
+    np.testing.assert_array_equal(got.numpy(), G["f3d_filter"])
+    assert len(np.unique(G["f3d_filter"])) > 1000           # a non-trivial field, and unseen points exist in the fixture:
+    assert (G["f3d_filter"] == G["f3d_filter"].max()).sum() > 1
+
+
 # ---- host-side behaviour of the product mirrors (no kernel is launched) ---------------------------------
 def test_mirrors_fail_loudly_without_a_device_and_on_bad_arguments():
     import train_epilogue as T
