@@ -88,6 +88,22 @@ filter3d_finish(int64_t P, const float* __restrict__ distance, const uint8_t* __
     out[i] = d / focal * (float)0.4472135954999579;           // :310: distance / focal_length * (0.2 ** 0.5)
 }
 
+// GaussianModel.add_densification_stats (gaussian_model.py:709-714)
+__global__ void __launch_bounds__(256)
+densification_stats_kernel(int64_t P, const float* __restrict__ grad, const uint8_t* __restrict__ filter, float* __restrict__ accum,
+                           float* __restrict__ accum_abs, float* __restrict__ accum_abs_max, float* __restrict__ denom)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || !filter[i]) return;
+    const float gx = grad[3 * i], gy = grad[3 * i + 1], gz = grad[3 * i + 2];
+    const float n2 = sqrtf(gx * gx + gy * gy);      // torch.norm(grad[filter, :2], dim=-1)
+    const float n1 = sqrtf(gz * gz);                // torch.norm(grad[filter, 2:], dim=-1): sqrt(x^2), not |x| (underflows like torch)
+    accum[i] += n2;
+    accum_abs[i] += n1;
+    accum_abs_max[i] = fmaxf(accum_abs_max[i], n1);
+    denom[i] += 1.0f;
+}
+
 } // namespace gof
 
 using namespace gof;
@@ -125,6 +141,20 @@ int gof_compute_3d_filter(int64_t P, const float* xyz, int32_t num_cams, const f
         GOF_HIP_CHECK(hipStreamSynchronize(stream));
         *any_valid_host = (int32_t)flag;
     }
+    return GOF_OK;
+}
+
+int gof_add_densification_stats(int64_t P, const float* viewspace_grad, const uint8_t* update_filter, float* accum, float* accum_abs,
+                                float* accum_abs_max, float* denom, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0) { set_error("bad number of points"); return GOF_E_INVALID; }
+    if (P == 0) return GOF_OK;
+    if (!viewspace_grad || !update_filter || !accum || !accum_abs || !accum_abs_max || !denom) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    GOF_PROFILE("add_densification_stats", stream);
+    hipLaunchKernelGGL(densification_stats_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P, viewspace_grad, update_filter,
+                       accum, accum_abs, accum_abs_max, denom);
+    GOF_LAUNCH_CHECK(stream, 0);
     return GOF_OK;
 }
 

@@ -62,6 +62,7 @@ def rebind_train_epilogue():
             self.optimizer.register_step_post_hook(hook)
     GaussianModel.training_setup = training_setup
     GaussianModel.compute_3D_filter = T.compute_3D_filter      # train.py:118,261,269: after every densification
+    GaussianModel.add_densification_stats = T.add_densification_stats   # train.py:256: every iteration until densify_until_iter
 
 
 def rebind_integrate_with_view_cache():

@@ -10,8 +10,8 @@ Injection points; NEW behaviour, the reference has no multi-GPU
   * train.py:135-137 camera sampling   -> Scene.getTrainCameras returns this rank's shard cams[rank::world]
   * gaussian_model.py:342-364          -> training_setup registers an optimizer step pre-hook that all-reduces
                                           the parameter gradients (the optimizer object survives densification)
-  * gaussian_model.py:709-714          -> add_densification_stats all-reduces its per-step increments
-                                          (SUM for the accumulators / denom, MAX for max_radii2D is done in the hook)
+  * gaussian_model.py:685-707          -> densify_and_prune first all-reduces the statistics accumulated since the last
+                                          densification (SUM for the accumulators / denom, MAX for max_radii2D / abs-max)
   * train.py:247-250,276-301           -> only rank 0 writes point clouds / checkpoints / TensorBoard
 Identical seeds on every rank (train.py:367-369) keep densify_and_split's sampling identical.
 """
@@ -52,15 +52,23 @@ def main():
 
     def training_setup(self, training_args):
         _setup(self, training_args)
-        model = self
 
         def pre_step(optimizer, args, kwargs):
             params = [p for g in optimizer.param_groups for p in g["params"]]
             GradientAllReducer(params).all_reduce()
-            all_reduce_densification_stats(model.xyz_gradient_accum, model.xyz_gradient_accum_abs, model.denom,
-                                           model.max_radii2D, getattr(model, "xyz_gradient_accum_abs_max", None))
         self.optimizer.register_step_pre_hook(pre_step)
     GaussianModel.training_setup = training_setup
+
+    # Densification statistics are accumulated per rank (each rank sees other views) and zeroed by every densification
+    # (densification_postfix, gaussian_model.py:609-629).  Reducing the running totals ONCE, right before they are consumed,
+    # gives every rank the statistics of all views since the last densification -> identical densify / prune decisions.
+    _densify = GaussianModel.densify_and_prune
+
+    def densify_and_prune(self, *a, **k):
+        all_reduce_densification_stats(self.xyz_gradient_accum, self.xyz_gradient_accum_abs, self.denom,
+                                       self.max_radii2D, getattr(self, "xyz_gradient_accum_abs_max", None))
+        return _densify(self, *a, **k)
+    GaussianModel.densify_and_prune = densify_and_prune
 
     if rank != 0:      # only rank 0 writes
         ref_scene.Scene.save = lambda self, iteration: None

@@ -60,3 +60,29 @@ def compute_3D_filter(self, cameras):
         cached = (key, camera_table(cams, xyz.device))
         self._gof_cam_table = cached
     self.filter_3D = filter_3d(xyz.detach(), cached[1])
+
+
+lib.gof_add_densification_stats.restype = C.c_int
+lib.gof_add_densification_stats.argtypes = [C.c_int64] + [C.c_void_p] * 7
+
+
+@torch.no_grad()
+def add_densification_stats(self, viewspace_point_tensor, update_filter):
+    """Method replacement for GaussianModel.add_densification_stats (scene/gaussian_model.py:709-714): one launch instead of four
+    boolean-mask read-modify-writes (each with a host sync).  The accumulators are updated in place."""
+    grad = viewspace_point_tensor.grad
+    if grad is None:
+        raise AttributeError("'NoneType' object is not subscriptable (viewspace_point_tensor has no gradient)")
+    n = int(grad.shape[0])
+    g = B._need_cuda_f32(grad, "viewspace_point_tensor.grad")
+    if update_filter.dtype != torch.bool or update_filter.shape[0] != n:
+        raise IndexError("add_densification_stats: update_filter must be a bool mask over the %d Gaussians" % n)
+    f = update_filter.contiguous().view(torch.uint8)
+    bufs = []
+    for name in ("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom"):
+        t = getattr(self, name)
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or t.device != g.device:
+            raise RuntimeError("add_densification_stats: %s must be a contiguous float32 (%d,1) tensor on %s" % (name, n, g.device))
+        bufs.append(t)
+    with torch.cuda.device(g.device):
+        B._check(lib.gof_add_densification_stats(n, g.data_ptr(), f.data_ptr(), *[t.data_ptr() for t in bufs], B._stream()))

@@ -89,6 +89,16 @@ size_t gof_filter3d_ws_bytes(int64_t num_points);
 int gof_compute_3d_filter(int64_t num_points, const float* xyz, int32_t num_cams, const float* cameras,
                           float* filter_3D /* [num_points] */, void* ws, size_t ws_bytes, int32_t* any_valid_host, void* stream);
 
+/* ---- densification statistics (scene/gaussian_model.py:709-714, GaussianModel.add_densification_stats) -------------------
+ * For every Gaussian i with update_filter[i] != 0:  n2 = ||grad[i,0:2]||, n1 = ||grad[i,2:3]|| (torch.norm: sqrt of the sum of
+ * squares, also for the single element);  accum[i] += n2;  accum_abs[i] += n1;  accum_abs_max[i] = max(accum_abs_max[i], n1);
+ * denom[i] += 1.  The reference does this with four boolean-mask read-modify-writes (each a nonzero + gather + scatter and a
+ * host sync) every iteration of the densification phase; here one launch.  grad is the [P,3] gradient of the screen-space
+ * points (x, y signed, z = sum of |.|, rasterizer backward); update_filter is a [P] byte/bool mask. */
+int gof_add_densification_stats(int64_t num_points, const float* viewspace_grad, const uint8_t* update_filter,
+                                float* xyz_gradient_accum, float* xyz_gradient_accum_abs, float* xyz_gradient_accum_abs_max,
+                                float* denom, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

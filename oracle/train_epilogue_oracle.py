@@ -98,6 +98,14 @@ def compute_3d_filter(xyz, cameras):
     return filter_3D[..., None]
 
 
+def add_densification_stats(accum, accum_abs, accum_abs_max, denom, grad, update_filter):
+    """GaussianModel.add_densification_stats (gaussian_model.py:709-714) on CPU tensors, in place."""
+    accum[update_filter] += torch.norm(grad[update_filter, :2], dim=-1, keepdim=True)                       # :710
+    accum_abs[update_filter] += torch.norm(grad[update_filter, 2:], dim=-1, keepdim=True)                    # :712
+    accum_abs_max[update_filter] = torch.max(accum_abs_max[update_filter], torch.norm(grad[update_filter, 2:], dim=-1, keepdim=True))   # :713
+    denom[update_filter] += 1                                                                                # :714
+
+
 # ---- torch/optim/adam.py (the optimizer scene/gaussian_model.py:360 builds) ----------------------------
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-15):
     """One step of torch.optim.Adam (no weight decay, no amsgrad) in fp32 numpy, operation order of

@@ -233,6 +233,40 @@ def test_compute_3d_filter_raises_like_the_reference_when_nothing_is_seen():
         O.compute_3d_filter(xyz.cpu(), [cam])                # the reference's own failure mode (max of an empty tensor)
 
 
+def test_add_densification_stats_matches_oracle_over_several_iterations():
+    import train_epilogue as T
+    P = 100_003
+    g = torch.Generator().manual_seed(12)
+    st = [torch.zeros((P, 1)) for _ in range(4)]
+    model = types.SimpleNamespace(xyz_gradient_accum=st[0].clone().to(DEV), xyz_gradient_accum_abs=st[1].clone().to(DEV),
+                                  xyz_gradient_accum_abs_max=st[2].clone().to(DEV), denom=st[3].clone().to(DEV))
+    for it in range(4):
+        grad = torch.randn((P, 3), generator=g) * (10.0 ** (-it * 3))          # down to 1e-9 (squares stay normal fp32 numbers)
+        grad[:, 2] = grad[:, 2].abs()
+        filt = torch.rand(P, generator=g) < 0.6
+        O.add_densification_stats(st[0], st[1], st[2], st[3], grad, filt)
+        vp = types.SimpleNamespace(grad=grad.to(DEV))
+        T.add_densification_stats(model, vp, filt.to(DEV))
+    for name, ref in zip(("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom"), st):
+        got = getattr(model, name).cpu()
+        # torch on the CPU accumulates the squares in double (acc_type), on the GPU -- like the kernel -- in fp32: a few ulp
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-30), name
+    assert torch.equal(model.denom.cpu(), st[3])
+    # against torch on THIS GPU (fp32 accumulation, what the reference executes): identical
+    st_gpu = [torch.zeros((P, 1), device=DEV) for _ in range(4)]
+    m2 = types.SimpleNamespace(xyz_gradient_accum=st_gpu[0].clone(), xyz_gradient_accum_abs=st_gpu[1].clone(), xyz_gradient_accum_abs_max=st_gpu[2].clone(), denom=st_gpu[3].clone())
+    g2 = torch.Generator().manual_seed(13)
+    for it in range(3):
+        grad = (torch.randn((P, 3), generator=g2) * (10.0 ** (-it * 3))).to(DEV)
+        filt = (torch.rand(P, generator=g2) < 0.5).to(DEV)
+        O.add_densification_stats(st_gpu[0], st_gpu[1], st_gpu[2], st_gpu[3], grad, filt)
+        T.add_densification_stats(m2, types.SimpleNamespace(grad=grad), filt)
+    for name, ref in zip(("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom"), st_gpu):
+        assert torch.equal(getattr(m2, name), ref), name
+    with pytest.raises(IndexError):
+        T.add_densification_stats(model, vp, torch.ones(P, device=DEV))       # not a bool mask
+
+
 # ---- FusedAdam ---------------------------------------------------------------------------------------------
 GROUPS = [("xyz", (3,), 1.6e-4), ("f_dc", (1, 3), 2.5e-3), ("f_rest", (15, 3), 1.25e-4), ("opacity", (1,), 5e-2),
           ("scaling", (3,), 5e-3), ("rotation", (4,), 1e-3)]          # scene/gaussian_model.py:349-358, arguments/__init__.py
