@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_train_epilogue_gpu.py -m gpu -q -k "densification or 3d_filter" 2>&1 | tail -1
+timeout 1200 python -m pytest tests/test_parity_gpu.py -m gpu -q -k "no_visible" 2>&1 | grep -E "passed|failed|^E  " | cut -c1-250 | head
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

@@ -276,6 +276,28 @@ def test_integrate_bit_exact_on_scene(name):
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
 
 
+def test_integrate_with_no_visible_gaussian_and_with_no_point_in_view():
+    """Degenerate inputs of the opacity-field query: every Gaussian culled (behind the camera) -> points inside the image get
+    alpha 0 and the background colour, points outside keep the initial 1; and a point set entirely outside the image."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = S.scene_frustum(500, W=64, H=48, focal=50.0, seed=21)
+    pts_in = S.tetra_points(sc)[:2000].astype(np.float32)
+    sc_behind = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    sc_behind["means3D"][:, 2] = -np.abs(sc_behind["means3D"][:, 2]) - 1.0
+    for scene, pts in ((sc_behind, pts_in), (sc, (pts_in * np.array([[1, 1, -1]], np.float32)).astype(np.float32))):
+        o = ob.OracleScene(scene)
+        oc, oal, ocol, orad = o.integrate(pts)
+        sd = to_dev(scene)
+        r = GaussianRasterizer(settings_from(sd))
+        color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
+                                                opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+        assert np.array_equal(radii.cpu().numpy(), orad)
+        assert np.array_equal(bits(color.cpu().numpy()), bits(oc))
+        assert np.array_equal(bits(alpha.cpu().numpy()), bits(oal))
+        assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
+    assert (orad > 0).any() and (oal == 1.0).all()          # second case: visible Gaussians, no point in front of the camera
+
+
 def test_integrate_view_cache_reuses_the_gaussian_side_bit_exactly():
     """Mesh-extraction driver fusion: under an announced view key the binning + pixel pass runs once; later
     point sets reuse it.  Outputs must be bit-identical to uncached calls, a new key (changed Gaussians) must recompute."""
