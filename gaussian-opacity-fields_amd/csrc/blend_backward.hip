@@ -221,7 +221,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     const float wgt = c.z;
                     PairEval p;
                     pair_prelude(v, rx, ry, p);
-                    pair_exact(v, wgt, p);                          // same arithmetic as the forward: alpha, G, t are bit-identical
+                    pair_exact_backward(v, wgt, p);                 // alpha, G, t, q to ~5e-7 of the forward's values (no decision depends on them here)
                     // Everything below is gradient arithmetic held to a tolerance (the reference rounds every term to fp32 before its
                     // atomicAdd and accumulates in arbitrary order), not to bit-identity: let the compiler contract mul+add into FMA
                     // here.  alpha, G, t, q above keep the forward's exact (uncontracted) arithmetic -- they are ill-conditioned.

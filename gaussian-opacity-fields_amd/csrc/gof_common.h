@@ -333,6 +333,9 @@ __device__ __forceinline__ float cull_log_threshold(float w)
     return (w > 0.0f) ? -__logf(255.0f * w) - 1e-3f : __builtin_huge_valf();
 }
 // exact remainder (after pair_prelude): t, min_value, power, exp, alpha
+// HW_EXP: exp through v_exp_f32 (<= 1 ulp) instead of the shared deterministic gexpf -- only where alpha is NOT compared with a
+// threshold (the backward: its contributors come from the forward's masks), never in the forward / integrate.
+template <bool HW_EXP = false>
 __device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w, PairEval& p)
 {
     const double AA = (double)p.AAf, BB = (double)p.BBf;
@@ -345,9 +348,31 @@ __device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w,
     const double min_value = (-q) * (BB * 0.25) + (double)v[9];
     float power = (float)(-0.5 * min_value);
     if (power > 0.0f) power = 0.0f;
-    p.G = gexpf(power);
+    p.G = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gexpf(power);
     p.alpha = fminf(0.99f, w * p.G);
     if (p.alpha < 1.0f / 255.0f) p.skip = true;
+}
+// The same quantities for the BACKWARD (no threshold decision depends on them there): the quotient BB/AA as an fp32 hi + lo
+// pair (reciprocal + FMA remainders), the product with BB/4 with its FMA error term, and the cancelling difference CC - product
+// taken hi first (exact by Sterbenz for the pairs that matter: min_value << CC).  min_value carries ~1e-6 absolute error -- the
+// fp64 path's value to ~5e-7 relative in G -- for 13 fp32 instructions instead of ~23 fp64 ones (incl. a quarter-rate division).
+__device__ __forceinline__ void pair_exact_backward(const float* __restrict__ v, float w, PairEval& p)
+{
+    const float ra = __builtin_amdgcn_rcpf(p.AAf);
+    float qh = p.BBf * ra;
+    qh = fmaf(fmaf(-qh, p.AAf, p.BBf), ra, qh);                 // refined quotient (within 1 ulp)
+    const float ql = fmaf(-qh, p.AAf, p.BBf) * ra;               // its remainder: qh + ql = BB/AA to ~2^-45
+    const float b4 = p.BBf * 0.25f;
+    const float ph = qh * b4;
+    const float pl = fmaf(ql, b4, fmaf(qh, b4, -ph));            // (qh + ql) * b4 = ph + pl
+    const float min_value = (v[9] - ph) - pl;
+    p.q = (double)qh;
+    p.t = -0.5f * qh;
+    float power = -0.5f * min_value;
+    if (power > 0.0f) power = 0.0f;
+    p.G = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
+    p.alpha = fminf(0.99f, w * p.G);
+    p.skip = false;
 }
 __device__ __forceinline__ void eval_pair(const float* __restrict__ v, float w, float rx, float ry, PairEval& p)
 {
