@@ -164,8 +164,8 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         "emit_instances": 24 * P + 8 * R,
         "sort_instances_by_tile": tile_passes * (16 * R + 4 * R),     # per pass: 8 B read + 8 B written, + histogram read
         "tile_ranges": 8 * R + 8 * gx * gy,
-        "blend_forward": 72 * r_visited_fwd + 60 * N,
-        "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,
+        "blend_forward": (72 + 32) * r_visited_fwd + 60 * N,            # records + footprint boxes read, contributor masks written, image state
+        "blend_backward": (72 + 32) * r_staged_bwd + 96 * N + 76 * p_visible,   # records + conics + masks read, pixel state/grads, accumulators
         "preprocess_bwd": p_visible * (316 + 232),
         "backward_memsets": 4 * P * (3 + 3 + 1 + 3 + 6 + 48 + 3 + 4 + 10),
     }
