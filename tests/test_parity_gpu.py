@@ -276,6 +276,23 @@ def test_integrate_bit_exact_on_scene(name):
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
 
 
+def test_parameter_gradients_share_one_allocation_for_the_dp_reducer():
+    """The backward carves the gradients of (means3D, sh, opacity, scales, rotations) from ONE buffer in that order; after
+    autograd they are still views of it, so dp.GradientAllReducer all-reduces the bucket in place (no pack / unpack)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from dp import GradientAllReducer
+    sd = to_dev(S.scene_frustum(5000, W=96, H=64, focal=70.0, seed=3))
+    params = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    color, _ = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                                                     scales=params["scales"], rotations=params["rotations"])
+    color.sum().backward()
+    grads = [p.grad for p in params.values()]
+    bucket = GradientAllReducer._shared_bucket(grads)
+    assert bucket is not None and bucket.numel() >= sum(g.numel() for g in grads)
+    assert all(g.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr() for g in grads)
+
+
 def test_integrate_with_no_visible_gaussian_and_with_no_point_in_view():
     """Degenerate inputs of the opacity-field query: every Gaussian culled (behind the camera) -> points inside the image get
     alpha 0 and the background colour, points outside keep the initial 1; and a point set entirely outside the image."""
