@@ -252,7 +252,8 @@ class IntegrateViewCache:
     def put(self, key, entry):
         nbytes = sum(t.numel() * t.element_size() for t in entry if isinstance(t, torch.Tensor))
         dev = next(t.device for t in entry if isinstance(t, torch.Tensor))
-        if self.bytes + nbytes > self._budget(dev):
+        free, total = torch.cuda.mem_get_info(dev)
+        if self.bytes + nbytes > self._budget(dev) or free < 0.15 * total:      # never squeeze the caller's own working set
             self.rejected += 1
             return False
         self.entries[key] = entry
