@@ -207,7 +207,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
 
 def full_loop(sd, dev, W, H, steps=10, warmup=3):
     """SURVEY.md 8(d)(i) "full-loop variant": one complete training iteration of train.py:125-190, 263-265 on the same
-    scene -- parameter activations (torch, as scene/gaussian_model.py:74-112), rasterizer forward, the reference's loss
+    scene -- the parameter activations render() reads (scene/gaussian_model.py:157-194, HIP), rasterizer forward, the reference's loss
     (L1 + D-SSIM + depth-normal consistency + distortion), backward, Adam over the 59 floats per Gaussian -- with the
     HIP training epilogue (train_epilogue/: ssim, depth_to_normal, FusedAdam).  Reported beside the headline, not as it."""
     import math
@@ -228,11 +228,14 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     view = types.SimpleNamespace(world_view_transform=sd["viewmatrix"], image_width=W, image_height=H,
                                  FoVx=2 * math.atan(sd["tanfovx"]), FoVy=2 * math.atan(sd["tanfovy"]))
     lambda_dssim, lambda_dn, lambda_dist = 0.2, 0.05, 100.0        # arguments/__init__.py defaults
+    filter_3D = (sd["scales"].min(dim=1, keepdim=True).values * 0.1).contiguous()           # a small 3D smoothing filter (compute_3D_filter's role)
 
     def iteration():
-        shs = torch.cat((params["f_dc"], params["f_rest"]), dim=1)                           # get_features
-        rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=shs, opacities=torch.sigmoid(params["opacity"]),
-                                scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
+        shs = torch.cat((params["f_dc"], params["f_rest"]), dim=1)                           # get_features (gaussian_model.py:173-176)
+        A = T.activations                                                                    # gaussian_renderer/__init__.py:60,70-71
+        rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=shs,
+                                opacities=A.opacity_with_3D_filter(params["opacity"], params["scaling"], filter_3D),
+                                scales=A.scaling_with_3D_filter(params["scaling"], filter_3D), rotations=A.rotation(params["rotation"]))
         image = rendering[:3]
         rgb_loss = (1.0 - lambda_dssim) * T.l1_loss(image, gt) + lambda_dssim * (1.0 - T.ssim(image, gt))   # train.py:156-161
         distortion_loss = rendering[8].mean()                                                # :164-167
@@ -261,10 +264,11 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     kt = B.profile_report()
     B.profile_enable(False)
     ep = {k: round(v["total_ms"] / max(1, v["calls"]), 5) for k, v in kt.items()
-          if k in ("ssim_forward", "ssim_backward", "depth_to_normal", "depth_to_normal_backward", "adam_step")}
+          if k in ("ssim_forward", "ssim_backward", "depth_to_normal", "depth_to_normal_backward", "adam_step", "act_scaling", "act_opacity",
+                   "act_rotation", "act_scaling_backward", "act_opacity_backward", "act_rotation_backward")}
     n_floats = sum(p.numel() for p in params.values())
     out = {"ms_per_iter": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps,
-           "includes": "activations (torch) + rasterizer fwd/bwd + L1/D-SSIM/depth-normal/distortion loss + Adam (59 floats/Gaussian)",
+           "includes": "3D-filter activations + rasterizer fwd/bwd + L1/D-SSIM/depth-normal/distortion loss + Adam (59 floats/Gaussian)",
            "epilogue_kernels_ms": ep}
     if ep.get("adam_step"):
         out["adam_GBps"] = round(28.0 * n_floats / (ep["adam_step"] * 1e-3) / 1e9, 1)     # p,g,m,v read + p,m,v written

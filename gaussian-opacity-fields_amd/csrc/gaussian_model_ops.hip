@@ -1,4 +1,7 @@
-// filter3d.hip -- GaussianModel.compute_3D_filter (reference scene/gaussian_model.py:262-311) as two launches instead of
+// gaussian_model_ops.hip -- per-Gaussian bookkeeping of the reference GaussianModel on HIP (C ABI in include/gof_train_hip.h):
+// compute_3D_filter, add_densification_stats and the three parameter activations render() reads every iteration.
+//
+// GaussianModel.compute_3D_filter (reference scene/gaussian_model.py:262-311) as two launches instead of
 // ~25 torch kernels + two host-synchronising boolean-mask index ops PER CAMERA.  C ABI in include/gof_train_hip.h.
 //
 //   filter3d_min_depth: thread = point, the camera table streams through LDS in chunks of 128; per camera the arithmetic of
@@ -104,6 +107,90 @@ densification_stats_kernel(int64_t P, const float* __restrict__ grad, const uint
     denom[i] += 1.0f;
 }
 
+// ---- parameter activations (gaussian_model.py:157-166, 183-194); thread = Gaussian, streaming ------------------------------
+__global__ void __launch_bounds__(256)
+act_scaling_fwd(int64_t P, const float* __restrict__ rs, const float* __restrict__ f3, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float f = f3[i], ff = f * f;                          // torch.square(self.filter_3D)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float s = expf(rs[3 * i + c]); out[3 * i + c] = sqrtf(s * s + ff); }     // :160-161
+}
+__global__ void __launch_bounds__(256)
+act_scaling_bwd(int64_t P, const float* __restrict__ rs, const float* __restrict__ f3, const float* __restrict__ g, float* __restrict__ grs)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float f = f3[i], ff = f * f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float s = expf(rs[3 * i + c]), ss = s * s;
+        const float o = sqrtf(ss + ff);
+        // d sqrt(u)/du = 1/(2 sqrt u); d(s^2)/ds = 2 s; d exp/dx = s   (autograd's chain, :158-161)
+        grs[3 * i + c] = g[3 * i + c] / (2.0f * o) * (2.0f * s) * s;
+    }
+}
+__global__ void __launch_bounds__(256)
+act_opacity_fwd(int64_t P, const float* __restrict__ ro, const float* __restrict__ rs, const float* __restrict__ f3, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float f = f3[i], ff = f * f;
+    const float s0 = expf(rs[3 * i]), s1 = expf(rs[3 * i + 1]), s2 = expf(rs[3 * i + 2]);
+    const float q0 = s0 * s0, q1 = s1 * s1, q2 = s2 * s2;       // scales_square (:188)
+    const float det1 = q0 * q1 * q2;                            // :189
+    const float det2 = (q0 + ff) * (q1 + ff) * (q2 + ff);       // :191-192
+    const float coef = sqrtf(det1 / det2);                      // :193
+    const float o = 1.0f / (1.0f + expf(-ro[i]));               // sigmoid
+    out[i] = o * coef;                                          // :194
+}
+__global__ void __launch_bounds__(256)
+act_opacity_bwd(int64_t P, const float* __restrict__ ro, const float* __restrict__ rs, const float* __restrict__ f3, const float* __restrict__ g,
+                float* __restrict__ gro, float* __restrict__ grs)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float f = f3[i], ff = f * f;
+    float q[3], a[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float s = expf(rs[3 * i + c]); q[c] = s * s; a[c] = q[c] + ff; }
+    const float det1 = q[0] * q[1] * q[2], det2 = a[0] * a[1] * a[2];
+    const float coef = sqrtf(det1 / det2);
+    const float o = 1.0f / (1.0f + expf(-ro[i]));
+    const float go = g[i];
+    gro[i] = go * coef * (o * (1.0f - o));
+    // d coef / d raw_scale_c = coef * (1 - q_c / a_c): coef = sqrt(r), r = prod q / prod a, d r / d q_c = r (1/q_c - 1/a_c), d q_c / d raw = 2 q_c
+    const float gc = go * o * coef;
+#pragma unroll
+    for (int c = 0; c < 3; c++) grs[3 * i + c] = gc * (1.0f - q[c] / a[c]);
+}
+__global__ void __launch_bounds__(256)
+act_rotation_fwd(int64_t P, const float4* __restrict__ rr, float4* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4 r = rr[i];
+    const float d = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);     // F.normalize: v / max(||v||, eps)
+    out[i] = make_float4(r.x / d, r.y / d, r.z / d, r.w / d);
+}
+__global__ void __launch_bounds__(256)
+act_rotation_bwd(int64_t P, const float4* __restrict__ rr, const float4* __restrict__ g, float4* __restrict__ grr)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4 r = rr[i], go = g[i];
+    const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+    if (n >= 1e-12f) {
+        const float inv = 1.0f / n;
+        const float4 u = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+        const float ug = u.x * go.x + u.y * go.y + u.z * go.z + u.w * go.w;
+        grr[i] = make_float4((go.x - u.x * ug) * inv, (go.y - u.y * ug) * inv, (go.z - u.z * ug) * inv, (go.w - u.w * ug) * inv);
+    } else {
+        grr[i] = make_float4(go.x / 1e-12f, go.y / 1e-12f, go.z / 1e-12f, go.w / 1e-12f);      // clamped denominator: constant
+    }
+}
+
 } // namespace gof
 
 using namespace gof;
@@ -157,5 +244,31 @@ int gof_add_densification_stats(int64_t P, const float* viewspace_grad, const ui
     GOF_LAUNCH_CHECK(stream, 0);
     return GOF_OK;
 }
+
+#define GOF_ACT_ENTRY(NAME, KERNEL, NULLCHECK, ...)                                                                  \
+    {                                                                                                                \
+        hipStream_t stream = static_cast<hipStream_t>(stream_);                                                      \
+        if (P < 0) { set_error("bad number of points"); return GOF_E_INVALID; }                                      \
+        if (P == 0) return GOF_OK;                                                                                   \
+        if (NULLCHECK) { set_error(NAME ": a pointer is NULL"); return GOF_E_INVALID; }                              \
+        GOF_PROFILE(NAME, stream);                                                                                   \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P, __VA_ARGS__);          \
+        GOF_LAUNCH_CHECK(stream, 0);                                                                                 \
+        return GOF_OK;                                                                                               \
+    }
+
+int gof_act_scaling(int64_t P, const float* rs, const float* f3, float* out, void* stream_)
+    GOF_ACT_ENTRY("act_scaling", act_scaling_fwd, !rs || !f3 || !out, rs, f3, out)
+int gof_act_scaling_backward(int64_t P, const float* rs, const float* f3, const float* g, float* grs, void* stream_)
+    GOF_ACT_ENTRY("act_scaling_backward", act_scaling_bwd, !rs || !f3 || !g || !grs, rs, f3, g, grs)
+int gof_act_opacity(int64_t P, const float* ro, const float* rs, const float* f3, float* out, void* stream_)
+    GOF_ACT_ENTRY("act_opacity", act_opacity_fwd, !ro || !rs || !f3 || !out, ro, rs, f3, out)
+int gof_act_opacity_backward(int64_t P, const float* ro, const float* rs, const float* f3, const float* g, float* gro, float* grs, void* stream_)
+    GOF_ACT_ENTRY("act_opacity_backward", act_opacity_bwd, !ro || !rs || !f3 || !g || !gro || !grs, ro, rs, f3, g, gro, grs)
+int gof_act_rotation(int64_t P, const float* rr, float* out, void* stream_)
+    GOF_ACT_ENTRY("act_rotation", act_rotation_fwd, !rr || !out, reinterpret_cast<const float4*>(rr), reinterpret_cast<float4*>(out))
+int gof_act_rotation_backward(int64_t P, const float* rr, const float* g, float* grr, void* stream_)
+    GOF_ACT_ENTRY("act_rotation_backward", act_rotation_bwd, !rr || !g || !grr, reinterpret_cast<const float4*>(rr),
+                  reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(grr))
 
 } // extern "C"

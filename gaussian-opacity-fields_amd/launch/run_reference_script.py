@@ -63,6 +63,10 @@ def rebind_train_epilogue():
     GaussianModel.training_setup = training_setup
     GaussianModel.compute_3D_filter = T.compute_3D_filter      # train.py:118,261,269: after every densification
     GaussianModel.add_densification_stats = T.add_densification_stats   # train.py:256: every iteration until densify_until_iter
+    # the three derived tensors render() reads every iteration (gaussian_renderer/__init__.py:60,70-71)
+    GaussianModel.get_scaling_with_3D_filter = property(T.activations.get_scaling_with_3D_filter)
+    GaussianModel.get_opacity_with_3D_filter = property(T.activations.get_opacity_with_3D_filter)
+    GaussianModel.get_rotation = property(T.activations.get_rotation)
 
 
 def rebind_integrate_with_view_cache():

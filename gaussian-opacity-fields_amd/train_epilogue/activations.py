@@ -1,0 +1,121 @@
+"""Fused replacements for the three derived tensors ``render()`` reads from the reference's ``GaussianModel`` every iteration
+(gaussian_renderer/__init__.py:60,70-71):
+
+    get_scaling_with_3D_filter  (scene/gaussian_model.py:157-162)   5 torch kernels + autograd  -> 1 + 1 launches
+    get_opacity_with_3D_filter  (:183-194)                         10 torch kernels + autograd  -> 1 + 1 launches
+    get_rotation                (:165-166, F.normalize)             3 torch kernels + autograd  -> 1 + 1 launches
+
+launch/run_reference_script.py installs them as properties on the reference's GaussianModel class.  Same values to fp32
+rounding, same gradients (tests/test_train_epilogue_gpu.py)."""
+import ctypes as C
+
+import torch
+
+from . import _backend as B
+
+lib = B.lib
+_vp, _i64 = C.c_void_p, C.c_int64
+for _name, _n in (("gof_act_scaling", 3), ("gof_act_scaling_backward", 4), ("gof_act_opacity", 4), ("gof_act_opacity_backward", 6),
+                  ("gof_act_rotation", 2), ("gof_act_rotation_backward", 3)):
+    getattr(lib, _name).restype = C.c_int
+    getattr(lib, _name).argtypes = [_i64] + [_vp] * _n + [_vp]
+
+
+def _f3(filter_3D, n, like):
+    f = B._need_cuda_f32(filter_3D.detach(), "filter_3D")
+    if f.numel() != n or f.device != like.device:
+        raise RuntimeError("filter_3D must hold one value per Gaussian (%d) on %s" % (n, like.device))
+    return f.reshape(n)
+
+
+class _Scaling(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_scaling, filter_3D):
+        rs = B._need_cuda_f32(raw_scaling, "_scaling")
+        n = int(rs.shape[0])
+        f = _f3(filter_3D, n, rs)
+        out = torch.empty_like(rs)
+        with torch.cuda.device(rs.device):
+            B._check(lib.gof_act_scaling(n, rs.data_ptr(), f.data_ptr(), out.data_ptr(), B._stream()))
+        ctx.save_for_backward(rs, f)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rs, f = ctx.saved_tensors
+        g = g.contiguous()
+        grs = torch.empty_like(rs)
+        with torch.cuda.device(rs.device):
+            B._check(lib.gof_act_scaling_backward(int(rs.shape[0]), rs.data_ptr(), f.data_ptr(), g.data_ptr(), grs.data_ptr(), B._stream()))
+        return grs, None
+
+
+class _Opacity(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_opacity, raw_scaling, filter_3D):
+        ro = B._need_cuda_f32(raw_opacity, "_opacity")
+        rs = B._need_cuda_f32(raw_scaling, "_scaling")
+        n = int(rs.shape[0])
+        f = _f3(filter_3D, n, rs)
+        out = torch.empty_like(ro)
+        with torch.cuda.device(rs.device):
+            B._check(lib.gof_act_opacity(n, ro.data_ptr(), rs.data_ptr(), f.data_ptr(), out.data_ptr(), B._stream()))
+        ctx.save_for_backward(ro, rs, f)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ro, rs, f = ctx.saved_tensors
+        g = g.contiguous()
+        gro, grs = torch.empty_like(ro), torch.empty_like(rs)
+        with torch.cuda.device(rs.device):
+            B._check(lib.gof_act_opacity_backward(int(rs.shape[0]), ro.data_ptr(), rs.data_ptr(), f.data_ptr(), g.data_ptr(), gro.data_ptr(),
+                                                  grs.data_ptr(), B._stream()))
+        return gro, grs, None
+
+
+class _Rotation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_rotation):
+        rr = B._need_cuda_f32(raw_rotation, "_rotation")
+        if rr.dim() != 2 or rr.shape[1] != 4:
+            raise RuntimeError("_rotation must have dimensions (num_points, 4)")
+        out = torch.empty_like(rr)
+        with torch.cuda.device(rr.device):
+            B._check(lib.gof_act_rotation(int(rr.shape[0]), rr.data_ptr(), out.data_ptr(), B._stream()))
+        ctx.save_for_backward(rr)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rr,) = ctx.saved_tensors
+        g = g.contiguous()
+        grr = torch.empty_like(rr)
+        with torch.cuda.device(rr.device):
+            B._check(lib.gof_act_rotation_backward(int(rr.shape[0]), rr.data_ptr(), g.data_ptr(), grr.data_ptr(), B._stream()))
+        return grr
+
+
+def scaling_with_3D_filter(raw_scaling, filter_3D):
+    return _Scaling.apply(raw_scaling, filter_3D)
+
+
+def opacity_with_3D_filter(raw_opacity, raw_scaling, filter_3D):
+    return _Opacity.apply(raw_opacity, raw_scaling, filter_3D)
+
+
+def rotation(raw_rotation):
+    return _Rotation.apply(raw_rotation)
+
+
+# property bodies for the reference's GaussianModel (self._scaling, self._opacity, self._rotation, self.filter_3D)
+def get_scaling_with_3D_filter(self):
+    return scaling_with_3D_filter(self._scaling, self.filter_3D)
+
+
+def get_opacity_with_3D_filter(self):
+    return opacity_with_3D_filter(self._opacity, self._scaling, self.filter_3D)
+
+
+def get_rotation(self):
+    return rotation(self._rotation)

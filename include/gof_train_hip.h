@@ -99,6 +99,23 @@ int gof_add_densification_stats(int64_t num_points, const float* viewspace_grad,
                                 float* xyz_gradient_accum, float* xyz_gradient_accum_abs, float* xyz_gradient_accum_abs_max,
                                 float* denom, void* stream);
 
+/* ---- parameter activations of the render path (scene/gaussian_model.py:157-166, 183-194) -------------------------------------
+ * render() reads three derived tensors per iteration (gaussian_renderer/__init__.py:60,70-71); in the reference each is a chain
+ * of 3-10 torch elementwise kernels plus their autograd (~50 launches per iteration).  One forward and one backward launch each:
+ *   scaling  [P,3]: sqrt(exp(_scaling)^2 + filter_3D^2)                                   (get_scaling_with_3D_filter, :157-162)
+ *   opacity  [P,1]: sigmoid(_opacity) * sqrt(prod(s^2) / prod(s^2 + filter_3D^2)), s = exp(_scaling)  (get_opacity_with_3D_filter, :183-194)
+ *   rotation [P,4]: _rotation / max(||_rotation||, 1e-12)                                 (get_rotation, :165-166: F.normalize)
+ * filter_3D is [P] (the reference's (P,1) column); it receives no gradient (it is recomputed, never optimised).
+ * The *_backward calls WRITE (not accumulate) the gradient w.r.t. their raw inputs. */
+int gof_act_scaling(int64_t P, const float* raw_scaling, const float* filter_3D, float* out, void* stream);
+int gof_act_scaling_backward(int64_t P, const float* raw_scaling, const float* filter_3D, const float* grad_out,
+                             float* grad_raw_scaling, void* stream);
+int gof_act_opacity(int64_t P, const float* raw_opacity, const float* raw_scaling, const float* filter_3D, float* out, void* stream);
+int gof_act_opacity_backward(int64_t P, const float* raw_opacity, const float* raw_scaling, const float* filter_3D, const float* grad_out,
+                             float* grad_raw_opacity, float* grad_raw_scaling, void* stream);
+int gof_act_rotation(int64_t P, const float* raw_rotation, float* out, void* stream);
+int gof_act_rotation_backward(int64_t P, const float* raw_rotation, const float* grad_out, float* grad_raw_rotation, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

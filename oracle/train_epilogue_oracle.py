@@ -106,6 +106,28 @@ def add_densification_stats(accum, accum_abs, accum_abs_max, denom, grad, update
     denom[update_filter] += 1                                                                                # :714
 
 
+# ---- scene/gaussian_model.py: the derived tensors render() reads ------------------------------------------------------------
+def scaling_with_3D_filter(raw_scaling, filter_3D):
+    scales = torch.exp(raw_scaling)                                                       # get_scaling, :152-154
+    scales = torch.square(scales) + torch.square(filter_3D)                               # :160
+    return torch.sqrt(scales)                                                             # :161
+
+
+def opacity_with_3D_filter(raw_opacity, raw_scaling, filter_3D):
+    opacity = torch.sigmoid(raw_opacity)                                                  # :184
+    scales = torch.exp(raw_scaling)                                                       # :186
+    scales_square = torch.square(scales)                                                  # :188
+    det1 = scales_square.prod(dim=1)                                                      # :189
+    scales_after_square = scales_square + torch.square(filter_3D)                         # :191
+    det2 = scales_after_square.prod(dim=1)                                                # :192
+    coef = torch.sqrt(det1 / det2)                                                        # :193
+    return opacity * coef[..., None]                                                      # :194
+
+
+def rotation(raw_rotation):
+    return F.normalize(raw_rotation)                                                      # :166
+
+
 # ---- torch/optim/adam.py (the optimizer scene/gaussian_model.py:360 builds) ----------------------------
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-15):
     """One step of torch.optim.Adam (no weight decay, no amsgrad) in fp32 numpy, operation order of

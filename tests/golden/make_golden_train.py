@@ -131,6 +131,27 @@ out["f3d_xyz"] = xyz3.numpy()
 out["f3d_cams"] = np.stack([np.concatenate([c.R.reshape(9), c.T.reshape(3), [c.focal_x, c.focal_y, c.image_width, c.image_height]]) for c in cams3])
 out["f3d_filter"] = fake.filter_3D.numpy()
 
+# ---- the derived tensors render() reads: GaussianModel.get_scaling_with_3D_filter / get_opacity_with_3D_filter / get_rotation,
+#      the reference's own property bodies on a stand-in object (scene/gaussian_model.py:152-194) ----
+Pa = 3000
+Stand = type("Stand", (), {k: getattr(GaussianModel, k) for k in ("get_scaling", "get_scaling_with_3D_filter", "get_opacity_with_3D_filter",
+                                                                  "get_rotation", "setup_functions")})   # the reference's own property objects
+act = Stand()
+act.setup_functions()
+act._scaling = (torch.randn((Pa, 3), generator=g) * 1.5 - 3.0).requires_grad_(True)
+act._opacity = (torch.randn((Pa, 1), generator=g) * 2.0).requires_grad_(True)
+act._rotation = torch.randn((Pa, 4), generator=g).requires_grad_(True)
+act.filter_3D = torch.rand((Pa, 1), generator=g) * 0.05
+sc_f = act.get_scaling_with_3D_filter
+op_f = act.get_opacity_with_3D_filter
+ro_n = act.get_rotation
+w_s, w_o, w_r = torch.randn(sc_f.shape, generator=g), torch.randn(op_f.shape, generator=g), torch.randn(ro_n.shape, generator=g)
+gs, go_, gr_ = torch.autograd.grad((sc_f * w_s).sum() + (op_f * w_o).sum() + (ro_n * w_r).sum(), [act._scaling, act._opacity, act._rotation])
+for k, v in (("raw_scaling", act._scaling), ("raw_opacity", act._opacity), ("raw_rotation", act._rotation), ("filter_3D", act.filter_3D),
+             ("scaling", sc_f), ("opacity", op_f), ("rotation", ro_n), ("w_s", w_s), ("w_o", w_o), ("w_r", w_r),
+             ("g_scaling", gs), ("g_opacity", go_), ("g_rotation", gr_)):
+    out["act_" + k] = v.detach().numpy()
+
 path = os.path.join(HERE, "ref_train_epilogue_golden.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

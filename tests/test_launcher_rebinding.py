@@ -40,6 +40,8 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
     import utils.loss_utils as ref_loss
     import utils.depth_utils as ref_depth
     from scene.gaussian_model import GaussianModel
+    props = {p_: getattr(GaussianModel, p_) for p_ in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation")}
+    assert all(isinstance(v, property) for v in props.values())          # they are properties in the reference too
     orig = {"ssim": ref_loss.ssim, "d2n": ref_depth.depth_to_normal, "d2p": ref_depth.depths_to_points,
             "setup": GaussianModel.training_setup, "f3d": GaussianModel.compute_3D_filter, "stats": GaussianModel.add_densification_stats}
     L = _load_launcher()
@@ -49,6 +51,8 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
         assert ref_loss.ssim is T.ssim and ref_depth.depth_to_normal is T.depth_to_normal and ref_depth.depths_to_points is T.depths_to_points
         assert GaussianModel.compute_3D_filter is T.compute_3D_filter and GaussianModel.add_densification_stats is T.add_densification_stats
         assert GaussianModel.training_setup is not orig["setup"]
+        for prop in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation"):
+            assert isinstance(getattr(GaussianModel, prop), property) and getattr(GaussianModel, prop).fget is getattr(T.activations, prop)
         # same call signatures as the functions they replace
         for new, old in ((T.ssim, orig["ssim"]), (T.depth_to_normal, orig["d2n"]), (T.depths_to_points, orig["d2p"]),
                          (T.compute_3D_filter, orig["f3d"]), (T.add_densification_stats, orig["stats"])):
@@ -56,6 +60,8 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
     finally:
         ref_loss.ssim, ref_depth.depth_to_normal, ref_depth.depths_to_points = orig["ssim"], orig["d2n"], orig["d2p"]
         GaussianModel.training_setup, GaussianModel.compute_3D_filter, GaussianModel.add_densification_stats = orig["setup"], orig["f3d"], orig["stats"]
+        for k_, v_ in props.items():
+            setattr(GaussianModel, k_, v_)
 
 
 def test_integrate_wrapper_and_marching_tets_rebinding(reference_on_path):

@@ -267,6 +267,57 @@ def test_add_densification_stats_matches_oracle_over_several_iterations():
         T.add_densification_stats(model, vp, torch.ones(P, device=DEV))       # not a bool mask
 
 
+# ---- parameter activations ---------------------------------------------------------------------------------------
+def _act_product(rs, ro, rr, f3, ws, wo, wr):
+    import train_epilogue as T
+    model = types.SimpleNamespace(_scaling=torch.from_numpy(rs).to(DEV).requires_grad_(True), _opacity=torch.from_numpy(ro).to(DEV).requires_grad_(True),
+                                  _rotation=torch.from_numpy(rr).to(DEV).requires_grad_(True), filter_3D=torch.from_numpy(f3).to(DEV))
+    A = T.activations
+    s, o, r = A.get_scaling_with_3D_filter(model), A.get_opacity_with_3D_filter(model), A.get_rotation(model)   # the property bodies
+    f = (s * torch.from_numpy(ws).to(DEV)).sum() + (o * torch.from_numpy(wo).to(DEV)).sum() + (r * torch.from_numpy(wr).to(DEV)).sum()
+    f.backward()                                                   # _scaling receives gradient from BOTH the scaling and the opacity op
+    return [t.detach().cpu().numpy() for t in (s, o, r, model._scaling.grad, model._opacity.grad, model._rotation.grad)]
+
+
+def test_activations_match_reference_golden():
+    got = _act_product(G["act_raw_scaling"], G["act_raw_opacity"], G["act_raw_rotation"], G["act_filter_3D"], G["act_w_s"], G["act_w_o"], G["act_w_r"])
+    for a, name in zip(got, ("scaling", "opacity", "rotation", "g_scaling", "g_opacity", "g_rotation")):
+        ref = G["act_" + name]
+        assert a.shape == ref.shape, name
+        # exp / sigmoid / sqrt chains in fp32: values 2e-6 relative; gradients 1e-5 of their maximum (products of those values)
+        if name.startswith("g_"):
+            _close(a, ref, 1e-5, name)
+        else:
+            np.testing.assert_allclose(a, ref, rtol=2e-6, atol=1e-30, err_msg=name)
+
+
+def test_activations_match_oracle_at_full_size_and_extremes():
+    P = 1_000_000
+    g = torch.Generator().manual_seed(44)
+    rs = (torch.randn((P, 3), generator=g) * 2.0 - 4.0).numpy()
+    ro = (torch.randn((P, 1), generator=g) * 4.0).numpy()           # sigmoid saturates at both ends
+    rr = torch.randn((P, 4), generator=g).numpy()
+    rr[:10] = 0.0                                                   # zero quaternion: F.normalize's clamped denominator
+    f3 = (torch.rand((P, 1), generator=g) * 0.1).numpy()
+    f3[:1000] = 0.0                                                 # no filter: coef == 1, opacity == sigmoid
+    ws, wo, wr = (torch.randn(s_, generator=g).numpy() for s_ in ((P, 3), (P, 1), (P, 4)))
+    got = _act_product(rs, ro, rr, f3, ws, wo, wr)
+    trs, tro, trr = (torch.from_numpy(a).requires_grad_(True) for a in (rs, ro, rr))
+    tf = torch.from_numpy(f3)
+    s, o, r = O.scaling_with_3D_filter(trs, tf), O.opacity_with_3D_filter(tro, trs, tf), O.rotation(trr)
+    f = (s * torch.from_numpy(ws)).sum() + (o * torch.from_numpy(wo)).sum() + (r * torch.from_numpy(wr)).sum()
+    gs, go, gr = torch.autograd.grad(f, [trs, tro, trr])
+    for a, ref, name in zip(got, (s, o, r, gs, go, gr), ("scaling", "opacity", "rotation", "g_scaling", "g_opacity", "g_rotation")):
+        ref = ref.detach().numpy()
+        assert np.isfinite(a).all(), name
+        if name.startswith("g_"):
+            _close(a, ref, 1e-5, name)
+        else:
+            np.testing.assert_allclose(a, ref, rtol=3e-6, atol=1e-30, err_msg=name)
+    assert np.array_equal(got[1][:1000], (1.0 / (1.0 + np.exp(-ro[:1000].astype(np.float64)))).astype(np.float32)) or \
+        np.allclose(got[1][:1000], 1.0 / (1.0 + np.exp(-ro[:1000].astype(np.float64))), rtol=3e-7)
+
+
 # ---- FusedAdam ---------------------------------------------------------------------------------------------
 GROUPS = [("xyz", (3,), 1.6e-4), ("f_dc", (1, 3), 2.5e-3), ("f_rest", (15, 3), 1.25e-4), ("opacity", (1,), 5e-2),
           ("scaling", (3,), 5e-3), ("rotation", (4,), 1e-3)]          # scene/gaussian_model.py:349-358, arguments/__init__.py

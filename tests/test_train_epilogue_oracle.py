@@ -81,6 +81,23 @@ def test_compute_3d_filter_oracle_matches_reference_python():
     assert (G["f3d_filter"] == G["f3d_filter"].max()).sum() > 1
 
 
+def test_activation_oracle_matches_reference_python():
+    """get_scaling_with_3D_filter / get_opacity_with_3D_filter / get_rotation: the reference's own property bodies (golden)."""
+    rs = torch.from_numpy(G["act_raw_scaling"]).requires_grad_(True)
+    ro = torch.from_numpy(G["act_raw_opacity"]).requires_grad_(True)
+    rr = torch.from_numpy(G["act_raw_rotation"]).requires_grad_(True)
+    f3 = torch.from_numpy(G["act_filter_3D"])
+    s, o, r = O.scaling_with_3D_filter(rs, f3), O.opacity_with_3D_filter(ro, rs, f3), O.rotation(rr)
+    np.testing.assert_array_equal(s.detach().numpy(), G["act_scaling"])
+    np.testing.assert_array_equal(o.detach().numpy(), G["act_opacity"])
+    np.testing.assert_array_equal(r.detach().numpy(), G["act_rotation"])
+    f = (s * torch.from_numpy(G["act_w_s"])).sum() + (o * torch.from_numpy(G["act_w_o"])).sum() + (r * torch.from_numpy(G["act_w_r"])).sum()
+    gs, go, gr = torch.autograd.grad(f, [rs, ro, rr])
+    np.testing.assert_array_equal(gs.numpy(), G["act_g_scaling"])
+    np.testing.assert_array_equal(go.numpy(), G["act_g_opacity"])
+    np.testing.assert_array_equal(gr.numpy(), G["act_g_rotation"])
+
+
 # ---- host-side behaviour of the product mirrors (no kernel is launched) ---------------------------------
 def test_mirrors_fail_loudly_without_a_device_and_on_bad_arguments():
     import train_epilogue as T
