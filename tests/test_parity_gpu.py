@@ -364,6 +364,27 @@ def test_integrate_view_cache_reuses_the_gaussian_side_bit_exactly():
         cache.clear()
 
 
+def test_integrate_full_size_s1m_against_oracle():
+    """The opacity-field query at 1M Gaussians, 1600x1063, 2M query points against the oracle (host cores of the GPU box):
+    every output bit-identical -- the footprint-conic cull, the zfront skip and the pixel-grouped point order at full scale."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = S.scene_frustum(1_000_000, seed=0)
+    allpts = S.tetra_points(sc)
+    pts = np.ascontiguousarray(allpts[np.random.default_rng(9).choice(len(allpts), 2_000_000, replace=False)], dtype=np.float32)
+    o = ob.OracleScene(sc)
+    oc, oal, ocol, orad = o.integrate(pts)
+    sd = to_dev(sc)
+    r = GaussianRasterizer(settings_from(sd))
+    color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
+                                            opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), orad)
+    c = color.cpu().numpy()
+    assert np.array_equal(bits(c), bits(oc)), [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)]
+    a = alpha.cpu().numpy()
+    assert np.array_equal(bits(a), bits(oal)), (int((bits(a) != bits(oal)).sum()), np.abs(a - oal).max())
+    assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
+
+
 def test_integrate_full_size_properties_config5():
     """BASELINE config 5 shape at FULL size (5M Gaussians, 45M query points, 1600x1063): size-independent properties of the
     opacity-field query instead of an oracle run -- range, untouched points, channel-8 checksum, idempotence, cache equivalence,
