@@ -56,9 +56,10 @@ __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* g
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
                                  uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
-                                 const uint32_t* point_list, const SplatRec* rec, const float4* fconic, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
+                                 const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
                                  float* out_alpha_integrated, float* out_color_integrated, uint32_t gx, uint32_t ntiles);
+__global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
@@ -445,7 +446,35 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 }
 
 // ---- integrate, point side: point binning (createWithKeys + sort + ranges, rasterizer_impl.cu:720-752) + point pass ----
-int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI,
+static size_t packed_geom_layout(int32_t P, const void* base, const SplatRec** rec, const float** zfront)
+{
+    const size_t n = (size_t)(P < 1 ? 1 : P);
+    const char* p = static_cast<const char*>(base);
+    if (rec) *rec = reinterpret_cast<const SplatRec*>(p);
+    const size_t off = (n * sizeof(SplatRec) + ALIGN - 1) & ~(size_t)(ALIGN - 1);
+    if (zfront) *zfront = reinterpret_cast<const float*>(p + off);
+    return off + ((n * sizeof(float) + ALIGN - 1) & ~(size_t)(ALIGN - 1)) + ALIGN;
+}
+size_t gof_integrate_packed_geom_bytes(int32_t P) { return packed_geom_layout(P, nullptr, nullptr, nullptr) + ALIGN; }
+
+int gof_integrate_pack_geom(const GofRasterArgs* a, const void* geom_ws, size_t geom_bytes, void* packed, size_t packed_bytes, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!a || a->P < 0) { set_error("bad args"); return GOF_E_INVALID; }
+    if (a->P == 0) return GOF_OK;
+    if (!geom_ws || !packed) { set_error("a workspace is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P) || packed_bytes < gof_integrate_packed_geom_bytes(a->P)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
+    GeomWs g;
+    geom_layout(a->P, aligned_base(const_cast<void*>(geom_ws)), &g);
+    const SplatRec* rec; const float* zf;
+    packed_geom_layout(a->P, aligned_base(packed), &rec, &zf);
+    hipLaunchKernelGGL(pack_view_geometry, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.rec, g.fconic,
+                       const_cast<SplatRec*>(rec), const_cast<float*>(zf));
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    return GOF_OK;
+}
+
+static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI, bool packed,
                          const void* geom_ws, size_t geom_bytes, const void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
                          void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
                          const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
@@ -455,10 +484,14 @@ int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_
     if (rc) return rc;
     if (a->P == 0 || PN <= 0) return GOF_OK;     // rasterize_points.cu:301
     if (!base_color || !out_color || !out_alpha_integrated || !out_color_integrated) { set_error("an output pointer is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H) ||
+    if (geom_bytes < (packed ? gof_integrate_packed_geom_bytes(a->P) : gof_geom_bytes(a->P)) || image_bytes < gof_image_bytes(a->W, a->H) ||
+        binning_bytes < gof_binning_bytes(R, a->W, a->H) ||
         point_bytes < gof_point_bytes(PN) || point_binning_bytes < gof_point_binning_bytes(NI, a->W, a->H)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
-    GeomWs g; ImageWs im; BinWs b, pb; PointWs w;
-    geom_layout(a->P, aligned_base(const_cast<void*>(geom_ws)), &g);
+    const SplatRec* rec_ptr; const float* zfront_ptr; int zstride;
+    if (packed) { packed_geom_layout(a->P, aligned_base(const_cast<void*>(geom_ws)), &rec_ptr, &zfront_ptr); zstride = 1; }
+    else { GeomWs gg; geom_layout(a->P, aligned_base(const_cast<void*>(geom_ws)), &gg); rec_ptr = gg.rec;
+           zfront_ptr = reinterpret_cast<const float*>(gg.fconic) + 7; zstride = 8; }        // fconic[2i + 1].w
+    ImageWs im; BinWs b, pb; PointWs w;
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
     bin_layout(R, a->W, a->H, aligned_base(const_cast<void*>(binning_ws)), &b, true);
     point_layout(PN, aligned_base(point_ws), &w);
@@ -487,10 +520,27 @@ int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_
     } }
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, im.point_ranges, b.vals, pb.vals, g.rec, g.fconic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
+                       im.ranges, im.point_ranges, b.vals, pb.vals, rec_ptr, zfront_ptr, zstride, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
                        base_color, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
+}
+
+int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI,
+                         const void* geom_ws, size_t geom_bytes, const void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                         void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                         const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
+{
+    return integrate_points_impl(a, R, PN, NI, false, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
+                                 point_binning_ws, point_binning_bytes, base_color, out_color, out_alpha_integrated, out_color_integrated, stream_);
+}
+int gof_integrate_points_packed(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI,
+                         const void* packed_geom, size_t packed_bytes, const void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                         void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                         const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
+{
+    return integrate_points_impl(a, R, PN, NI, true, packed_geom, packed_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
+                                 point_binning_ws, point_binning_bytes, base_color, out_color, out_alpha_integrated, out_color_integrated, stream_);
 }
 
 int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, int32_t PN, uint32_t NI,

@@ -209,12 +209,24 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
     }
 }
 
+// copies what the point pass needs of the geometry workspace (64-byte records, front depths) into a compact buffer
+__global__ void __launch_bounds__(256)
+pack_view_geometry(int P, const SplatRec* __restrict__ rec, const float4* __restrict__ fconic, SplatRec* __restrict__ rec_out, float* __restrict__ zfront_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4* src = reinterpret_cast<const float4*>(&rec[i]);
+    float4* dst = reinterpret_cast<float4*>(&rec_out[i]);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    zfront_out[i] = fconic[2 * (size_t)i + 1].w;
+}
+
 // Phase B.  base_color: the [9,H,W] image integrate_pixels wrote (channels 0-2 = the pixel colour every point of the
 // pixel receives, forward.cu:1207-1208); out_color may alias it.
 __global__ void __launch_bounds__(256)
 integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restrict__ point_ranges,
                  const uint32_t* __restrict__ gaussian_list, const uint32_t* __restrict__ point_list,
-                 const SplatRec* __restrict__ rec, const float4* __restrict__ fconic, const uint32_t* __restrict__ cmask, int W, int H,
+                 const SplatRec* __restrict__ rec, const float* __restrict__ zfront, int zstride, const uint32_t* __restrict__ cmask, int W, int H,
                  float focal_x, float focal_y, const float2* __restrict__ pt_xy, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
                  float* __restrict__ pt_acc, const float* __restrict__ base_color, float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
                  float* __restrict__ out_color_integrated, uint32_t gx, uint32_t ntiles)
@@ -262,7 +274,7 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             const uint32_t id = gaussian_list[k];
             const float4* src = reinterpret_cast<const float4*>(&rec[id]);
             s_rec[0][tid] = src[0]; s_rec[1][tid] = src[1]; s_rec[2][tid] = src[2];
-            s_zfront[tid] = fconic[2 * (size_t)id + 1].w;
+            s_zfront[tid] = zfront[(size_t)id * zstride];
         }
         const int n = toDo < 0 ? 0 : (toDo < TILE_PIX ? toDo : TILE_PIX);
         const int nwords = (n + 31) >> 5;

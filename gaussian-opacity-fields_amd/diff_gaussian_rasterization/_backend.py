@@ -54,6 +54,10 @@ def _load():
     lib.gof_integrate_run.argtypes = [A, u32, vp, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_integrate_view.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.gof_integrate_points.argtypes = [A, u32, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]
+    lib.gof_integrate_points_packed.argtypes = lib.gof_integrate_points.argtypes
+    lib.gof_integrate_pack_geom.argtypes = [A, vp, sz, vp, sz, vp]
+    lib.gof_integrate_packed_geom_bytes.restype = sz
+    lib.gof_integrate_packed_geom_bytes.argtypes = [i32]
     lib.gof_point_binning_bytes.restype = sz
     lib.gof_point_binning_bytes.argtypes = [u32, i32, i32]
     lib.gof_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
@@ -64,7 +68,7 @@ def _load():
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
     for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
-                 "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_mark_visible", "gof_mtets_count", "gof_mtets_emit"):
+                 "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_integrate_points_packed", "gof_integrate_pack_geom", "gof_mark_visible", "gof_mtets_count", "gof_mtets_emit"):
         getattr(lib, name).restype = C.c_int
     return lib
 
@@ -316,23 +320,29 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
         # Gaussian side of the view (binning + pixel pass): once per view key when a driver announces one (IntegrateViewCache)
         key = getattr(_integrate_key, "value", None)
         entry = _view_cache.get(key) if key is not None else None
+        points_fn = lib.gof_integrate_points
         if entry is None:
             geom, img, binning, radii, rendered = _prepare_and_bin(v)
             base = out_color
             _check(lib.gof_integrate_view(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                           _ptr(img), img.numel(), _ptr(base), _stream()))
-            if key is not None and _view_cache.put(key, (geom, img, binning, radii, rendered, base, v.P, v.W, v.H)):
-                out_color = torch.empty_like(base)         # the cached base image must stay untouched by channel 8
+            if key is not None:
+                # keep only what the point pass reads of the geometry workspace (records + front depths: 68 of ~220 B per Gaussian)
+                packed = v.bytes_tensor(lib.gof_integrate_packed_geom_bytes(v.P))
+                _check(lib.gof_integrate_pack_geom(v.ref(), _ptr(geom), geom.numel(), _ptr(packed), packed.numel(), _stream()))
+                if _view_cache.put(key, (packed, img, binning, radii, rendered, base, v.P, v.W, v.H)):
+                    out_color = torch.empty_like(base)     # the cached base image must stay untouched by channel 8
         else:
             geom, img, binning, radii, rendered, base, cP, cW, cH = entry
             if (cP, cW, cH) != (v.P, v.W, v.H):
                 raise RuntimeError("integrate view cache: key %r was announced for a different problem size" % (key,))
             out_color = torch.empty_like(base)
+            points_fn = lib.gof_integrate_points_packed
         pws = v.bytes_tensor(lib.gof_point_bytes(PN))
         ni = C.c_uint32(0)
         _check(lib.gof_integrate_prepare_points(v.ref(), PN, _ptr(pts), _ptr(pws), pws.numel(), C.byref(ni), _stream()))
         pbin = v.bytes_tensor(lib.gof_point_binning_bytes(int(ni.value), v.W, v.H))
-        _check(lib.gof_integrate_points(v.ref(), rendered, PN, int(ni.value), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+        _check(points_fn(v.ref(), rendered, PN, int(ni.value), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                         _ptr(img), img.numel(), _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), _ptr(out_color),
                                         _ptr(out_alpha), _ptr(out_color_pts), _stream()))
     return rendered, out_color, out_alpha, out_color_pts, radii, geom, binning, img

@@ -186,6 +186,19 @@ int gof_integrate_points(const GofRasterArgs* args, uint32_t num_rendered, int32
                          const float* base_color, float* out_color,
                          float* out_alpha_integrated, float* out_color_integrated, void* stream);
 
+/* A cached view only needs the 64-byte records and the front depths of the geometry workspace: gof_integrate_pack_geom copies
+ * them into a buffer of gof_integrate_packed_geom_bytes(P) (68 B per Gaussian instead of ~220), gof_integrate_points_packed is
+ * gof_integrate_points reading that buffer in place of geom_ws. */
+size_t gof_integrate_packed_geom_bytes(int32_t P);
+int gof_integrate_pack_geom(const GofRasterArgs* args, const void* geom_ws, size_t geom_bytes,
+                            void* packed_geom, size_t packed_bytes, void* stream);
+int gof_integrate_points_packed(const GofRasterArgs* args, uint32_t num_rendered, int32_t PN, uint32_t num_integrated,
+                                const void* packed_geom, size_t packed_bytes, const void* binning_ws, size_t binning_bytes,
+                                void* image_ws, size_t image_bytes,
+                                void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                                const float* base_color, float* out_color,
+                                float* out_alpha_integrated, float* out_color_integrated, void* stream);
+
 /* ---- mark_visible (replaces _C.mark_visible, rasterize_points.cu:213-232) -------------- */
 int gof_mark_visible(int32_t P, const float* means3D,
                      const float* viewmatrix, const float* projmatrix,
