@@ -75,6 +75,27 @@ def _worker(rank, world, port, ret):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     ok = ok and sorted(sum(gathered, [])) == views and len(set(map(tuple, gathered))) == world
+    # view-sharded opacity-field evaluation (extract_mesh.py:17-34): identical to the serial loop over all views
+    from dp import evaluate_alpha
+    PN, NV = 4001, 7
+    gp = torch.Generator().manual_seed(5)
+    pts = torch.randn(PN, 3, generator=gp)
+    table_a = torch.rand(NV, PN, generator=gp)
+    table_a[:, :50] = 1.0                                   # points no view sees keep alpha_integrated = 1 (colour stays 1)
+    table_a[3, 100:200] = table_a[1, 100:200]               # exact ties between two views: the first one must win
+    table_c = torch.rand(NV, PN, 3, generator=gp)
+
+    def fake_integrate(points, view):
+        return {"alpha_integrated": table_a[view].clone(), "color_integrated": table_c[view].clone()}
+    views_all = list(range(NV))
+    fa = torch.ones(PN); fc = torch.ones(PN, 3)
+    for v in views_all:                                     # the reference's serial loop
+        a_i = table_a[v]
+        fc = torch.where((a_i < fa).reshape(-1, 1), table_c[v], fc)
+        fa = torch.min(fa, a_i)
+    alpha_dp, color_dp = evaluate_alpha(pts, views_all, fake_integrate, return_color=True)
+    ok = ok and torch.equal(alpha_dp, 1 - fa) and torch.equal(color_dp, fc)
+    ok = ok and torch.equal(evaluate_alpha(pts, views_all, fake_integrate), 1 - fa)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
