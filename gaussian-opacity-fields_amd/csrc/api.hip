@@ -22,6 +22,7 @@ __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const 
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
                                int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out, float4* fconic_out,
                                uint32_t* tiles_touched, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
+template <bool TILED>
 __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
                                const float* dL_dv2g, const float* dL_dcolor, float* dL_dmeans, float* dL_dsh,
@@ -363,13 +364,15 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     const Dims d = dims_of(a);
     const size_t P = (size_t)a->P;
     // torch::zeros of the binding (rasterize_points.cu:161-170): required, K8 accumulates and K9 skips culled Gaussians
+    // preprocess_bwd<true> (SH rows tiled through LDS) writes every element of dL_dsh itself: no memset for it
+    const bool k9_tiled = a->shs && dL_dsh && a->M == 16 && ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     { GOF_PROFILE("backward_memsets", stream);
     GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans2D, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dcolors, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans3D, 0, 3 * P * sizeof(float), stream));
     if (dL_dcov3D) GOF_HIP_CHECK(hipMemsetAsync(dL_dcov3D, 0, 6 * P * sizeof(float), stream));
-    if (dL_dsh && a->M > 0) GOF_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, 3 * P * (size_t)a->M * sizeof(float), stream));
+    if (dL_dsh && a->M > 0 && !k9_tiled) GOF_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, 3 * P * (size_t)a->M * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dscales, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_drotations, 0, 4 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dview2gaussian, 0, 10 * P * sizeof(float), stream)); }
@@ -383,9 +386,12 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     }
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     GOF_PROFILE("preprocess_bwd", stream);
-    hipLaunchKernelGGL(preprocess_bwd, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
-                       g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales,
-                       dL_drotations);
+    if (k9_tiled)
+        hipLaunchKernelGGL(preprocess_bwd<true>, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
+                           g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales, dL_drotations);
+    else
+        hipLaunchKernelGGL(preprocess_bwd<false>, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
+                           g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales, dL_drotations);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }

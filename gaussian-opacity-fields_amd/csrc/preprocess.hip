@@ -439,6 +439,13 @@ __device__ __forceinline__ void sh_backward(int deg, V3 pos, V3 campos, const fl
     dL_dmean_add.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
 }
 
+// TILED (M == 16, 16-byte aligned SH arrays): the 192-byte SH row of a Gaussian is read and its gradient row written with a
+// 192-byte stride between lanes, i.e. every 16-byte access of a wave touches 64 different 64-byte sectors.  The workgroup instead
+// moves its 256 x 192 B tile through LDS with fully coalesced 16-byte accesses (rows padded to 49 floats: conflict-free), each
+// thread works on its own LDS row, and culled Gaussians / coefficients above the active degree leave zeros in the tile -- so the
+// host skips the 192 B/Gaussian memset of dL_dsh as well.
+constexpr int K9_ROW = 49;
+template <bool TILED>
 __global__ void __launch_bounds__(256)
 preprocess_bwd(int P, int D, int M,
                const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
@@ -447,7 +454,23 @@ preprocess_bwd(int P, int D, int M,
                float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drots)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    __shared__ float s_sh[TILED ? 256 * K9_ROW : 1];
+    const int b0 = blockIdx.x * 256;
+    const int rows = min(256, P - b0);
+    if (TILED) {
+        const float4* src = reinterpret_cast<const float4*>(shs + (size_t)b0 * 48);
+        for (int i = threadIdx.x; i < rows * 12; i += 256) {
+            const float4 v = src[i];
+            const int f = i * 4, g = f / 48, k = f - g * 48;
+            float* d = &s_sh[g * K9_ROW + k];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    const bool visible = idx < P && radii[idx] > 0;
+    if (!TILED && !visible) return;
+    float* const my_row = &s_sh[TILED ? threadIdx.x * K9_ROW : 0];
+    if (visible) {
     const V3 mean = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
     const V3 scale = { scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
     const float4 rot = reinterpret_cast<const float4*>(rotations)[idx];
@@ -519,13 +542,39 @@ preprocess_bwd(int P, int D, int M,
         const V3 campos = { cam.campos[0], cam.campos[1], cam.campos[2] };
         const V3 dL_dRGB = { dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2] };
         V3 addm;
-        sh_backward(D, mean, campos, shs + (size_t)idx * M * 3, clamped[idx], dL_dRGB, dL_dsh + (size_t)idx * M * 3, M, addm);
+        if (TILED) {
+            float shr[48];                              // this Gaussian's coefficients: LDS row -> registers (static indices)
+            const int nco = 3 * (D + 1) * (D + 1);
+#pragma unroll
+            for (int k = 0; k < 48; k++) shr[k] = (k < nco) ? my_row[k] : 0.0f;
+            sh_backward(D, mean, campos, shr, clamped[idx], dL_dRGB, my_row, M, addm);
+            for (int k = nco; k < 48; k++) my_row[k] = 0.0f;                 // coefficients above the active degree
+        } else {
+            sh_backward(D, mean, campos, shs + (size_t)idx * M * 3, clamped[idx], dL_dRGB, dL_dsh + (size_t)idx * M * 3, M, addm);
+        }
         dmean = dmean + addm;
     }
     dL_dmeans[3 * idx + 0] = dmean.x;
     dL_dmeans[3 * idx + 1] = dmean.y;
     dL_dmeans[3 * idx + 2] = dmean.z;
+    } else if (TILED && idx < P) {
+#pragma unroll
+        for (int k = 0; k < 48; k++) my_row[k] = 0.0f;                       // culled Gaussian: zero gradient row
+    }
+    if (TILED) {
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(dL_dsh + (size_t)b0 * 48);
+        for (int i = threadIdx.x; i < rows * 12; i += 256) {
+            const int f = i * 4, g = f / 48, k = f - g * 48;
+            const float* r = &s_sh[g * K9_ROW + k];
+            dst[i] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
 }
+template __global__ void preprocess_bwd<false>(int, int, int, const float*, const int32_t*, const float*, const uint8_t*, const float*, const float*,
+                                               Cam, const float*, const float*, float*, float*, float*, float*);
+template __global__ void preprocess_bwd<true>(int, int, int, const float*, const int32_t*, const float*, const uint8_t*, const float*, const float*,
+                                              Cam, const float*, const float*, float*, float*, float*, float*);
 
 // ---------------------------------------------------------------------------------------------------
 // K10: query points (forward.cu:722-766)
