@@ -32,26 +32,52 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-// one thread per depth-sorted Gaussian (replaces duplicateWithKeys, rasterizer_impl.cu:70-111)
+// Instance emission in depth order (replaces duplicateWithKeys, rasterizer_impl.cu:70-111).  Lane = depth-sorted Gaussian for the
+// set-up (rectangle, count, first output slot), then the WAVE writes its Gaussians' instances cooperatively: output slot p of the
+// wave's contiguous range belongs to the lane o with off[o] <= p < off[o] + cnt[o] (6-step binary search over the lanes' offsets
+// with ds_bpermute), entry k = p - off[o] is tile (miny + k / w, minx + k % w): 64 consecutive slots per store instruction instead
+// of 64 slots scattered ~10 entries apart.
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const SplatRec* __restrict__ rec,
                const int32_t* __restrict__ radii, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t gy)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t idx = order[i];
-    const int r = radii[idx];
-    if (r > 0) {
-        uint32_t off = order_off[i];
-        const float px = rec[idx].f[REC_XY], py = rec[idx].f[REC_XY + 1];
-        uint32_t minx, miny, maxx, maxy;
-        get_rect(px, py, r, minx, miny, maxx, maxy, gx, gy);
-        for (uint32_t y = miny; y < maxy; y++)
-            for (uint32_t x = minx; x < maxx; x++) {
-                tiles[off] = y * gx + x;
-                gids[off] = idx;
-                off++;
-            }
+    const int lane = threadIdx.x & 63;
+    uint32_t idx = 0, off = 0, cnt = 0, minx = 0, miny = 0, w = 1;
+    if (i < P) {
+        idx = order[i];
+        off = order_off[i];
+        const int r = radii[idx];
+        if (r > 0) {
+            uint32_t maxx, maxy;
+            get_rect(rec[idx].f[REC_XY], rec[idx].f[REC_XY + 1], r, minx, miny, maxx, maxy, gx, gy);
+            w = maxx - minx;
+            cnt = w * (maxy - miny);
+        }
+    }
+    // the wave's output range [first, first + total): offsets are an exclusive scan in this order, so they are contiguous
+    const uint32_t first = __shfl(off, 0);
+    const uint32_t last_off = __shfl(off, 63), last_cnt = __shfl(cnt, 63);
+    // lanes past P (last wave only) carry off = 0: give them the end of the range so the search never selects them
+    const int valid_lanes = min(64, P - (i - lane));
+    const uint32_t end = __shfl(off, valid_lanes - 1) + __shfl(cnt, valid_lanes - 1);
+    if (i >= P) off = end;
+    (void)last_off; (void)last_cnt;
+    for (uint32_t p = first + lane; __ballot(p < end) != 0ull; p += 64) {
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+            const int mid = (lo + hi + 1) >> 1;
+            const uint32_t v = __shfl(off, mid);
+            if (v <= p) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t o_off = __shfl(off, lo), o_w = __shfl(w, lo), o_minx = __shfl(minx, lo), o_miny = __shfl(miny, lo), o_idx = __shfl(idx, lo);
+        if (p < end) {
+            const uint32_t k = p - o_off;
+            const uint32_t y = k / o_w, x = k - y * o_w;
+            tiles[p] = (o_miny + y) * gx + (o_minx + x);
+            gids[p] = o_idx;
+        }
     }
 }
 
