@@ -363,18 +363,16 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
     const Dims d = dims_of(a);
     const size_t P = (size_t)a->P;
-    // torch::zeros of the binding (rasterize_points.cu:161-170): required, K8 accumulates and K9 skips culled Gaussians
+    // torch::zeros of the binding (rasterize_points.cu:161-170): needed for what blend_backward ACCUMULATES into and for the dead
+    // dL_dcov3D; preprocess_bwd writes every element of dL_dmeans3D / dL_dscales / dL_drotations (zeros for culled Gaussians)
     // preprocess_bwd<true> (SH rows tiled through LDS) writes every element of dL_dsh itself: no memset for it
     const bool k9_tiled = a->shs && dL_dsh && a->M == 16 && ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     { GOF_PROFILE("backward_memsets", stream);
     GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans2D, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dcolors, 0, 3 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans3D, 0, 3 * P * sizeof(float), stream));
     if (dL_dcov3D) GOF_HIP_CHECK(hipMemsetAsync(dL_dcov3D, 0, 6 * P * sizeof(float), stream));
     if (dL_dsh && a->M > 0 && !k9_tiled) GOF_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, 3 * P * (size_t)a->M * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dscales, 0, 3 * P * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_drotations, 0, 4 * P * sizeof(float), stream));
     GOF_HIP_CHECK(hipMemsetAsync(dL_dview2gaussian, 0, 10 * P * sizeof(float), stream)); }
 
     if (R > 0) {

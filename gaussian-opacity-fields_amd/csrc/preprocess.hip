@@ -468,6 +468,13 @@ preprocess_bwd(int P, int D, int M,
         __syncthreads();
     }
     const bool visible = idx < P && radii[idx] > 0;
+    if (idx < P && !visible) {
+        // culled Gaussian: the reference returns here and relies on the binding's torch::zeros (rasterize_points.cu:161-170); this
+        // kernel owns dL_dmeans / dL_dscales / dL_drots completely, so the host does not memset them
+        dL_dmeans[3 * idx] = 0.0f; dL_dmeans[3 * idx + 1] = 0.0f; dL_dmeans[3 * idx + 2] = 0.0f;
+        dL_dscales[3 * idx] = 0.0f; dL_dscales[3 * idx + 1] = 0.0f; dL_dscales[3 * idx + 2] = 0.0f;
+        reinterpret_cast<float4*>(dL_drots)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (!TILED && !visible) return;
     float* const my_row = &s_sh[TILED ? threadIdx.x * K9_ROW : 0];
     if (visible) {

@@ -1,17 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED|^E  " | cut -c1-250 | head -20
-timeout 600 python bench.py --steps 30 --warmup 5 > gpurun_out/bench7.json 2> gpurun_out/bench7.err
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof7 -o r7 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-loop > $R/gpurun_out/prof7.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc7_$c -o p -- python $R/tests/devtools/dev_pmc.py > $R/gpurun_out/pmc7_$c.log 2>&1
-done
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc7_valu -o p -- python $R/tests/devtools/dev_pmc.py > $R/gpurun_out/pmc7_valu.log 2>&1
-cd $R; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench7.json'))
-print(d["value"], d["ms_per_step"], d["full_loop"]["ms_per_iter"], {k:v["avg_ms"] for k,v in d["roofline"]["kernels"].items()})
-print(d["roofline"]["frac"], d["roofline"].get("valu_issue_frac"), d["cpu_baseline"])
-PY
+timeout 2400 python -m pytest tests/test_parity_gpu.py tests/test_reference_gpu.py tests/test_host_api.py -m gpu -q -k "not integrate and not config5" 2>&1 | tail -1
+timeout 300 python tests/devtools/dev_time.py 2>&1 | tail -1 | cut -c1-330
