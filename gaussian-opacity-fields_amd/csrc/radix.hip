@@ -263,8 +263,163 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
 }
 
 uint32_t rs_units(size_t n) { return (uint32_t)((n + RS_BLOCK - 1) / RS_BLOCK); }   // blocks
-// u32 words of scratch: [256 * units] histogram + scan scratch
-size_t rs_tmp_words(size_t n) { const size_t h = (size_t)RS_DIGITS * rs_units(n); return h + scan_tmp_words(h) + 64; }
+
+// ---------------------------------------------------------------------------------------------------
+// "onesweep" passes: ONE kernel per digit instead of histogram + 3 scan kernels + scatter.
+//   os_hist      -- one read of the keys builds the global digit histograms of ALL passes (LDS atomics, then 256 global atomics
+//                   per block and pass); os_scan_hist turns each into exclusive digit bases.
+//   os_pass      -- a block takes a ticket (logical tile id = scheduling order, so every predecessor is resident), ranks its tile
+//                   exactly like rs_scatter, publishes its per-digit counts as (AGGREGATE | count) descriptors, thread d walks the
+//                   predecessors' descriptors of digit d backwards until it meets an inclusive PREFIX (decoupled look-back),
+//                   publishes its own PREFIX, and scatters.  Per pass the keys/values are read once and written once.
+// A block only ever waits for blocks with smaller tickets, which never wait for it: no deadlock.  The poll loop is bounded all
+// the same (OS_SPIN_LIMIT): on expiry it raises a device flag and carries on with a wrong offset instead of hanging the GPU.
+// ---------------------------------------------------------------------------------------------------
+constexpr int OS_MAX_PASSES = 4;
+constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VALUE = (1u << 30) - 1u;
+constexpr uint32_t OS_SPIN_LIMIT = 1u << 18;
+constexpr uint32_t OS_MAX_UNITS = 512;                       // tiles of RS_BLOCK items: up to 2M pairs
+constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
+
+__global__ void __launch_bounds__(256)
+os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase)
+{
+    __shared__ uint32_t s_h[OS_MAX_PASSES][RS_DIGITS];
+    for (int p = 0; p < npass; p++) s_h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t k = keys[i];
+        for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(k >> (8 * p)) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    for (int p = 0; p < npass; p++) {
+        const uint32_t c = s_h[p][threadIdx.x];
+        if (c) atomicAdd(&gbase[p * RS_DIGITS + threadIdx.x], c);
+    }
+}
+__global__ void __launch_bounds__(256)
+os_scan_hist(uint32_t* __restrict__ gbase, int npass)
+{
+    __shared__ uint32_t s_wave[4];
+    for (int p = 0; p < npass; p++) {
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(gbase[p * RS_DIGITS + threadIdx.x], &total, s_wave);
+        gbase[p * RS_DIGITS + threadIdx.x] = ex;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+        uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ desc,
+        uint32_t* __restrict__ ticket, uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
+    __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
+    __shared__ uint32_t s_gbase[RS_DIGITS];      // global start of this block's run of every digit
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_key[RS_BLOCK];
+    __shared__ uint32_t s_val[RS_BLOCK];
+    __shared__ uint32_t s_tile;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_cur[wave][lane + 64 * k] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t blk_begin = tile * RS_BLOCK;
+    const uint32_t begin = blk_begin + wave * RS_CHUNK;
+
+    uint32_t key[RS_STEPS], val[RS_STEPS];
+    uint16_t rnk[RS_STEPS], cnt[RS_STEPS];       // rank among same-digit lanes of the step; group size (leader only)
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
+        const uint32_t i = begin + s * 64 + lane;
+        key[s] = 0xFFFFFFFFu; val[s] = 0;
+        if (i < n) { key[s] = keys_in[i]; val[s] = vals_in[i]; }
+    }
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
+        const uint32_t i = begin + s * 64 + lane;
+        const bool ok = i < n;
+        const uint64_t valid = __ballot(ok);
+        const uint32_t d = (key[s] >> shift) & 0xFFu;
+        const uint64_t peers = match_digit(d, valid);
+        const uint32_t r = (uint32_t)__popcll(peers & lt);
+        const uint32_t c = (uint32_t)__popcll(peers);
+        rnk[s] = (uint16_t)r;
+        cnt[s] = (uint16_t)((ok && r == 0) ? c : 0);
+        if (ok && r == 0) s_cur[wave][d] += c;
+    }
+    __syncthreads();
+    {   // digit d = threadIdx.x: counts of the 4 waves -> publish, look back, cursors
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = s_cur[0][d], c1 = s_cur[1][d], c2 = s_cur[2][d], c3 = s_cur[3][d];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t* my = desc + (size_t)tile * RS_DIGITS + d;
+        uint32_t excl = 0;
+        if (tile > 0) {
+            __hip_atomic_store(my, OS_FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int j = (int)tile - 1;
+            uint32_t spins = 0;
+            while (j >= 0) {
+                const uint32_t v = __hip_atomic_load(desc + (size_t)j * RS_DIGITS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 30) == 0u) {
+                    ++spins;
+                    if (spins > OS_SPIN_LIMIT || ((spins & 1023u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        atomicExch(err, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += v & OS_VALUE;
+                if (v & OS_FLAG_PREFIX) break;
+                j--;
+                spins = 0;
+            }
+        }
+        __hip_atomic_store(my, OS_FLAG_PREFIX | ((excl + tot) & OS_VALUE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t blk_total;
+        const uint32_t start = block_exclusive_scan(tot, &blk_total, s_scan);
+        s_bstart[d] = start;
+        s_gbase[d] = gbase[d] + excl;
+        s_cur[0][d] = start; s_cur[1][d] = start + c0; s_cur[2][d] = start + c0 + c1; s_cur[3][d] = start + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
+        const uint32_t i = begin + s * 64 + lane;
+        const bool ok = i < n;
+        const uint32_t d = (key[s] >> shift) & 0xFFu;
+        const uint32_t base = ok ? s_cur[wave][d] : 0u;              // all lanes of a digit group read the same cursor
+        if (cnt[s]) s_cur[wave][d] = base + cnt[s];                 // the group's lowest lane advances it
+        if (ok) { s_key[base + rnk[s]] = key[s]; s_val[base + rnk[s]] = val[s]; }
+    }
+    __syncthreads();
+    const uint32_t blk_n = min((uint32_t)RS_BLOCK, n - blk_begin);
+#pragma unroll
+    for (int j = 0; j < RS_BLOCK / 256; j++) {
+        const uint32_t p = j * 256 + threadIdx.x;
+        if (p < blk_n) {
+            const uint32_t k = s_key[p];
+            const uint32_t d = (k >> shift) & 0xFFu;
+            const uint32_t g = s_gbase[d] + (p - s_bstart[d]);
+            keys_out[g] = k;
+            vals_out[g] = s_val[p];
+        }
+    }
+}
+
+// u32 words of scratch: header (digit bases of 4 passes, tickets, error flag) + one descriptor per (pass, block, digit); never
+// smaller than what the three-kernel fallback needs
+size_t rs_tmp_words(size_t n)
+{
+    const size_t h = (size_t)RS_DIGITS * rs_units(n);
+    const size_t onesweep = (size_t)OS_HDR + (size_t)OS_MAX_PASSES * h;
+    const size_t classic = h + scan_tmp_words(h) + 64;
+    return onesweep > classic ? onesweep : classic;
+}
 
 // Stable sort of (key, value) pairs on key bits [0, end_bit), 8 bits per pass.  Buffers a* hold the input; the
 // result ends up in (*keys_res, *vals_res), which alias either a* or b*.
@@ -272,12 +427,37 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream)
 {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
-    if (n > 0) {
+    const int npass = (end_bit + 7) / 8;
+    if (n > 0 && npass > 0) {
         const uint32_t nunits = rs_units(n);
         const size_t hwords = (size_t)RS_DIGITS * nunits;
+        const dim3 grid(nunits), block(256);
+#ifndef GOF_RS_CLASSIC
+        // measured on MI355X: 1M pairs x 4 passes 0.142 -> 0.107 ms, but 8.8M pairs x 2 passes 0.178 -> 0.199 ms (with ~1000 resident
+        // blocks the look-back chains get long): the single-kernel passes are used where launch latency dominates
+        if (nunits <= OS_MAX_UNITS && npass <= OS_MAX_PASSES) {
+            uint32_t* gbase = tmp;
+            uint32_t* tickets = tmp + OS_MAX_PASSES * RS_DIGITS;
+            uint32_t* err = tickets + 8;
+            uint32_t* desc = tmp + OS_HDR;
+            hipError_t e = hipMemsetAsync(tmp, 0, ((size_t)OS_HDR + (size_t)npass * hwords) * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase);
+            hipLaunchKernelGGL(os_scan_hist, dim3(1), block, 0, stream, gbase, npass);
+            for (int p = 0; p < npass; p++) {
+                hipLaunchKernelGGL(os_pass, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, 8 * p, gbase + p * RS_DIGITS,
+                                   desc + (size_t)p * hwords, tickets + p, err);
+                uint32_t* t;
+                t = ki; ki = ko; ko = t;
+                t = vi; vi = vo; vo = t;
+            }
+            *keys_res = ki;
+            *vals_res = vi;
+            return hipGetLastError();
+        }
+#endif
         uint32_t* hist = tmp;
         uint32_t* scan_tmp = tmp + hwords;
-        const dim3 grid(nunits), block(256);
         for (int shift = 0; shift < end_bit; shift += 8) {
             hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits);
             hipError_t e = device_scan_u32(hist, nullptr, hist, hwords, false, scan_tmp, nullptr, stream);
