@@ -160,7 +160,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     alg_bytes = {                                                    # SURVEY.md 8(d) per-unit figures x units
         "preprocess_fwd": P * (236 + 119),
         "scan_tiles": 8 * P,
-        "sort_gaussians_by_depth": 4 * 16 * P + 4 * 4 * P,           # 4 passes: 8 B read + 8 B written, + histogram read
+        "sort_gaussians_by_depth": 4 * 16 * P + 4 * P,               # 4 passes: 8 B read + 8 B written; one histogram read for all passes
         "emit_instances": 24 * P + 8 * R,
         "sort_instances_by_tile": tile_passes * (16 * R + 4 * R),     # per pass: 8 B read + 8 B written, + histogram read
         "tile_ranges": 8 * R + 8 * gx * gy,
