@@ -37,13 +37,13 @@ hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* ou
                            const uint32_t** total_dev_out, hipStream_t stream);
 size_t rs_tmp_words(size_t n);
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
-                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream);
+                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 int radix_passes(int end_bit);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const SplatRec* rec, const int32_t* radii,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t gy);
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t gy, uint32_t capacity);
 __global__ void point_keys(int PN, const float2* points2D, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
-__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift);
+__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev);
 __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* gids, const float* depths, uint64_t* keys);
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H,
@@ -206,19 +206,21 @@ static inline Dims dims_of(const GofRasterArgs* a)
 
 // Sort (tile, id) instances by tile; the instances were emitted into the buffer pair chosen so that the
 // result of the final pass lands in (b.tiles, b.vals).
-static int sort_by_tile(const BinWs& b, uint32_t n, uint32_t* tiles_in, uint32_t* vals_in, int tile_bits, hipStream_t stream)
+static int sort_by_tile(const BinWs& b, uint32_t n, uint32_t* tiles_in, uint32_t* vals_in, int tile_bits, hipStream_t stream,
+                        const uint32_t* n_dev = nullptr)
 {
     uint32_t* tiles_other = (tiles_in == b.tiles) ? b.tiles_alt : b.tiles;
     uint32_t* vals_other = (vals_in == b.vals) ? b.vals_alt : b.vals;
     uint32_t *kr = nullptr, *vr = nullptr;
-    GOF_HIP_CHECK(radix_sort_pairs_u32(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream));
+    GOF_HIP_CHECK(radix_sort_pairs_u32(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev));
     if (kr != b.tiles || vr != b.vals) { set_error("internal: sort result in the wrong buffer"); return GOF_E_DEVICE; }
     return GOF_OK;
 }
 
 // instance emission in depth order + tile sort + tile ranges, shared by forward and integrate
+// n_dev (nullable): the instance count is only known on the device; R is then the CAPACITY of the binning workspace
 static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, const GeomWs& g, const BinWs& b, const ImageWs& im,
-                         const int32_t* radii, hipStream_t stream)
+                         const int32_t* radii, hipStream_t stream, const uint32_t* n_dev = nullptr)
 {
     const int dbg = a->debug;
     const int tile_bits = (int)higher_msb(d.ntiles);
@@ -228,17 +230,17 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
         { GOF_PROFILE("emit_instances", stream);
         hipLaunchKernelGGL(emit_instances, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.dval_a, g.order_off, g.rec, radii,
-                           t_in, v_in, d.gx, d.gy); }
+                           t_in, v_in, d.gx, d.gy, R); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
-        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream);
+        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev);
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
-        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0);
+        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev);
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     return GOF_OK;
@@ -259,23 +261,11 @@ size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H) { return bin_layout(R
 size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_layout(NI, W, H, nullptr, nullptr, false) + ALIGN; }
 size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
 
-int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
-                        int32_t* radii, uint32_t* num_rendered_host, void* stream_)
+// preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
+static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    int rc = validate(a);
-    if (rc) return rc;
-    if (!num_rendered_host) { set_error("num_rendered_host is NULL"); return GOF_E_INVALID; }
-    *num_rendered_host = 0;
-    if (a->P == 0) return GOF_OK;
-    if (!radii || !geom_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P)) { set_error("geometry workspace too small: %zu < %zu", geom_bytes, gof_geom_bytes(a->P)); return GOF_E_WORKSPACE; }
-    if (image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace too small"); return GOF_E_WORKSPACE; }
-    GeomWs g;
-    geom_layout(a->P, aligned_base(geom_ws), &g);
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
-
     GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));
     { GOF_PROFILE("preprocess_fwd", stream);
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
@@ -291,11 +281,30 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)
-    const uint32_t* total_dev = nullptr;
     { GOF_PROFILE("scan_tiles", stream);
     GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, g.dval_a, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
-                                  &total_dev, stream)); }
+                                  total_dev_out, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
+    return GOF_OK;
+}
+
+int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
+                        int32_t* radii, uint32_t* num_rendered_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!num_rendered_host) { set_error("num_rendered_host is NULL"); return GOF_E_INVALID; }
+    *num_rendered_host = 0;
+    if (a->P == 0) return GOF_OK;
+    if (!radii || !geom_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P)) { set_error("geometry workspace too small: %zu < %zu", geom_bytes, gof_geom_bytes(a->P)); return GOF_E_WORKSPACE; }
+    if (image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace too small"); return GOF_E_WORKSPACE; }
+    GeomWs g;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    const uint32_t* total_dev = nullptr;
+    rc = forward_stage1(a, g, radii, &total_dev, stream);
+    if (rc) return rc;
     // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
     uint32_t host_words[2] = { 0, 0 };
     GOF_HIP_CHECK(hipMemcpyAsync(&host_words[0], total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -306,6 +315,54 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     if (a->prefiltered && host_words[1]) {
         set_error("Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:193-197
         return GOF_E_PREFILTER;
+    }
+    return GOF_OK;
+}
+
+// The whole forward without a pipeline bubble: the binning workspace is sized for `capacity` instances chosen by the caller (e.g.
+// 1.25 x the count of the previous frame); every launch after the scan is sized for the capacity and reads the actual count on the
+// device; the count is copied to PINNED host memory right after the scan and the host waits for THAT event only -- ~0.3 ms into
+// the call, with emission, tile sort and the blend already queued behind it.  If the count exceeds the capacity the call returns
+// GOF_E_CAPACITY (nothing was written out of bounds) and the caller redoes the frame through gof_forward_prepare/render.
+int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes,
+                      void* image_ws, size_t image_bytes, int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!num_rendered_pinned_host || !out_color) { set_error("num_rendered_pinned_host / out_color is NULL"); return GOF_E_INVALID; }
+    if (a->P == 0 || a->prefiltered || a->debug) { set_error("gof_forward_fused: empty / prefiltered / debug calls use gof_forward_prepare + gof_forward_render"); return GOF_E_INVALID; }
+    if (!radii || !geom_ws || !binning_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(capacity, a->W, a->H)) {
+        set_error("workspace too small (geom %zu, image %zu, binning %zu)", geom_bytes, image_bytes, binning_bytes); return GOF_E_WORKSPACE; }
+    GeomWs g; ImageWs im; BinWs b;
+    geom_layout(a->P, aligned_base(geom_ws), &g);
+    image_layout(a->W, a->H, aligned_base(image_ws), &im);
+    bin_layout(capacity, a->W, a->H, aligned_base(binning_ws), &b, true);
+    const Dims d = dims_of(a);
+    const uint32_t* total_dev = nullptr;
+    rc = forward_stage1(a, g, radii, &total_dev, stream);
+    if (rc) return rc;
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *num_rendered_pinned_host = 0xFFFFFFFFu;
+    GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipEventRecord(ev, stream));
+    if (capacity > 0) {
+        rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
+        if (rc) return rc;
+    } else {
+        GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
+    }
+    { GOF_PROFILE("blend_forward", stream);
+    hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                       im.ranges, b.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
+    GOF_LAUNCH_CHECK(stream, 0);
+    GOF_HIP_CHECK(hipEventSynchronize(ev));
+    if (*num_rendered_pinned_host > capacity) {
+        set_error("instance count %u exceeds the capacity %u of the binning workspace", *num_rendered_pinned_host, capacity);
+        return GOF_E_CAPACITY;
     }
     return GOF_OK;
 }
@@ -517,7 +574,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.point_ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (NI > 0) {
-        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8);
+        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr);
         GOF_LAUNCH_CHECK(stream, a->debug);
         hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.points2D, w.depths, pb.pt_xy, pb.pt_depth);
         GOF_LAUNCH_CHECK(stream, a->debug);

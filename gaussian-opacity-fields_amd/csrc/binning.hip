@@ -39,7 +39,8 @@ uint32_t higher_msb(uint32_t n)
 // of 64 slots scattered ~10 entries apart.
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const SplatRec* __restrict__ rec,
-               const int32_t* __restrict__ radii, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t gy)
+               const int32_t* __restrict__ radii, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t gy,
+               uint32_t capacity)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -72,7 +73,7 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
             if (v <= p) lo = mid; else hi = mid - 1;
         }
         const uint32_t o_off = __shfl(off, lo), o_w = __shfl(w, lo), o_minx = __shfl(minx, lo), o_miny = __shfl(miny, lo), o_idx = __shfl(idx, lo);
-        if (p < end) {
+        if (p < end && p < capacity) {                 // capacity < the instance count only in the sync-free forward (then redone)
             const uint32_t k = p - o_off;
             const uint32_t y = k / o_w, x = k - y * o_w;
             tiles[p] = (o_miny + y) * gx + (o_minx + x);
@@ -118,8 +119,9 @@ gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const
 
 // replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before
 __global__ void __launch_bounds__(256)
-tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges, int shift)
+tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges, int shift, const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) L = min(L, *n_dev);
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
     const uint32_t currtile = tiles[idx] >> shift;

@@ -25,7 +25,7 @@ constexpr int KNN_BOX = 256;
 constexpr int KNN_GROUP = 32;     // boxes per group
 
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
-                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream);
+                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 size_t rs_tmp_words(size_t n);
 
 struct KnnBox { float lo[3]; float hi[3]; float pad[2]; };

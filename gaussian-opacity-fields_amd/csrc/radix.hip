@@ -164,8 +164,10 @@ constexpr int RS_STEPS = RS_CHUNK / 64;              // steps of 64 items per wa
 constexpr int RS_BLOCK = 4 * RS_CHUNK;               // items per block
 
 __global__ void __launch_bounds__(256)
-rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblocks)
+rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblocks,
+        const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) n = min(n, *n_dev);            // device-side item count (sync-free forward): n is then the capacity
     __shared__ uint32_t s_cnt[4][RS_DIGITS];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -190,8 +192,10 @@ rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __re
 // cursors), exchanged through LDS into digit-sorted order and written out as contiguous runs per digit.
 __global__ void __launch_bounds__(256)
 rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-           uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblocks)
+           uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblocks,
+           const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
     __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
     __shared__ uint32_t s_gbase[RS_DIGITS];      // global start of this block's run of every digit
@@ -248,7 +252,7 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         if (ok) { s_key[base + rnk[s]] = key[s]; s_val[base + rnk[s]] = val[s]; }
     }
     __syncthreads();
-    const uint32_t blk_n = min((uint32_t)RS_BLOCK, n - blk_begin);
+    const uint32_t blk_n = blk_begin < n ? min((uint32_t)RS_BLOCK, n - blk_begin) : 0u;   // tiles past a device-side count are empty
 #pragma unroll
     for (int j = 0; j < RS_BLOCK / 256; j++) {
         const uint32_t p = j * 256 + threadIdx.x;
@@ -282,8 +286,9 @@ constexpr uint32_t OS_MAX_UNITS = 512;                       // tiles of RS_BLOC
 constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
 
 __global__ void __launch_bounds__(256)
-os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase)
+os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase, const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t s_h[OS_MAX_PASSES][RS_DIGITS];
     for (int p = 0; p < npass; p++) s_h[p][threadIdx.x] = 0;
     __syncthreads();
@@ -311,8 +316,9 @@ os_scan_hist(uint32_t* __restrict__ gbase, int npass)
 __global__ void __launch_bounds__(256)
 os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
         uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ desc,
-        uint32_t* __restrict__ ticket, uint32_t* __restrict__ err)
+        uint32_t* __restrict__ ticket, uint32_t* __restrict__ err, const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
     __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
     __shared__ uint32_t s_gbase[RS_DIGITS];      // global start of this block's run of every digit
@@ -397,7 +403,7 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
         if (ok) { s_key[base + rnk[s]] = key[s]; s_val[base + rnk[s]] = val[s]; }
     }
     __syncthreads();
-    const uint32_t blk_n = min((uint32_t)RS_BLOCK, n - blk_begin);
+    const uint32_t blk_n = blk_begin < n ? min((uint32_t)RS_BLOCK, n - blk_begin) : 0u;   // tiles past a device-side count are empty
 #pragma unroll
     for (int j = 0; j < RS_BLOCK / 256; j++) {
         const uint32_t p = j * 256 + threadIdx.x;
@@ -422,9 +428,10 @@ size_t rs_tmp_words(size_t n)
 }
 
 // Stable sort of (key, value) pairs on key bits [0, end_bit), 8 bits per pass.  Buffers a* hold the input; the
-// result ends up in (*keys_res, *vals_res), which alias either a* or b*.
+// result ends up in (*keys_res, *vals_res), which alias either a* or b*.  n_dev (nullable): the item count lives on the device
+// (sync-free forward); n is then the CAPACITY the launches are sized for and every kernel clamps to min(n, *n_dev).
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
-                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream)
+                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev)
 {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     const int npass = (end_bit + 7) / 8;
@@ -442,11 +449,11 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
             uint32_t* desc = tmp + OS_HDR;
             hipError_t e = hipMemsetAsync(tmp, 0, ((size_t)OS_HDR + (size_t)npass * hwords) * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase);
+            hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase, n_dev);
             hipLaunchKernelGGL(os_scan_hist, dim3(1), block, 0, stream, gbase, npass);
             for (int p = 0; p < npass; p++) {
                 hipLaunchKernelGGL(os_pass, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, 8 * p, gbase + p * RS_DIGITS,
-                                   desc + (size_t)p * hwords, tickets + p, err);
+                                   desc + (size_t)p * hwords, tickets + p, err, n_dev);
                 uint32_t* t;
                 t = ki; ki = ko; ko = t;
                 t = vi; vi = vo; vo = t;
@@ -459,10 +466,10 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
         uint32_t* hist = tmp;
         uint32_t* scan_tmp = tmp + hwords;
         for (int shift = 0; shift < end_bit; shift += 8) {
-            hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits);
+            hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits, n_dev);
             hipError_t e = device_scan_u32(hist, nullptr, hist, hwords, false, scan_tmp, nullptr, stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(rs_scatter, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, shift, hist, nunits);
+            hipLaunchKernelGGL(rs_scatter, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, shift, hist, nunits, n_dev);
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;

@@ -49,6 +49,8 @@ def _load():
         f.argtypes = args
     lib.gof_forward_prepare.argtypes = [A, vp, sz, vp, sz, vp, C.POINTER(u32), vp]
     lib.gof_forward_render.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
+    lib.gof_forward_fused.restype = C.c_int
     lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 9 + [vp, sz, vp]
     lib.gof_integrate_prepare_points.argtypes = [A, i32, vp, vp, sz, C.POINTER(u32), vp]
     lib.gof_integrate_run.argtypes = [A, u32, vp, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
@@ -162,23 +164,61 @@ def _prepare_and_bin(v):
     return geom, img, binning, radii, rendered
 
 
+GOF_E_CAPACITY = -5
+FUSED_FORWARD = os.environ.get("GOF_FUSED_FORWARD", "1") != "0"
+_capacity = {}          # (device, P, W, H) -> instance capacity learnt from earlier frames
+_pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
+
+
+def _round_capacity(n):
+    return (int(n * 1.25) + (1 << 16)) & ~0xFFFF
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
-                        image_height, image_width, sh, degree, campos, prefiltered, debug):
+                        image_height, image_width, sh, degree, campos, prefiltered, debug, fused=None):
     """Replaces ``_C.rasterize_gaussians`` (RasterizeGaussiansCUDA, rasterize_points.cu:36-122).
-    Returns ``(num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer)``."""
+    Returns ``(num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer)``.
+
+    The first frame of a (device, P, W, H) shape runs the reference's two-stage forward (instance count read back in the middle to
+    size the binning buffer).  Later frames size that buffer for 1.25 x the last count and run ``gof_forward_fused`` -- no pipeline
+    bubble; the returned ``num_rendered`` is then the CAPACITY (it fixes the workspace layout for the backward); a frame that
+    needs more is redone through the two-stage path, transparently.  ``fused=False`` / ``GOF_FUSED_FORWARD=0`` disable this."""
     v = _View(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, view2gaussian_precomp,
               viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh,
               degree, campos, prefiltered, debug)
+    use_fused = FUSED_FORWARD if fused is None else bool(fused)
     with torch.cuda.device(v.device):
         out_color = torch.empty((OUTPUT_CHANNELS, v.H, v.W), dtype=torch.float32, device=v.device)
         if v.P == 0:
             out_color.zero_()
             empty = v.bytes_tensor(0)
             return 0, out_color, torch.zeros(0, dtype=torch.int32, device=v.device), empty, empty.clone(), empty.clone()
+        shape_key = (str(v.device), v.P, v.W, v.H)
+        cap = _capacity.get(shape_key) if (use_fused and not prefiltered and not debug) else None
+        if cap is not None:
+            geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
+            img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
+            binning = v.bytes_tensor(lib.gof_binning_bytes(cap, v.W, v.H))
+            radii = torch.zeros(v.P, dtype=torch.int32, device=v.device)
+            pin = _pinned.get(str(v.device))
+            if pin is None:
+                pin = _pinned[str(v.device)] = torch.zeros(4, dtype=torch.int32).pin_memory()
+            rc = lib.gof_forward_fused(v.ref(), cap, _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+                                       _ptr(radii), _ptr(out_color), C.c_void_p(pin.data_ptr()), _stream())
+            if rc == 0:
+                true_r = int(pin[0].item()) & 0xFFFFFFFF
+                if _round_capacity(true_r) > cap:
+                    _capacity[shape_key] = _round_capacity(true_r)        # growing scene: stay ahead of it
+                return cap, out_color, radii, geom, binning, img
+            if rc != GOF_E_CAPACITY:
+                _check(rc)
+            del geom, img, binning, radii                                     # too small: redo the frame below with the exact count
         geom, img, binning, radii, rendered = _prepare_and_bin(v)
         _check(lib.gof_forward_render(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                       _ptr(img), img.numel(), _ptr(out_color), _stream()))
+        if use_fused and not prefiltered and not debug:
+            _capacity[shape_key] = max(_capacity.get(shape_key, 0), _round_capacity(rendered))
     return rendered, out_color, radii, geom, binning, img
 
 

@@ -40,6 +40,7 @@ extern "C" {
 #define GOF_E_WORKSPACE  -2   /* a workspace is smaller than the gof_*_bytes() query  */
 #define GOF_E_DEVICE     -3   /* HIP runtime error (text in gof_last_error())         */
 #define GOF_E_PREFILTER  -4   /* prefiltered=1 but a Gaussian was culled (debug only) */
+#define GOF_E_CAPACITY   -5   /* gof_forward_fused: more instances than the caller's capacity (redo via prepare/render) */
 
 #define GOF_OUTPUT_CHANNELS 9  /* auxiliary.h:21-24: rgb 0-2, normal 3-5, depth 6, alpha 7, distortion 8 */
 
@@ -111,6 +112,18 @@ int gof_forward_render(const GofRasterArgs* args,
                        void* image_ws, size_t image_bytes,
                        float* out_color,
                        void* stream);
+
+/* The two stages in ONE call without the pipeline bubble of the mid-forward read-back: the caller sizes the
+ * binning workspace for `capacity` instances (e.g. 1.25 x the previous frame's count), every launch after the scan is sized for
+ * the capacity and reads the actual count on the device, the count goes to PINNED host memory right after the scan and the host
+ * waits for that copy only (~0.3 ms into the call, the rest already queued).  Returns GOF_E_CAPACITY -- with nothing written out
+ * of bounds and *num_rendered_pinned_host = the required count -- when the capacity was too small: redo the frame with
+ * gof_forward_prepare / gof_forward_render.  The backward and the introspection calls take `capacity` as their num_rendered
+ * (it fixes the workspace layout).  Not for P == 0, prefiltered or debug calls. */
+int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
+                      void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes,
+                      void* image_ws, size_t image_bytes,
+                      int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, void* stream);
 
 /* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
 /* Scratch the backward needs besides the outputs (accumulators); may be 0. */

@@ -41,7 +41,7 @@ def product_forward_raw(sd, **over):
     args = (sd["bg"], sd["means3D"], colors, sd["opacities"], scales, rot, sd["scale_modifier"], cov, v2g,
             sd["viewmatrix"], sd["projmatrix"], sd["tanfovx"], sd["tanfovy"], sd["kernel_size"], sd["subpixel_offset"],
             sd["H"], sd["W"], sh, sd["sh_degree"], sd["campos"], over.get("prefiltered", False), over.get("debug", False))
-    R, color, radii, geom, binning, img = B.rasterize_gaussians(*args)
+    R, color, radii, geom, binning, img = B.rasterize_gaussians(*args, fused=over.get("fused", False))   # exact num_rendered for the parity checks
     view = B._View(*args)
     return dict(R=R, color=color, radii=radii, geom=geom, binning=binning, img=img, view=view, args=args)
 
