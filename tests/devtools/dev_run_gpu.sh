@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-GOF_FUSED_FORWARD=0 timeout 300 python tests/devtools/dev_event_overhead.py 2>&1 | tail -1
-GOF_FUSED_FORWARD=1 timeout 300 python tests/devtools/dev_event_overhead.py 2>&1 | tail -1
-done
+timeout 600 python -m pytest tests/test_train_epilogue_gpu.py -m gpu -q -x -k "end_to_end_training" 2>&1 | grep -E "passed|failed|^E  " | cut -c1-300 | head
