@@ -5,12 +5,13 @@
 //
 // MI355X design:
 //  * The reference issues 17 global fp32 atomicAdd per contributing (pixel, splat) pair
-//    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave look at the SAME splat at
-//    the same time, so the 17 partial gradients are reduced in three levels:
-//      1. 4 DPP add steps in registers (quad_perm x2, row_half_mirror, row_mirror): every lane of a
-//         16-lane row (= one pixel row of the tile) holds the row sum; no LDS traffic;
-//      2. lanes 15/31/47/63 of each wave add the 4 row sums of all 4 waves into a per-batch LDS
-//         accumulator s_acc[17][256] with ds_add_f32 (<= 16 adds per address per batch);
+//    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave (an 8x8 pixel quadrant) look at the SAME splat
+//    at the same time, so the 17 partial gradients are reduced in three levels:
+//      1. in registers, per 16-lane row (= 8x2 pixels): a TRANSPOSED (butterfly) reduction of 16 of the values -- the
+//         two quad exchange steps halve the number of live values, two row rotations finish -- plus a plain 4-step
+//         DPP sum of the 17th (row_sum16_transposed / row_sum);
+//      2. lanes 0..3 of every row that contributed add their 4 sums each (and lane 15 the 17th) into a per-batch LDS
+//         accumulator s_acc[17][BATCH] with ds_add_f32: 5 LDS instructions per splat instead of 17;
 //      3. after the batch, thread j flushes entry j with ONE global atomic per component and only if
 //         some pixel of the tile contributed: <= 17 atomics per (tile, splat) instead of up to
 //         17 x 256, issued 64 lanes wide.
@@ -19,14 +20,14 @@
 //    skips per pixel, backward.cu:763-765).
 //  * WHICH (pixel, entry) pairs contribute is not re-derived: blend_forward leaves one bit per pixel and
 //    list position (contributor masks, see cmask_base); a wave visits only the entries in which one of
-//    its pixels has the bit set and recomputes alpha for exactly those lanes with the forward's exact
-//    arithmetic.  (The set is the one the reference's backward re-discovers with its position /
+//    its pixels has the bit set.  (The set is the one the reference's backward re-discovers with its position /
 //    alpha-threshold tests, backward.cu:763-805.)
-//  * alpha, T and the contributor bookkeeping use the exact arithmetic of the forward (they decide
-//    WHICH pairs contribute, bit-identically to the forward pass); the gradient formulas downstream
-//    are evaluated in fp32 with hardware rcp/rsq (<= 2 ulp).  The reference itself rounds every
-//    per-pair term to fp32 before its atomicAdd, so this stays inside its own noise floor
-//    (measured: 3e-7 relative to the oracle's double accumulation).
+//  * Since no decision depends on the backward's alpha any more, only its VALUE does: the fp32 prelude (normal, AA, BB)
+//    is kept bit-identical to the forward's -- min_value is ill-conditioned in it -- but the quotient BB/AA is formed as an
+//    fp32 hi + lo pair and min_value from it (pair_exact_backward), exp by v_exp_f32, the transmittance recurrence with
+//    the hardware reciprocal, and the gradient formulas are compiled with FMA contraction (#pragma clang fp contract(fast)
+//    on that block only).  The reference itself rounds every per-pair term to fp32 before its atomicAdd and accumulates
+//    in arbitrary order; measured against the oracle's double accumulation: <= 1.6e-6 of the gradient maximum.
 //
 // Gradient semantics reproduced exactly (they are the training signal): dL_dweight is detached
 // (backward.cu:851-852) so only dL_dmax_t carries the distortion gradient; the alpha channel's

@@ -1,27 +1,26 @@
 // blend_forward.hip -- K7, the tiled forward alpha-blend (replaces renderCUDA, reference
 // forward.cu:409-612).
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile; lane l of wave w owns pixel
-// (x = l % 16, y = 4*w + l / 16) -- the same thread_rank -> pixel map as the reference, so
-// per-pixel results do not depend on the decomposition.
+// One 256-thread workgroup (4 wave64) per 16x16 tile; wave w covers the 8x8 pixel quadrant (w & 1, w >> 1) (tile_pixel):
+// a compact footprint meets fewer splats than the reference's 16x4 strip, and per-pixel results do not depend on the map.
 //
-// MI355X design -- the kernel is VALU-issue bound (fp64 division, exp, fp64 sqrt per pair), and a
-// tile list is ~10x longer than the set of splats that actually reach a given pixel (at S1M a pixel
-// looks at ~300 entries, ~25 contribute).  A lock-step loop makes all 64 pixels of a wave pay the
+// MI355X design -- the kernel is VALU-issue bound (two fp64 divisions and an exp per contributing pair), and a
+// tile list is ~4x longer than the set of splats that actually reach a given pixel (at S1M a wave scans ~420 entries,
+// a pixel keeps ~89 candidates, ~72 contribute).  A lock-step loop makes all 64 pixels of a wave pay the
 // exact path whenever ANY of them needs it.  Instead, per staged batch of 256 entries:
 //
-//   phase 1 (cull scan, wave-uniform over entries): every lane tests its pixel against the entry's
-//     conservative footprint box (4 compares; the box of the alpha >= 1/255 level-set ellipsoid is
-//     computed once per Gaussian in preprocess_fwd, see footprint_bbox) -- if no pixel of the wave is
-//     inside, the entry costs 6 instructions -- then evaluates the fp32 prelude and the error-bounded
-//     cull (pair_certainly_transparent) and records the survivors as a 256-bit mask of ITS pixel in
-//     LDS (s_mask[word][thread]).
+//   phase 1 (cull scan): (a) lane = ENTRY, 64 entries at a time: the entry's conservative footprint box (the box of the
+//     alpha >= 1/255 level-set ellipsoid, computed once per Gaussian in preprocess_fwd, see footprint_bbox) against the
+//     wave's pixel rectangle -> a wave-uniform ballot of the entries that touch the wave at all; (b) lane = PIXEL, scalar
+//     loop over those entries: the pixel's own box test, the fp32 prelude and the error-bounded cull
+//     (pair_certainly_transparent); survivors are recorded as a 256-bit mask of ITS pixel in LDS (s_mask[word][thread]).
 //   phase 2 (per-lane ordered consumption): every lane pops the next set bit of its own mask, reads
 //     that entry's record from LDS with a per-lane address and runs the exact path (fp64 t /
 //     min_value, exp, blend update).  Entries are consumed in ascending list order per pixel, so
 //     the per-pixel operation sequence -- and therefore every output bit -- is unchanged; the number
 //     of heavy iterations of a wave drops from "#entries any pixel passes" to "max #candidates of
-//     one pixel".
+//     one pixel" (~97 at S1M).  The entries that really contributed are written back into the mask and stored to the
+//     binning workspace (contributor masks, cmask_base): the backward visits exactly those.
 //
 //  * tile-list entries are staged as whole 64-byte SplatRec lines (one aligned gather per entry,
 //    colour included; the reference re-reads colour from global memory per contributing pair,
