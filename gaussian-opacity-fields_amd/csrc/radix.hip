@@ -168,24 +168,18 @@ rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __re
         const uint32_t* __restrict__ n_dev)
 {
     if (n_dev) n = min(n, *n_dev);            // device-side item count (sync-free forward): n is then the capacity
-    __shared__ uint32_t s_cnt[4][RS_DIGITS];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; k++) s_cnt[wave][lane + 64 * k] = 0;
-    const uint32_t begin = blockIdx.x * RS_BLOCK + wave * RS_CHUNK;
-#pragma unroll 4
-    for (int s = 0; s < RS_STEPS; s++) {
-        const uint32_t i = begin + s * 64 + lane;
-        const bool ok = i < n;
-        const uint64_t valid = __ballot(ok);
-        if (valid == 0ull) break;
-        const uint32_t d = ok ? ((keys[i] >> shift) & 0xFFu) : 0u;
-        const uint64_t peers = match_digit(d, valid);
-        if (ok && (uint32_t)(__ffsll((long long)peers) - 1) == lane) s_cnt[wave][d] += (uint32_t)__popcll(peers);
-    }
+    // counting only (no ranks needed here): one LDS atomic per item, all 16 loads of a thread in flight together
+    __shared__ uint32_t s_cnt[RS_DIGITS];
+    s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t d = threadIdx.x;
-    hist[(size_t)d * nblocks + blockIdx.x] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
+    const uint32_t begin = blockIdx.x * RS_BLOCK + threadIdx.x;
+    uint32_t k[RS_BLOCK / 256];
+#pragma unroll
+    for (int s = 0; s < RS_BLOCK / 256; s++) { const uint32_t i = begin + s * 256; k[s] = i < n ? keys[i] : 0u; }
+#pragma unroll
+    for (int s = 0; s < RS_BLOCK / 256; s++) { const uint32_t i = begin + s * 256; if (i < n) atomicAdd(&s_cnt[(k[s] >> shift) & 0xFFu], 1u); }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
 // Stable scatter of one block: keys/values are ranked in registers (wave-level multisplit with per-wave LDS
