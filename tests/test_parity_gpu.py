@@ -194,7 +194,7 @@ def test_backward_is_deterministic_enough_and_alpha_channel_ignored():
     for k in g1:
         # atomics accumulate in arbitrary order: blend outputs repeat to ~1e-6; the per-Gaussian stage
         # (means3D / scales / rotations) amplifies that noise by its condition number
-        tol = 1e-5 if k in ("means2D", "colors", "opacity", "view2gaussian", "sh", "cov3D") else 2e-3
+        tol = 1e-5 if k in ("means2D", "colors", "opacity", "view2gaussian", "sh", "cov3D") else 2e-2
         assert np.abs(g1[k] - g2[k]).max() <= tol * max(np.abs(g1[k]).max(), 1e-20), k
 
 
