@@ -61,6 +61,7 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
                                  float* out_alpha_integrated, float* out_color_integrated, uint32_t gx, uint32_t ntiles);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
+__global__ void gather_u32(uint32_t n, const uint32_t* in, const uint32_t* idx, uint32_t* out);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
@@ -282,7 +283,9 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)
     { GOF_PROFILE("scan_tiles", stream);
-    GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, g.dval_a, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
+    // dkey_b is free after the (even number of) sort passes: tiles_touched gathered into depth order once, then a plain scan
+    hipLaunchKernelGGL(gather_u32, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.tiles_touched, g.dval_a, g.dkey_b);
+    GOF_HIP_CHECK(device_scan_u32(g.dkey_b, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
                                   total_dev_out, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;

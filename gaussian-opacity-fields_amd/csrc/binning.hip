@@ -32,6 +32,14 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
+// tiles_touched in depth order: ONE random gather (4 B out of a 64-byte sector each) instead of one in each of the two scan passes
+__global__ void __launch_bounds__(256)
+gather_u32(uint32_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
 // Instance emission in depth order (replaces duplicateWithKeys, rasterizer_impl.cu:70-111).  Lane = depth-sorted Gaussian for the
 // set-up (rectangle, count, first output slot), then the WAVE writes its Gaussians' instances cooperatively: output slot p of the
 // wave's contiguous range belongs to the lane o with off[o] <= p < off[o] + cnt[o] (6-step binary search over the lanes' offsets
