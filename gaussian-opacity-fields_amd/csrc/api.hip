@@ -21,7 +21,7 @@ __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const 
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
                                int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out, float4* fconic_out,
-                               uint32_t* tiles_touched, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
+                               uint32_t* tiles_touched, uint2* rect_out, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
 template <bool TILED>
 __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
@@ -39,8 +39,8 @@ size_t rs_tmp_words(size_t n);
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 int radix_passes(int end_bit);
-__global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const SplatRec* rec, const int32_t* radii,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t gy, uint32_t capacity);
+__global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity);
 __global__ void point_keys(int PN, const float2* points2D, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev);
@@ -61,7 +61,7 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
                                  float* out_alpha_integrated, float* out_color_integrated, uint32_t gx, uint32_t ntiles);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
-__global__ void gather_u32(uint32_t n, const uint32_t* in, const uint32_t* idx, uint32_t* out);
+__global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
@@ -120,6 +120,7 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     carve(p, g.fconic, 2 * n);
     carve(p, g.depths, n);
     carve(p, g.tiles_touched, n);
+    carve(p, g.rect, n);
     carve(p, g.clamped, n);
     carve(p, g.flags, 4);
     carve(p, g.total, 4);
@@ -230,8 +231,8 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         uint32_t* t_in = odd ? b.tiles_alt : b.tiles;
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
         { GOF_PROFILE("emit_instances", stream);
-        hipLaunchKernelGGL(emit_instances, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.dval_a, g.order_off, g.rec, radii,
-                           t_in, v_in, d.gx, d.gy, R); }
+        hipLaunchKernelGGL(emit_instances, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.dval_a, g.order_off, g.dkey_b, g.dval_b,
+                           t_in, v_in, d.gx, R); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
         int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev);
@@ -273,7 +274,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox, g.fconic,
-                       g.tiles_touched, g.clamped, g.dkey_a, g.dval_a, g.flags); }
+                       g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
@@ -283,9 +284,10 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)
     { GOF_PROFILE("scan_tiles", stream);
-    // dkey_b is free after the (even number of) sort passes: tiles_touched gathered into depth order once, then a plain scan
-    hipLaunchKernelGGL(gather_u32, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.tiles_touched, g.dval_a, g.dkey_b);
-    GOF_HIP_CHECK(device_scan_u32(g.dkey_b, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
+    // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
+    // scanned in place
+    hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, g.dkey_b, g.dval_b, g.order_off);
+    GOF_HIP_CHECK(device_scan_u32(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
                                   total_dev_out, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;

@@ -32,23 +32,29 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-// tiles_touched in depth order: ONE random gather (4 B out of a 64-byte sector each) instead of one in each of the two scan passes
+// Everything the instance emission needs of a Gaussian, gathered into DEPTH order with one random 8-byte read per Gaussian (the
+// tile rectangle preprocess_fwd packed): the rectangle words, and the instance count for the scan.  (Gathering tiles_touched in
+// both scan passes and radii + the record's pixel position again in the emission cost three 64-byte sectors per Gaussian.)
 __global__ void __launch_bounds__(256)
-gather_u32(uint32_t n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out)
+gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, uint32_t* __restrict__ minxy_sorted,
+             uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ counts)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
+    if (i >= n) return;
+    const uint2 r = rect[order[i]];
+    minxy_sorted[i] = r.x;
+    wh_sorted[i] = r.y;
+    counts[i] = (r.y & 0xFFFFu) * (r.y >> 16);
 }
 
 // Instance emission in depth order (replaces duplicateWithKeys, rasterizer_impl.cu:70-111).  Lane = depth-sorted Gaussian for the
-// set-up (rectangle, count, first output slot), then the WAVE writes its Gaussians' instances cooperatively: output slot p of the
+// set-up (rectangle and first output slot, read coalesced from the depth-ordered arrays of gather_rects), then the WAVE writes its Gaussians' instances cooperatively: output slot p of the
 // wave's contiguous range belongs to the lane o with off[o] <= p < off[o] + cnt[o] (6-step binary search over the lanes' offsets
 // with ds_bpermute), entry k = p - off[o] is tile (miny + k / w, minx + k % w): 64 consecutive slots per store instruction instead
 // of 64 slots scattered ~10 entries apart.
 __global__ void __launch_bounds__(256)
-emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const SplatRec* __restrict__ rec,
-               const int32_t* __restrict__ radii, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t gy,
-               uint32_t capacity)
+emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
+               const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -56,12 +62,11 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     if (i < P) {
         idx = order[i];
         off = order_off[i];
-        const int r = radii[idx];
-        if (r > 0) {
-            uint32_t maxx, maxy;
-            get_rect(rec[idx].f[REC_XY], rec[idx].f[REC_XY + 1], r, minx, miny, maxx, maxy, gx, gy);
-            w = maxx - minx;
-            cnt = w * (maxy - miny);
+        const uint32_t mxy = minxy_sorted[i], wh = wh_sorted[i];
+        if (wh) {
+            minx = mxy & 0xFFFFu; miny = mxy >> 16;
+            w = wh & 0xFFFFu;
+            cnt = w * (wh >> 16);
         }
     }
     // the wave's output range [first, first + total): offsets are an exclusive scan in this order, so they are contiguous

@@ -43,6 +43,7 @@ struct GeomWs {
     float4* bbox;           // [P] conservative pixel bounding box {xlo, xhi, ylo, yhi} of the alpha >= 1/255 footprint
     float4* fconic;         // [2P] footprint conic in ray space, unit-normalised: {m00, m01, m11, m02}, {m12, m22, q, -} (preprocess.hip)
     uint32_t* tiles_touched;// [P]
+    uint2* rect;            // [P] tile rectangle {minx | miny << 16, w | h << 16} of a visible Gaussian, {0, 0} if culled
     uint8_t* clamped;       // [P] bit c set when colour channel c was clamped (forward.cu:67-69)
     uint32_t* flags;        // [4] device-side status words (prefilter violation, ...)
     // depth ordering of the Gaussians (binning.hip): keys = float bits of the view depth (0xFFFFFFFF if culled)

@@ -208,20 +208,22 @@ preprocess_fwd(int P, int D, int M,
                int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
                uint32_t gx, uint32_t gy, int prefiltered,
                int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
-               float4* __restrict__ conic_out, float4* __restrict__ bbox_out, float4* __restrict__ fconic_out, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped,
+               float4* __restrict__ conic_out, float4* __restrict__ bbox_out, float4* __restrict__ fconic_out, uint32_t* __restrict__ tiles_touched,
+               uint2* __restrict__ rect_out, uint8_t* __restrict__ clamped,
                uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
     int32_t my_radii = 0;
     uint32_t my_tiles = 0;
+    uint2 my_rect = make_uint2(0u, 0u);
 
     const V3 p_orig = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
     const V3 p_view = transform_point_4x3(p_orig, cam.view);
     // near cull only (auxiliary.h:189): the lateral frustum test is commented out in the reference
     if (p_view.z <= 0.2f) {
         if (prefiltered) atomicOr(&flags[0], 1u);
-        radii[idx] = 0; tiles_touched[idx] = 0;
+        radii[idx] = 0; tiles_touched[idx] = 0; rect_out[idx] = make_uint2(0u, 0u);
         depth_key[idx] = 0xFFFFFFFFu; depth_val[idx] = (uint32_t)idx;
         return;
     }
@@ -335,9 +337,11 @@ preprocess_fwd(int P, int D, int M,
         depths[idx] = p_view.z;
         my_radii = (int32_t)my_radius;
         my_tiles = (maxy - miny) * (maxx - minx);
+        my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
     } while (0);
     radii[idx] = my_radii;
     tiles_touched[idx] = my_tiles;
+    rect_out[idx] = my_rect;
     // sort key of the binning stage: positive floats order like their bit patterns; culled Gaussians go last
     depth_key[idx] = my_radii > 0 ? __float_as_uint(p_view.z) : 0xFFFFFFFFu;
     depth_val[idx] = (uint32_t)idx;
