@@ -19,11 +19,16 @@ def shard_views(views: List, rank: int, world: int) -> List:
 
 
 class GradientAllReducer:
-    def __init__(self, params: Iterable[torch.Tensor], average: bool = False, group=None):
+    def __init__(self, params: Iterable[torch.Tensor], average: bool = False, group=None, wire_dtype=None):
+        """wire_dtype: None (default) = all-reduce the fp32 gradients as they are.  torch.bfloat16 halves the bytes on the xGMI
+        links (the collective is exposed at the end of the step) at the price of bf16-rounded gradient sums --
+        an opt-in for training runs, never used by bench.py's headline."""
         self.params = list(params)
         self.average = average
         self.group = group
+        self.wire_dtype = wire_dtype
         self._flat = None
+        self._wire = None
 
     def _ensure(self, n, device, dtype):
         if self._flat is None or self._flat.numel() != n or self._flat.device != device:
@@ -53,6 +58,15 @@ class GradientAllReducer:
         if not ps or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
         bucket = self._shared_bucket([p.grad for p in ps])
+        if bucket is not None and self.wire_dtype is not None:
+            if self._wire is None or self._wire.numel() != bucket.numel() or self._wire.device != bucket.device:
+                self._wire = torch.empty(bucket.numel(), dtype=self.wire_dtype, device=bucket.device)
+            self._wire.copy_(bucket)
+            dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=self.group)
+            bucket.copy_(self._wire)
+            if self.average:
+                bucket.div_(dist.get_world_size(self.group))
+            return
         if bucket is not None:                       # the rasterizer's backward carved them from one allocation: reduce in place
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:

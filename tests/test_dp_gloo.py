@@ -63,6 +63,14 @@ def _worker(rank, world, port, ret):
     ok = ok and red2._flat is None                       # the pack/unpack bucket was never needed
     ok = ok and all(torch.allclose(p.grad, e, atol=1e-6) for p, e in zip(params, expect))
     ok = ok and all(p.grad.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr() for p in params)
+    # opt-in bf16 wire format: same sums to bf16 precision (gloo reduces bf16 on the CPU)
+    for p, l, o, n in zip(params, local, offs, sizes):
+        bucket[o:o + n].view(l.shape).copy_(l)
+    try:
+        GradientAllReducer(params, wire_dtype=torch.bfloat16).all_reduce()
+        ok = ok and all(torch.allclose(p.grad, e, rtol=2e-2, atol=2e-2) for p, e in zip(params, expect))
+    except RuntimeError as ex:                       # a gloo build without bf16 reductions: the option is exercised on RCCL only
+        ok = ok and "BFloat16" in str(ex)
     # ... and a set that is NOT one ascending allocation falls back to pack / reduce / unpack
     ok = ok and GradientAllReducer._shared_bucket([params[1].grad, params[0].grad]) is None
     # densification statistics
