@@ -104,6 +104,43 @@ def test_forward_bit_exact(name):
     assert_image_matches(res["color"].cpu().numpy(), oc)
 
 
+def _fuzz_scene(seed):
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(17, 300)), int(rng.integers(17, 300))
+    sc = S.scene_frustum(int(rng.integers(50, 3000)), W=W, H=H, focal=float(rng.uniform(0.4, 2.0) * W), seed=seed,
+                         sigma_px=float(np.exp(rng.uniform(np.log(0.3), np.log(25.0)))), zmin=float(rng.uniform(0.25, 2.0)),
+                         zmax=float(rng.uniform(3.0, 60.0)), kernel_size=float(rng.choice([0.0, 0.1, 0.3])))
+    P = sc["means3D"].shape[0]
+    sc["scales"] *= np.exp(rng.normal(0.0, rng.uniform(0.0, 1.5), (P, 3))).astype(np.float32)          # needles / discs
+    sc["opacities"] = rng.choice([rng.uniform(0.0, 1.0, (P, 1)), rng.uniform(0.002, 0.01, (P, 1)), rng.uniform(0.9, 1.2, (P, 1))]).astype(np.float32)
+    sc["means3D"][rng.random(P) < 0.05, 2] *= -1.0                                                     # some behind the camera
+    sc["sh_degree"] = int(rng.integers(0, 4))
+    return sc
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_forward_and_integrate_fuzz_bit_exact(seed):
+    """Randomised small scenes (image size, focal length, splat size from sub-pixel to tile-covering, anisotropy up to ~1:100,
+    opacity regimes, depth range, kernel size, SH degree): image, state and the opacity-field query bit-identical to the oracle --
+    the conservative culls (footprint box, fp32 cull, footprint conic, front depth) must never drop a contributing pair."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = _fuzz_scene(seed)
+    o, oc, orad, res = _forward_pair(sc)
+    assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad)
+    for arr in INT_ARRAYS:
+        assert _same(fetch(res, arr), o.fetch(arr)), arr
+    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["color"].cpu().numpy(), oc)
+    pts = np.ascontiguousarray(S.tetra_points(sc)[:20000], dtype=np.float32)
+    io, ia, icol, _ = o.integrate(pts)
+    sd = to_dev(sc)
+    color, alpha, colp, _ = GaussianRasterizer(settings_from(sd)).integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
+                                                                             opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    assert np.array_equal(bits(color.cpu().numpy()), bits(io))
+    assert np.array_equal(bits(alpha.cpu().numpy()), bits(ia))
+    assert np.array_equal(bits(colp.cpu().numpy()), bits(icol))
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2])
 def test_forward_lower_sh_degrees(deg):
     sc = S.scene_frustum(2000, W=96, H=64, focal=70.0, seed=6)
