@@ -230,12 +230,18 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     lambda_dssim, lambda_dn, lambda_dist = 0.2, 0.05, 100.0        # arguments/__init__.py defaults
     filter_3D = (sd["scales"].min(dim=1, keepdim=True).values * 0.1).contiguous()           # a small 3D smoothing filter (compute_3D_filter's role)
 
-    def iteration():
+    def iteration(one_call_loss=False):
         shs = torch.cat((params["f_dc"], params["f_rest"]), dim=1)                           # get_features (gaussian_model.py:173-176)
         A = T.activations                                                                    # gaussian_renderer/__init__.py:60,70-71
         rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=shs,
                                 opacities=A.opacity_with_3D_filter(params["opacity"], params["scaling"], filter_3D),
                                 scales=A.scaling_with_3D_filter(params["scaling"], filter_3D), rotations=A.rotation(params["rotation"]))
+        if one_call_loss:                                                                    # train.py:150-188 as ONE operator (gof_train_loss)
+            loss = T.training_loss(rendering, gt, view, lambda_dssim, lambda_dn, lambda_dist).loss
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
         image = rendering[:3]
         rgb_loss = (1.0 - lambda_dssim) * T.l1_loss(image, gt) + lambda_dssim * (1.0 - T.ssim(image, gt))   # train.py:156-161
         distortion_loss = rendering[8].mean()                                                # :164-167
@@ -258,6 +264,14 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
         iteration()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    for _ in range(warmup):
+        iteration(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration(True)
+    torch.cuda.synchronize()
+    ms_one = 1e3 * (time.perf_counter() - t0) / steps
     B.profile_enable(True)                    # epilogue kernel durations: three more iterations with the library's HIP events
     for _ in range(3):
         iteration()
@@ -269,7 +283,10 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     n_floats = sum(p.numel() for p in params.values())
     out = {"ms_per_iter": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps,
            "includes": "3D-filter activations + rasterizer fwd/bwd + L1/D-SSIM/depth-normal/distortion loss + Adam (59 floats/Gaussian)",
-           "epilogue_kernels_ms": ep}
+           "epilogue_kernels_ms": ep,
+           "one_call_loss": {"ms_per_iter": round(ms_one, 4), "iters_per_s": round(1e3 / ms_one, 2),
+                             "what": "the same iteration with train.py:150-188 evaluated by train_epilogue.training_loss (gof_train_loss, "
+                                     "five launches) instead of the inline torch composition; needs the 7-line train.py change of INTEGRATION.md"}}
     if ep.get("adam_step"):
         out["adam_GBps"] = round(28.0 * n_floats / (ep["adam_step"] * 1e-3) / 1e9, 1)     # p,g,m,v read + p,m,v written
     return out

@@ -33,9 +33,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red)
 }
 
 // loss_utils.py:43-58.  grid (ceil(W/16), ceil(H/16), planes), block 256.
+// WITH_L1 (gof_train_loss): the tile also sums |img1 - img2| (loss_utils.py:17-18, train.py:156) from the pixels it holds anyway.
+template <bool WITH_L1>
 __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int W, int H, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
-                float* __restrict__ partial, float* __restrict__ dmaps, int planes)
+                float* __restrict__ partial, float* __restrict__ dmaps, int planes, float* __restrict__ partial_l1)
 {
     __shared__ float s_x[SSIM_E][SSIM_E + 1];
     __shared__ float s_y[SSIM_E][SSIM_E + 1];
@@ -92,7 +94,13 @@ ssim_fwd_kernel(int W, int H, const float* __restrict__ img1, const float* __res
         dmaps[((size_t)2 * planes + plane) * plane_sz + pix] = dm_ds12;
     }
     const float tot = block_sum_256(inside ? m : 0.0f, s_red);
-    if (threadIdx.x == 0) partial[((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
+    const size_t tile = ((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) partial[tile] = tot;
+    if (WITH_L1) {
+        __shared__ float s_red1[4];
+        const float l1 = block_sum_256(inside ? fabsf(s_x[ty + SSIM_R][tx + SSIM_R] - s_y[ty + SSIM_R][tx + SSIM_R]) : 0.0f, s_red1);
+        if (threadIdx.x == 0) partial_l1[tile] = l1;
+    }
 }
 
 // one block per plane: fixed-order sum of the tile partials (deterministic .mean(), loss_utils.py:60-63)
@@ -107,9 +115,12 @@ ssim_reduce_kernel(const float* __restrict__ partial, int tiles, float* __restri
     if (threadIdx.x == 0) plane_sums[blockIdx.x] = tot;
 }
 
+// WITH_L1 (gof_train_loss): every plane is scaled by `ssim_scale` and the L1 term's l1_scale * sign(img1 - img2) is added.
+template <bool WITH_L1>
 __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int W, int H, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
-                const float* __restrict__ dmaps, const float* __restrict__ plane_scale, float* __restrict__ dL_dimg1, int planes)
+                const float* __restrict__ dmaps, const float* __restrict__ plane_scale, float* __restrict__ dL_dimg1, int planes,
+                float ssim_scale, float l1_scale)
 {
     __shared__ float s_m[3][SSIM_E][SSIM_E + 1];
     __shared__ float s_h[3][SSIM_E][SSIM_T];
@@ -147,7 +158,13 @@ ssim_bwd_kernel(int W, int H, const float* __restrict__ img1, const float* __res
     }
     const size_t pix = base + (size_t)gy * W + gx;
     const float x = img1[pix], y = img2[pix];
-    dL_dimg1[pix] = plane_scale[plane] * (a + 2.0f * x * b + y * d);
+    if (WITH_L1) {
+        const float df = x - y;
+        const float sg = df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : df);      // torch.sign: 0 at 0, NaN stays NaN
+        dL_dimg1[pix] = ssim_scale * (a + 2.0f * x * b + y * d) + l1_scale * sg;
+    } else {
+        dL_dimg1[pix] = plane_scale[plane] * (a + 2.0f * x * b + y * d);
+    }
 }
 
 // ---- depth -> points -> normals ----------------------------------------------------------------------
@@ -264,6 +281,91 @@ depth_normal_bwd_kernel(int W, int H, const float* __restrict__ depth, const flo
     dL_ddepth[pix] = v3dot(ray_dir(c, x, y, inv_fx, inv_fy, ncx, ncy), g);
 }
 
+
+// ---- the loss of train.py:150-188 in one pass over the rendering (gof_train_loss) ---------------------------------
+// Geometry terms: distortion_loss = mean(rendering[8]) (train.py:164-167); depth-normal consistency (train.py:170-182):
+// depth_normal = depth_to_normal(view, rendering[6]), render_normal = F.normalize(rendering[3:6], dim=0) rotated to world
+// space by c2w[:3,:3], error = 1 - <render_normal_world, depth_normal>.  One thread per pixel: the two tile sums, the
+// gradient w.r.t. channels 3-5 (through the rotation and the normalisation), the constant gradient of channels 7-8, and
+// dL/d(depth_normal) for the gather-form depth backward that follows.  g_dn = lambda_depth_normal / (H W), g_dist likewise.
+__global__ void __launch_bounds__(256)
+loss_geom_kernel(int W, int H, const float* __restrict__ rendering, const float* __restrict__ wvt, float inv_fx, float inv_fy,
+                 float ncx, float ncy, float g_dn, float g_dist, float* __restrict__ partial_dn, float* __restrict__ partial_dist,
+                 float* __restrict__ gN, float* __restrict__ dL)
+{
+    __shared__ float s_red[4];
+    __shared__ float s_red1[4];
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const bool inside = x < W && y < H;
+    const size_t plane = (size_t)H * W;
+    float err = 0.0f, dist = 0.0f;
+    if (inside) {
+        const DepthCam c = load_depth_cam(wvt);
+        const float* depth = rendering + 6 * plane;
+        const size_t pix = (size_t)y * W + x;
+        V3 n = {0.f, 0.f, 0.f};
+        if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {                   // depth_utils.py:31-34
+            const V3 dx = v3sub(point_at(c, depth, W, x, y + 1, inv_fx, inv_fy, ncx, ncy), point_at(c, depth, W, x, y - 1, inv_fx, inv_fy, ncx, ncy));
+            const V3 dy = v3sub(point_at(c, depth, W, x + 1, y, inv_fx, inv_fy, ncx, ncy), point_at(c, depth, W, x - 1, y, inv_fx, inv_fy, ncx, ncy));
+            const V3 cr = v3cross(dx, dy);
+            const float dn = fmaxf(sqrtf(v3dot(cr, cr)), 1e-12f);
+            n = {cr.x / dn, cr.y / dn, cr.z / dn};
+        }
+        const V3 r = {rendering[3 * plane + pix], rendering[4 * plane + pix], rendering[5 * plane + pix]};
+        const float len = sqrtf(v3dot(r, r));
+        const float den = fmaxf(len, 1e-12f);                               // F.normalize(p=2, dim=0), train.py:175
+        const V3 rn = {r.x / den, r.y / den, r.z / den};
+        const V3 wn = {c.r[0] * rn.x + c.r[1] * rn.y + c.r[2] * rn.z,      // c2w[:3,:3] @ render_normal, train.py:177-179
+                       c.r[3] * rn.x + c.r[4] * rn.y + c.r[5] * rn.z,
+                       c.r[6] * rn.x + c.r[7] * rn.y + c.r[8] * rn.z};
+        err = 1.0f - v3dot(wn, n);                                          // train.py:181
+        dist = rendering[8 * plane + pix];
+        if (dL) {
+            gN[pix * 3 + 0] = -g_dn * wn.x; gN[pix * 3 + 1] = -g_dn * wn.y; gN[pix * 3 + 2] = -g_dn * wn.z;
+            const V3 gw = {-g_dn * n.x, -g_dn * n.y, -g_dn * n.z};
+            const V3 g = {c.r[0] * gw.x + c.r[3] * gw.y + c.r[6] * gw.z,   // rotation transposed
+                          c.r[1] * gw.x + c.r[4] * gw.y + c.r[7] * gw.z,
+                          c.r[2] * gw.x + c.r[5] * gw.y + c.r[8] * gw.z};
+            V3 gr;
+            if (len >= 1e-12f) {
+                const float il = 1.0f / len, ng = v3dot(rn, g);
+                gr = {(g.x - rn.x * ng) * il, (g.y - rn.y * ng) * il, (g.z - rn.z * ng) * il};
+            } else {
+                gr = {g.x / 1e-12f, g.y / 1e-12f, g.z / 1e-12f};            // clamped denominator: constant 1/eps
+            }
+            dL[3 * plane + pix] = gr.x; dL[4 * plane + pix] = gr.y; dL[5 * plane + pix] = gr.z;
+            dL[7 * plane + pix] = 0.0f;                                     // the alpha channel is not part of the loss
+            dL[8 * plane + pix] = g_dist;
+        }
+    }
+    const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const float e = block_sum_256(err, s_red);
+    const float d = block_sum_256(dist, s_red1);
+    if (threadIdx.x == 0) { partial_dn[tile] = e; partial_dist[tile] = d; }
+}
+
+// one block: fixed-order sums of the four partial arrays, then the scalar composition of train.py:161, 188 in fp32
+// terms = {loss, Ll1, ssim, rgb_loss, depth_normal_loss, distortion_loss}
+__global__ void __launch_bounds__(256)
+loss_final_kernel(const float* __restrict__ p_ssim, const float* __restrict__ p_l1, const float* __restrict__ p_dn,
+                  const float* __restrict__ p_dist, int tiles, float n_rgb, float n_pix, float w_l1, float lambda_dssim,
+                  float lambda_dn, float lambda_dist, float* __restrict__ terms)
+{
+    __shared__ float s_red[4][4];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < 3 * tiles; i += 256) { v[0] += p_ssim[i]; v[1] += p_l1[i]; }
+    for (int i = threadIdx.x; i < tiles; i += 256) { v[2] += p_dn[i]; v[3] += p_dist[i]; }
+    float tot[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tot[k] = block_sum_256(v[k], s_red[k]);
+    if (threadIdx.x == 0) {
+        const float Ll1 = tot[1] / n_rgb, ssim = tot[0] / n_rgb, dn = tot[2] / n_pix, dist = tot[3] / n_pix;
+        const float rgb = w_l1 * Ll1 + lambda_dssim * (1.0f - ssim);
+        terms[0] = rgb + dn * lambda_dn + dist * lambda_dist;
+        terms[1] = Ll1; terms[2] = ssim; terms[3] = rgb; terms[4] = dn; terms[5] = dist;
+    }
+}
+
 // ---- Adam --------------------------------------------------------------------------------------------
 constexpr int ADAM_BLOCK_ELEMS = 4096;     // 256 threads x 4 float4
 struct AdamArgs {
@@ -349,7 +451,7 @@ int gof_ssim_forward(int32_t planes, int32_t W, int32_t H, const float* img1, co
     const dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes);
     float* partial = static_cast<float*>(scratch);
     { GOF_PROFILE("ssim_forward", stream);
-      hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, stream, W, H, img1, img2, win, partial, dmaps, planes);
+      hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, stream, W, H, img1, img2, win, partial, dmaps, planes, (float*)nullptr);
       GOF_LAUNCH_CHECK(stream, 0);
       hipLaunchKernelGGL(ssim_reduce_kernel, dim3(planes), dim3(256), 0, stream, partial, (int)(grid.x * grid.y), plane_sums);
       GOF_LAUNCH_CHECK(stream, 0); }
@@ -366,7 +468,7 @@ int gof_ssim_backward(int32_t planes, int32_t W, int32_t H, const float* img1, c
     memcpy(win.w, window_host, sizeof(win.w));
     const dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes);
     { GOF_PROFILE("ssim_backward", stream);
-      hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, stream, W, H, img1, img2, win, dmaps, plane_scale, dL_dimg1, planes);
+      hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, stream, W, H, img1, img2, win, dmaps, plane_scale, dL_dimg1, planes, 0.0f, 0.0f);
       GOF_LAUNCH_CHECK(stream, 0); }
     return GOF_OK;
 }
@@ -409,6 +511,63 @@ int gof_depth_to_normal_backward(int32_t W, int32_t H, const float* depth, const
       hipLaunchKernelGGL(depth_normal_bwd_kernel, grid, dim3(256), 0, stream, W, H, depth, world_view_transform, inv_fx, inv_fy, ncx, ncy,
                          dL_dnormals, dL_dpoints, dL_ddepth);
       GOF_LAUNCH_CHECK(stream, 0); }
+    return GOF_OK;
+}
+
+static size_t loss_tiles(int32_t W, int32_t H) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+size_t gof_train_loss_scratch_bytes(int32_t W, int32_t H)
+{
+    if (W <= 0 || H <= 0) return 256;
+    const size_t px = (size_t)W * H;
+    // partial sums (ssim 3, l1 3, depth-normal 1, distortion 1 per tile) | SSIM derivative maps 3 x 3 planes | dL/d(depth normal)
+    return align256(8 * loss_tiles(W, H) * sizeof(float)) + align256(9 * px * sizeof(float)) + align256(3 * px * sizeof(float));
+}
+
+int gof_train_loss(int32_t W, int32_t H, const float* rendering, const float* gt_image, const float* window_host,
+                   const float* world_view_transform, float fx, float fy, double lambda_dssim, double lambda_depth_normal,
+                   double lambda_distortion, float* terms, float* dL_drendering, void* scratch, size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int e = ssim_check(3, W, H, rendering, gt_image, window_host)) return e;
+    if (int e = depth_check(W, H, rendering, world_view_transform, fx, fy)) return e;
+    if (!terms || !scratch) { set_error("terms / scratch is NULL"); return GOF_E_INVALID; }
+    if (scratch_bytes < gof_train_loss_scratch_bytes(W, H)) { set_error("train-loss scratch too small"); return GOF_E_WORKSPACE; }
+    SsimWindow win;
+    memcpy(win.w, window_host, sizeof(win.w));
+    const size_t px = (size_t)W * H, tiles = loss_tiles(W, H);
+    char* base = static_cast<char*>(scratch);
+    float* p_ssim = reinterpret_cast<float*>(base);
+    float* p_l1 = p_ssim + 3 * tiles;
+    float* p_dn = p_l1 + 3 * tiles;
+    float* p_dist = p_dn + tiles;
+    float* dmaps = reinterpret_cast<float*>(base + align256(8 * tiles * sizeof(float)));
+    float* gN = reinterpret_cast<float*>(base + align256(8 * tiles * sizeof(float)) + align256(9 * px * sizeof(float)));
+    const dim3 grid3((W + 15) / 16, (H + 15) / 16, 3), grid1((W + 15) / 16, (H + 15) / 16);
+    const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
+    const float ncx = -((float)W / 2.0f) / fx, ncy = -((float)H / 2.0f) / fy;
+    const double n_rgb = 3.0 * (double)px, n_pix = (double)px;
+    { GOF_PROFILE("train_loss", stream);
+      hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid3, dim3(256), 0, stream, W, H, rendering, gt_image, win, p_ssim,
+                         dL_drendering ? dmaps : (float*)nullptr, 3, p_l1);
+      GOF_LAUNCH_CHECK(stream, 0);
+      hipLaunchKernelGGL(loss_geom_kernel, grid1, dim3(256), 0, stream, W, H, rendering, world_view_transform, inv_fx, inv_fy, ncx, ncy,
+                         (float)(lambda_depth_normal / n_pix), (float)(lambda_distortion / n_pix), p_dn, p_dist, gN, dL_drendering);
+      GOF_LAUNCH_CHECK(stream, 0);
+      hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, p_ssim, p_l1, p_dn, p_dist, (int)tiles, (float)n_rgb,
+                         (float)n_pix, (float)(1.0 - lambda_dssim), (float)lambda_dssim, (float)lambda_depth_normal,
+                         (float)lambda_distortion, terms);
+      GOF_LAUNCH_CHECK(stream, 0);
+      if (dL_drendering) {
+          // d loss / d image = (1 - l) sign(image - gt) / (3HW) - l d ssim / d image (train.py:161)
+          hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid3, dim3(256), 0, stream, W, H, rendering, gt_image, win, dmaps, (const float*)nullptr,
+                             dL_drendering, 3, (float)(-lambda_dssim / n_rgb), (float)((1.0 - lambda_dssim) / n_rgb));
+          GOF_LAUNCH_CHECK(stream, 0);
+          hipLaunchKernelGGL(depth_normal_bwd_kernel, grid1, dim3(256), 0, stream, W, H, rendering + 6 * px, world_view_transform, inv_fx, inv_fy,
+                             ncx, ncy, gN, (const float*)nullptr, dL_drendering + 6 * px);
+          GOF_LAUNCH_CHECK(stream, 0);
+      } }
     return GOF_OK;
 }
 

@@ -30,6 +30,10 @@ def _declare():
     lib.gof_depth_to_normal.argtypes = [i32, i32, vp, vp, f32, f32, vp, vp, vp]
     lib.gof_depth_to_normal_backward.argtypes = [i32, i32, vp, vp, f32, f32, vp, vp, vp, vp]
     lib.gof_adam_step.argtypes = [i32, C.POINTER(GofAdamTensor), C.c_double, C.c_double, C.c_double, vp]
+    lib.gof_train_loss_scratch_bytes.restype = sz
+    lib.gof_train_loss_scratch_bytes.argtypes = [i32, i32]
+    lib.gof_train_loss.argtypes = [i32, i32, vp, vp, W11, vp, f32, f32, C.c_double, C.c_double, C.c_double, vp, vp, vp, sz, vp]
+    lib.gof_train_loss.restype = C.c_int
     for n in ("gof_ssim_forward", "gof_ssim_backward", "gof_depth_to_normal", "gof_depth_to_normal_backward", "gof_adam_step"):
         getattr(lib, n).restype = C.c_int
 
@@ -89,6 +93,20 @@ def depth_to_normal_backward(depth_hw, wvt, fx, fy, g_normals, g_points):
     _check(lib.gof_depth_to_normal_backward(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, g_normals.data_ptr(),
                                             g_points.data_ptr() if g_points is not None else None, out.data_ptr(), _stream()))
     return out
+
+
+def train_loss(rendering, gt_image, taps, wvt, fx, fy, lambda_dssim, lambda_depth_normal, lambda_distortion, want_grad):
+    """gof_train_loss: (terms[6] = loss, Ll1, ssim, rgb_loss, depth_normal_loss, distortion_loss; d loss / d rendering or None)."""
+    H, W = int(rendering.shape[-2]), int(rendering.shape[-1])
+    dev = rendering.device
+    terms = torch.empty(6, dtype=torch.float32, device=dev)
+    dL = torch.empty_like(rendering) if want_grad else None
+    nb = lib.gof_train_loss_scratch_bytes(W, H)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _check(lib.gof_train_loss(W, H, rendering.data_ptr(), gt_image.data_ptr(), taps, wvt.data_ptr(), fx, fy, float(lambda_dssim),
+                              float(lambda_depth_normal), float(lambda_distortion), terms.data_ptr(),
+                              dL.data_ptr() if want_grad else None, scratch.data_ptr(), nb, _stream()))
+    return terms, dL
 
 
 def adam_step(entries, beta1, beta2, eps):

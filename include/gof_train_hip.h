@@ -59,6 +59,23 @@ int gof_depth_to_normal_backward(int32_t W, int32_t H, const float* depth, const
                                  float fx, float fy, const float* dL_dnormals, const float* dL_dpoints,
                                  float* dL_ddepth, void* stream);
 
+/* ---- the loss of one training iteration (train.py:150-188) as ONE call ("fused L1 + SSIM + depth-normal
+ *      + distortion loss kernels").  train.py composes it inline from ~60 torch launches and their autograd:
+ *          Ll1 = l1_loss(image, gt); rgb_loss = (1 - l_dssim) Ll1 + l_dssim (1 - ssim(image, gt))                 :156-161
+ *          distortion_loss = rendering[8].mean()                                                                  :164-167
+ *          depth_normal = depth_to_normal(view, rendering[6]); render_normal = normalize(rendering[3:6], dim=0)
+ *          depth_normal_loss = mean(1 - <c2w[:3,:3] @ render_normal, depth_normal>)                               :170-182
+ *          loss = rgb_loss + depth_normal_loss l_dn + distortion_loss l_dist                                      :188
+ *      (the decoupled-appearance variant of Ll1, :158-159, goes through a network and stays torch code).
+ *      rendering [9,H,W] is the rasterizer's output, gt_image [3,H,W].  terms (device, 6 floats) receives
+ *      {loss, Ll1, ssim, rgb_loss, depth_normal_loss, distortion_loss}; dL_drendering [9,H,W] (nullable: values only) receives
+ *      d loss / d rendering, every element written.  Five launches, sums in a fixed order (deterministic).
+ *      A train.py that calls this instead of :150-188 is shown in INTEGRATION.md; the drop-in mirrors above stay the default. */
+size_t gof_train_loss_scratch_bytes(int32_t W, int32_t H);
+int gof_train_loss(int32_t W, int32_t H, const float* rendering, const float* gt_image, const float* window_host /* 11 taps */,
+                   const float* world_view_transform, float fx, float fy, double lambda_dssim, double lambda_depth_normal,
+                   double lambda_distortion, float* terms, float* dL_drendering, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- Adam (scene/gaussian_model.py:360; torch/optim/adam.py _multi_tensor_adam, no weight decay / amsgrad) */
 typedef struct GofAdamTensor {
     float* param;             /* [n] updated in place                          */

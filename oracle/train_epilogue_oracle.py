@@ -70,6 +70,31 @@ def depth_to_normal(world_view_transform, W, H, FoVx, FoVy, depth, dtype=torch.f
     return output, points
 
 
+# ---- train.py: the loss of one iteration --------------------------------------------------------------
+def training_loss(rendering, gt_image, world_view_transform, W, H, FoVx, FoVy, lambda_dssim, lambda_depth_normal, lambda_distortion,
+                  dtype=torch.float32):
+    """train.py:150-188 (without the decoupled-appearance branch, :158-159) on CPU tensors; the lambdas already gated by
+    iteration (:184-185).  Returns (loss, Ll1, ssim, rgb_loss, depth_normal_loss, distortion_loss)."""
+    image = rendering[:3, :, :]                                                           # :150
+    Ll1 = l1_loss(image, gt_image)                                                        # :156
+    ssim_value = ssim(image, gt_image)
+    rgb_loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim_value)             # :161
+    distortion_map = rendering[8, :, :]                                                   # :164
+    distortion_loss = distortion_map.mean()                                               # :167
+    depth = rendering[6, :, :]                                                            # :170
+    depth_normal, _ = depth_to_normal(world_view_transform, W, H, FoVx, FoVy, depth[None, ...], dtype)   # :171
+    depth_normal = depth_normal.permute(2, 0, 1)                                          # :172
+    render_normal = rendering[3:6, :, :]                                                  # :174
+    render_normal = F.normalize(render_normal, p=2, dim=0)                                # :175
+    c2w = (world_view_transform.T).inverse()                                              # :177
+    normal2 = c2w[:3, :3] @ render_normal.reshape(3, -1)                                  # :178
+    render_normal_world = normal2.reshape(3, *render_normal.shape[1:])                    # :179
+    normal_error = 1 - (render_normal_world * depth_normal).sum(dim=0)                    # :181
+    depth_normal_loss = normal_error.mean()                                               # :182
+    loss = rgb_loss + depth_normal_loss * lambda_depth_normal + distortion_loss * lambda_distortion   # :188
+    return loss, Ll1, ssim_value, rgb_loss, depth_normal_loss, distortion_loss
+
+
 # ---- scene/gaussian_model.py: compute_3D_filter ------------------------------------------------------------
 def compute_3d_filter(xyz, cameras):
     """GaussianModel.compute_3D_filter (gaussian_model.py:262-311) on CPU tensors; cameras: objects with R, T (numpy), focal_x,

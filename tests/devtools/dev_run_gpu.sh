@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -q -k "backward_fuzz" 2>&1 | grep -E "passed|failed|^FAILED|^E  " | cut -c1-250 | head -20
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'])
+print(json.dumps(d['full_loop'],indent=1))"

@@ -51,6 +51,22 @@ def test_depth_to_normal_oracle_matches_reference_python(tag):
     np.testing.assert_array_equal(O.depths_to_points(wvt, W, H, fovx, fovy, depth.detach()).numpy(), G[f"dn_{tag}_points_flat"])
 
 
+GL = np.load(os.path.join(ROOT, "tests", "golden", "ref_train_loss_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_training_loss_oracle_matches_reference_python(tag):
+    """train.py:150-188 restated (oracle) vs the same statements executed over the reference's own l1_loss / ssim / depth_to_normal."""
+    W, H, fovx, fovy = GL[f"{tag}_cam"]
+    l_dssim, l_dn, l_dist = GL[f"{tag}_lambdas"]
+    r = torch.from_numpy(GL[f"{tag}_rendering"]).requires_grad_(True)
+    terms = O.training_loss(r, torch.from_numpy(GL[f"{tag}_gt"]), torch.from_numpy(GL[f"{tag}_wvt"]), int(W), int(H), fovx, fovy,
+                            float(l_dssim), float(l_dn), float(l_dist))
+    terms[0].backward()
+    np.testing.assert_allclose([t.item() for t in terms], GL[f"{tag}_terms"], rtol=1e-6)
+    np.testing.assert_allclose(r.grad.numpy(), GL[f"{tag}_grad"], rtol=1e-5, atol=1e-10)
+
+
 def test_adam_oracle_matches_torch_adam():
     """fp32 numpy restatement vs torch.optim.Adam (single-tensor CPU implementation) over 3 steps, per-group lr."""
     sizes, lrs = G["adam_sizes"], G["adam_lrs"]
