@@ -72,7 +72,9 @@ def main():
 
     if distributed:
         from dp import GradientAllReducer
-        reducer = GradientAllReducer(list(params.values()))
+        # the SH gradient travels as 12 B per Gaussian and view (all-gather + local expansion) instead of 192 B (dp/reducer.py);
+        # GOF_DP_DENSE_SH=1 all-reduces the dense 236 B instead (A/B)
+        reducer = GradientAllReducer(list(params.values()), sh_params=None if os.environ.get("GOF_DP_DENSE_SH") == "1" else [params["shs"]])
 
     def step():
         for p in params.values():
@@ -124,7 +126,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S1M: %d Gaussians @ %dx%d, SH degree 3, kernel_size %.2f, fwd+bwd%s" % (
-                P, W, H, args.kernel_size, " + RCCL grad all-reduce (236 B/Gaussian)" if distributed else ""),
+                P, W, H, args.kernel_size, (" + RCCL gradient exchange (%s)" % reducer.last_exchange) if distributed else ""),
                 "num_rendered": stage["R"], "fwd_Msplats_per_s": round(P / (stage["fwd_ms"] * 1e-3) / 1e6, 2),
                 "fwd_ms": round(stage["fwd_ms"], 4), "bwd_ms": round(stage["bwd_ms"], 4), "parallelism": "dp%d (views)" % world},
             "roofline": stage["roofline"],

@@ -30,6 +30,10 @@ __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const 
 __global__ void preprocess_points(int PN, const float* points3D, Cam cam, int W, int H, float focal_x, float focal_y,
                                   float2* points2D, float* depths, uint32_t* tiles_touched);
 __global__ void mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present);
+__global__ void sh_grad_pack(int P, const float* dL_dcolor, const uint8_t* clamped, const int32_t* radii, float* packed);
+template <int MC>
+__global__ void sh_grad_expand(int P, int D, int M, int n_views, const float* means3D, const float* campos, long campos_stride, const float* packed,
+                               long packed_stride, float scale, float* out_dc, long stride_dc, float* out_rest, long stride_rest);
 
 uint32_t higher_msb(uint32_t n);
 size_t scan_tmp_words(size_t n);
@@ -629,6 +633,45 @@ int gof_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
     if (!means3D || !viewmatrix || !projmatrix || !present) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
     const Cam cam = { viewmatrix, projmatrix, nullptr };
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, cam, present);
+    GOF_LAUNCH_CHECK(stream, 0);
+    return GOF_OK;
+}
+
+// ---- data-parallel training: compressed SH-gradient exchange (preprocess.hip) ---------------------------
+int gof_sh_grad_pack(int32_t P, const float* dL_dcolors, const void* geom_ws, size_t geom_bytes, const int32_t* radii, float* packed, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0) { set_error("bad P"); return GOF_E_INVALID; }
+    if (P == 0) return GOF_OK;
+    if (!dL_dcolors || !geom_ws || !radii || !packed) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    if (geom_bytes < gof_geom_bytes(P)) { set_error("geometry workspace too small for P = %d", P); return GOF_E_WORKSPACE; }
+    GeomWs g;
+    geom_layout(P, aligned_base(const_cast<void*>(geom_ws)), &g);
+    GOF_PROFILE("sh_grad_pack", stream);
+    hipLaunchKernelGGL(sh_grad_pack, dim3((P + 255) / 256), dim3(256), 0, stream, P, dL_dcolors, g.clamped, radii, packed);
+    GOF_LAUNCH_CHECK(stream, 0);
+    return GOF_OK;
+}
+
+int gof_sh_grad_expand(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D, const float* campos, int64_t campos_stride,
+                       const float* packed, int64_t packed_stride, float scale, float* out_dc, int64_t stride_dc, float* out_rest,
+                       int64_t stride_rest, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (P < 0 || n_views < 1) { set_error("bad P / n_views (%d, %d)", P, n_views); return GOF_E_INVALID; }
+    if (D < 0 || D > 3 || M < 1 || M > 16 || (D + 1) * (D + 1) > M) { set_error("bad SH degree / coefficient count (%d, %d)", D, M); return GOF_E_INVALID; }
+    if (P == 0) return GOF_OK;
+    if (!means3D || !campos || !packed || !out_dc || (M > 1 && !out_rest)) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    if (n_views > 1 && (packed_stride < (int64_t)3 * P || campos_stride < 3)) { set_error("view strides too small"); return GOF_E_INVALID; }
+    GOF_PROFILE("sh_grad_expand", stream);
+    const dim3 grid((uint32_t)((P + 255) / 256));
+    const size_t lds = 256 * (3 * M + 1) * sizeof(float);
+    if (M == 16)
+        hipLaunchKernelGGL(sh_grad_expand<16>, grid, dim3(256), lds, stream, P, D, M, n_views, means3D, campos, (long)campos_stride, packed,
+                           (long)packed_stride, scale, out_dc, (long)stride_dc, out_rest, (long)stride_rest);
+    else
+        hipLaunchKernelGGL(sh_grad_expand<0>, grid, dim3(256), lds, stream, P, D, M, n_views, means3D, campos, (long)campos_stride, packed,
+                           (long)packed_stride, scale, out_dc, (long)stride_dc, out_rest, (long)stride_rest);
     GOF_LAUNCH_CHECK(stream, 0);
     return GOF_OK;
 }

@@ -622,4 +622,131 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, Cam cam, uint8_t* 
     present[idx] = (pv.z <= 0.2f) ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Data-parallel training: compressed exchange of the SH gradient (no reference counterpart).
+// K9's SH gradient of one view is an outer product: dL_dsh[k] = basis_k(dir) * dL_dRGB with dL_dRGB = the blend's colour gradient
+// masked by the forward's clamp bits (sh_backward above) -- 12 bytes of information expanded to 192.  Ranks therefore exchange
+// dL_dRGB (all-gather, 12 B per Gaussian and view) instead of all-reducing dL_dsh (192 B), and every rank expands the sum
+//     dL_dsh[k] = sum_views basis_k(normalize(mean - campos_view)) * dL_dRGB_view
+// locally, views in rank order (deterministic, identical on every rank; each product is bit-identical to the one K9 forms).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sh_grad_pack(int P, const float* __restrict__ dL_dcolor, const uint8_t* __restrict__ clamped, const int32_t* __restrict__ radii,
+             float* __restrict__ packed)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    V3 g = { 0.f, 0.f, 0.f };
+    if (radii[idx] > 0) {                                   // preprocess_bwd skips the others (backward.cu:612-613)
+        const uint32_t cb = clamped[idx];
+        g = { dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2] };
+        g.x *= (cb & 1u) ? 0 : 1;                           // backward.cu:36-38, as sh_backward
+        g.y *= (cb & 2u) ? 0 : 1;
+        g.z *= (cb & 4u) ? 0 : 1;
+    }
+    packed[3 * idx] = g.x; packed[3 * idx + 1] = g.y; packed[3 * idx + 2] = g.z;
+}
+
+// One thread per Gaussian: per view the direction and the dRGBdsh_k of sh_backward (the same expressions) once, 48 running sums in
+// registers; the workgroup's 256 x 192-byte tile of results leaves through LDS with coalesced stores (rows padded to 49 floats as
+// in preprocess_bwd<true>) -- to one [P,M,3] tensor or to the reference's separate DC / higher-band tensors
+// (scene/gaussian_model.py:351-352).  View v: packed + v*packed_stride is [P][3], campos + v*campos_stride is [3] (strides in
+// floats: the all-gathered buffer carries each rank's camera centre after its P rows).
+template <int MC>                                          // MC = 16: the coefficient count as a constant (index arithmetic), 0: any M
+__global__ void __launch_bounds__(256)
+sh_grad_expand(int P, int D, int M, int n_views, const float* __restrict__ means3D, const float* __restrict__ campos, long campos_stride,
+               const float* __restrict__ packed, long packed_stride, float scale, float* __restrict__ out_dc, long stride_dc,
+               float* __restrict__ out_rest, long stride_rest)
+{
+    extern __shared__ float s_tile[];                       // [256][3 M + 1]
+    if (MC) M = MC;
+    const int row_len = 3 * M + 1;
+    const long base = (long)blockIdx.x * 256;
+    const long idx = base + threadIdx.x;
+    V3 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = { 0.f, 0.f, 0.f };
+    if (idx < P) {
+        const V3 mean = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+        for (int v = 0; v < n_views; v++) {
+            const float* g = packed + (size_t)v * packed_stride + (size_t)idx * 3;
+            const V3 rgb = { g[0], g[1], g[2] };
+            if (rgb.x == 0.f && rgb.y == 0.f && rgb.z == 0.f) continue;       // culled or not reached in this view
+            const float* c = campos + (size_t)v * campos_stride;
+            const V3 cp = { c[0], c[1], c[2] };
+            const V3 dir_orig = mean - cp;
+            const V3 dir = dir_orig / sqrtf(dot3(dir_orig, dir_orig));
+            const float x = dir.x, y = dir.y, z = dir.z;
+            acc[0] = acc[0] + SH_C0 * rgb;
+            if (D > 0) {
+                acc[1] = acc[1] + (-SH_C1 * y) * rgb;
+                acc[2] = acc[2] + (SH_C1 * z) * rgb;
+                acc[3] = acc[3] + (-SH_C1 * x) * rgb;
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    const float xy = x * y, yz = y * z, xz = x * z;
+                    acc[4] = acc[4] + (SH_C2[0] * xy) * rgb;
+                    acc[5] = acc[5] + (SH_C2[1] * yz) * rgb;
+                    acc[6] = acc[6] + (SH_C2[2] * (2.f * zz - xx - yy)) * rgb;
+                    acc[7] = acc[7] + (SH_C2[3] * xz) * rgb;
+                    acc[8] = acc[8] + (SH_C2[4] * (xx - yy)) * rgb;
+                    if (D > 2) {
+                        acc[9] = acc[9] + (SH_C3[0] * y * (3.f * xx - yy)) * rgb;
+                        acc[10] = acc[10] + (SH_C3[1] * xy * z) * rgb;
+                        acc[11] = acc[11] + (SH_C3[2] * y * (4.f * zz - xx - yy)) * rgb;
+                        acc[12] = acc[12] + (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * rgb;
+                        acc[13] = acc[13] + (SH_C3[4] * x * (4.f * zz - xx - yy)) * rgb;
+                        acc[14] = acc[14] + (SH_C3[5] * z * (xx - yy)) * rgb;
+                        acc[15] = acc[15] + (SH_C3[6] * x * (xx - 3.f * yy)) * rgb;
+                    }
+                }
+            }
+        }
+    }
+    float* my = s_tile + threadIdx.x * row_len;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < M) {
+            const V3 r = scale * acc[k];
+            my[3 * k] = r.x; my[3 * k + 1] = r.y; my[3 * k + 2] = r.z;
+        }
+    }
+    __syncthreads();
+    const int rows = (int)min((long)256, (long)P - base);
+    const int per_row = 3 * M;
+    if (out_rest == out_dc + 3 && stride_dc == per_row && stride_rest == per_row) {
+        // one [P,M,3] tensor: the tile is one contiguous run of rows * 3M floats
+        float* o = out_dc + base * per_row;
+        if (MC && rows == 256 && (((uintptr_t)o) & 15) == 0) {
+            for (int j = threadIdx.x * 4; j < 256 * 3 * MC; j += 1024) {
+                float4 q;
+                { const int r = j / (3 * MC), c = j - r * (3 * MC); q.x = s_tile[r * row_len + c]; }
+                { const int r = (j + 1) / (3 * MC), c = j + 1 - r * (3 * MC); q.y = s_tile[r * row_len + c]; }
+                { const int r = (j + 2) / (3 * MC), c = j + 2 - r * (3 * MC); q.z = s_tile[r * row_len + c]; }
+                { const int r = (j + 3) / (3 * MC), c = j + 3 - r * (3 * MC); q.w = s_tile[r * row_len + c]; }
+                *reinterpret_cast<float4*>(o + j) = q;
+            }
+        } else {
+            for (int j = threadIdx.x; j < rows * per_row; j += 256) {
+                const int r = j / per_row, c = j - r * per_row;
+                o[j] = s_tile[r * row_len + c];
+            }
+        }
+    } else {
+        // separate DC [P,1,3] and higher-band [P,M-1,3] tensors (or any other pair of row strides)
+        for (int j = threadIdx.x; j < rows * 3; j += 256) {
+            const int r = j / 3, c = j - r * 3;
+            out_dc[(base + r) * stride_dc + c] = s_tile[r * row_len + c];
+        }
+        const int rest = per_row - 3;
+        for (int j = threadIdx.x; j < rows * rest; j += 256) {
+            const int r = j / rest, c = j - r * rest;
+            out_rest[(base + r) * stride_rest + c] = s_tile[r * row_len + 3 + c];
+        }
+    }
+}
+
+template __global__ void sh_grad_expand<16>(int, int, int, int, const float*, const float*, long, const float*, long, float, float*, long, float*, long);
+template __global__ void sh_grad_expand<0>(int, int, int, int, const float*, const float*, long, const float*, long, float, float*, long, float*, long);
+
 } // namespace gof

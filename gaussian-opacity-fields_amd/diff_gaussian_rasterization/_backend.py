@@ -63,6 +63,9 @@ def _load():
     lib.gof_point_binning_bytes.restype = sz
     lib.gof_point_binning_bytes.argtypes = [u32, i32, i32]
     lib.gof_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.gof_sh_grad_pack.argtypes = [i32, vp, vp, sz, vp, vp, vp]
+    lib.gof_sh_grad_expand.argtypes = [i32, i32, i32, i32, vp, vp, i64, vp, i64, C.c_float, vp, i64, vp, i64, vp]
+    lib.gof_sh_grad_pack.restype = lib.gof_sh_grad_expand.restype = C.c_int
     lib.gof_mtets_count.argtypes = [i64, i64, vp, vp, vp, sz, C.POINTER(i64), C.POINTER(i64), vp]
     lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.gof_debug_fetch.restype = i64
@@ -235,18 +238,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
               viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, H, W, sh, degree, campos, False, debug)
     P, M, dev = v.P, v.M, v.device
     f = dict(dtype=torch.float32, device=dev)
-    # The gradients of the Gaussian PARAMETERS (means3D, sh, opacity, scales, rotations: 59 floats per Gaussian at SH degree 3)
+    # The gradients of the Gaussian PARAMETERS (means3D, opacity, scales, rotations, sh: 59 floats per Gaussian at SH degree 3)
     # are carved from ONE allocation in that order, 16-byte aligned segments: a data-parallel trainer can all-reduce the
-    # bucket in place (dp/reducer.py) instead of packing 236 B per Gaussian into a bucket and back.
-    sizes = [3 * P, 3 * M * P, P, 3 * P, 4 * P]
+    # bucket in place (dp/reducer.py) instead of packing 236 B per Gaussian into a bucket and back -- or only its first four
+    # segments when the SH gradient travels in compressed form (sh_grad_pack / sh_grad_expand below).
+    sizes = [3 * P, P, 3 * P, 4 * P, 3 * M * P]
     offs, tot = [], 0
     for n in sizes:
         offs.append(tot)
         tot += (n + 3) & ~3
     bucket = torch.empty(tot, **f)
-    g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_sh = bucket[offs[1]:offs[1] + sizes[1]].view(P, M, 3)
-    g_opacity = bucket[offs[2]:offs[2] + sizes[2]].view(P, 1); g_scales = bucket[offs[3]:offs[3] + sizes[3]].view(P, 3)
-    g_rot = bucket[offs[4]:offs[4] + sizes[4]].view(P, 4)
+    g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_opacity = bucket[offs[1]:offs[1] + sizes[1]].view(P, 1)
+    g_scales = bucket[offs[2]:offs[2] + sizes[2]].view(P, 3); g_rot = bucket[offs[3]:offs[3] + sizes[3]].view(P, 4)
+    g_sh = bucket[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
     g_means2D = torch.empty((P, 3), **f); g_colors = torch.empty((P, 3), **f)
     g_cov3D = torch.empty((P, 6), **f); g_v2g = torch.empty((P, 10), **f)
     if P != 0:
@@ -259,7 +263,58 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                     _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D),
                                     _ptr(g_sh), _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g),
                                     _ptr(scratch), nscratch, _stream()))
+        if _sh_track["on"] and M > 0:
+            _sh_track["count"] += 1
+            _sh_track["src"] = {"dL_dcolors": g_colors, "geom": geomBuffer, "radii": radii, "means3D": v.keep["means3D"], "campos": v.keep["campos"],
+                                "degree": int(degree), "M": M, "P": P}
     return g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_v2g
+
+
+# ---- data-parallel training: the SH gradient in compressed form (include/gof_hip.h: gof_sh_grad_pack / gof_sh_grad_expand) ----
+_sh_track = {"on": False, "count": 0, "src": None}
+
+
+def track_sh_grad_source(on=True):
+    """While on, every backward remembers what the SH gradient of that view was expanded from (the blend's colour gradient, the
+    forward's clamp flags, the camera centre).  dp/reducer.py enables it; nothing is kept otherwise."""
+    _sh_track["on"] = bool(on)
+    _sh_track["count"], _sh_track["src"] = 0, None
+
+
+def take_sh_grad_source():
+    """The source of the SH gradient accumulated since the last call, if it came from EXACTLY ONE rasterizer backward (the
+    reference's training iteration, train.py:147-189); None otherwise (the caller then exchanges the dense gradient)."""
+    n, src = _sh_track["count"], _sh_track["src"]
+    _sh_track["count"], _sh_track["src"] = 0, None
+    return src if n == 1 else None
+
+
+def sh_grad_pack(src, out):
+    """out[:P] (float32 [>=P,3], contiguous) = this view's masked colour gradient."""
+    with torch.cuda.device(out.device):
+        _check(lib.gof_sh_grad_pack(src["P"], _ptr(src["dL_dcolors"]), _ptr(src["geom"]), src["geom"].numel(), _ptr(src["radii"]),
+                                    _ptr(out), _stream()))
+
+
+def sh_grad_expand(src, gathered, scale, outs):
+    """gathered: float32 [n_views, P+1, 3] (rows 0..P-1 of a view = its packed gradient, row P = its camera centre).
+    outs: (dL_dsh [P,M,3],) or (dL_dfeatures_dc [P,1,3], dL_dfeatures_rest [P,M-1,3]); every element is overwritten."""
+    P, M = src["P"], src["M"]
+    n_views = int(gathered.shape[0])
+    vs = (P + 1) * 3
+    if len(outs) == 1:
+        dc, rest = outs[0], outs[0]
+        p_dc, p_rest, s_dc, s_rest = dc.data_ptr(), dc.data_ptr() + 12, 3 * M, 3 * M
+    else:
+        dc, rest = outs
+        p_dc, p_rest, s_dc, s_rest = dc.data_ptr(), rest.data_ptr(), 3, 3 * (M - 1)
+    if not (dc.is_contiguous() and rest.is_contiguous() and gathered.is_contiguous()):
+        raise RuntimeError("sh_grad_expand: contiguous tensors expected")
+    if dc.numel() + (rest.numel() if rest is not dc else 0) != 3 * M * P:
+        raise RuntimeError("sh_grad_expand: the output tensors do not hold %d x %d x 3 floats" % (P, M))
+    with torch.cuda.device(gathered.device):
+        _check(lib.gof_sh_grad_expand(P, src["degree"], M, n_views, _ptr(src["means3D"]), gathered.data_ptr() + 12 * P, vs,
+                                      gathered.data_ptr(), vs, float(scale), p_dc, s_dc, p_rest if M > 1 else None, s_rest, _stream()))
 
 
 class IntegrateViewCache:

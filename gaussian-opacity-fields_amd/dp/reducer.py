@@ -6,6 +6,12 @@ Gaussians: large enough to run at link bandwidth, a single launch instead of six
 one multi-tensor copy.  `_features_rest` is 76 % of the bytes; splitting it into more buckets
 only adds launches.  The reduction is a SUM by default (the reference accumulates one view per
 optimiser step; summing N views keeps its per-view gradient scale) or a MEAN.
+
+Compressed SH gradient (`sh_params`): the SH gradient of a view is an outer product of 12 B of information per
+Gaussian (the blend's colour gradient) with the SH basis of the view direction; ranks all-gather those 12 B and expand
+the sum over views locally (gof_sh_grad_pack / gof_sh_grad_expand) instead of all-reducing 192 B.  Bytes on the wire
+per Gaussian and rank at N ranks: dense ring all-reduce 2(N-1)/N x 236; compressed 2(N-1)/N x 44 + (N-1) x 12
+(N = 8: 413 -> 161; N = 2: 236 -> 56).  The sum runs over the views in rank order: deterministic and identical on all ranks.
 """
 from typing import Iterable, List
 
@@ -19,8 +25,14 @@ def shard_views(views: List, rank: int, world: int) -> List:
 
 
 class GradientAllReducer:
-    def __init__(self, params: Iterable[torch.Tensor], average: bool = False, group=None, wire_dtype=None):
-        """wire_dtype: None (default) = all-reduce the fp32 gradients as they are.  torch.bfloat16 halves the bytes on the xGMI
+    def __init__(self, params: Iterable[torch.Tensor], average: bool = False, group=None, wire_dtype=None, sh_params=None, sh_ops=None,
+                 track: bool = True):
+        """sh_params: the SH parameter(s) among `params` whose gradient may travel in compressed form -- one [P,M,3] tensor, or
+        the reference's pair (_features_dc [P,1,3], _features_rest [P,M-1,3]).  Used only when their gradient since the last
+        exchange stems from exactly one rasterizer backward (else the dense path runs).  sh_ops: the pack / expand
+        implementation (default: the HIP kernels behind diff_gaussian_rasterization._backend).  track=False: the caller has
+        switched the rasterizer's tracking on itself (a reducer built per step must not reset it).
+        wire_dtype: None (default) = all-reduce the fp32 gradients as they are.  torch.bfloat16 halves the bytes on the xGMI
         links (the collective is exposed at the end of the step) at the price of bf16-rounded gradient sums --
         an opt-in for training runs, never used by bench.py's headline."""
         self.params = list(params)
@@ -29,6 +41,47 @@ class GradientAllReducer:
         self.wire_dtype = wire_dtype
         self._flat = None
         self._wire = None
+        self.sh_params = list(sh_params) if sh_params else []
+        if len(self.sh_params) > 2:
+            raise ValueError("sh_params: one [P,M,3] tensor or the pair (features_dc, features_rest)")
+        self._sh_ops = sh_ops
+        self.last_exchange = None                    # "dense" | "compressed-sh": what the last all_reduce() did (tests, logging)
+        if self.sh_params and track:
+            self._ops().track(True)
+
+    def _ops(self):
+        if self._sh_ops is None:
+            from diff_gaussian_rasterization import _backend as B     # HIP library; raises ImportError if it is missing
+
+            class _HipOps:
+                track = staticmethod(B.track_sh_grad_source)
+                take = staticmethod(B.take_sh_grad_source)
+                pack = staticmethod(B.sh_grad_pack)
+                expand = staticmethod(B.sh_grad_expand)
+            self._sh_ops = _HipOps
+        return self._sh_ops
+
+    def _exchange_sh_compressed(self, world):
+        """All-gather the packed colour gradients (+ camera centres) and expand the sum over views into the SH gradients.
+        Returns False (nothing done) when the compressed form is not applicable this step."""
+        src = self._ops().take()
+        grads = [p.grad for p in self.sh_params]
+        if src is None or any(g is None for g in grads):
+            return False
+        P, M = src["P"], src["M"]
+        if sum(g.numel() for g in grads) != 3 * M * P or not all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+            return False
+        dev = grads[0].device
+        mine = torch.empty((P + 1, 3), dtype=torch.float32, device=dev)
+        self._ops().pack(src, mine)
+        mine[P].copy_(src["campos"].reshape(3))
+        gathered = torch.empty((world, P + 1, 3), dtype=torch.float32, device=dev)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        else:                                        # gloo (CPU tests, single-GPU development runs)
+            dist.all_gather(list(gathered.unbind(0)), mine, group=self.group)
+        self._ops().expand(src, gathered, 1.0 / world if self.average else 1.0, grads)
+        return True
 
     def _ensure(self, n, device, dtype):
         if self._flat is None or self._flat.numel() != n or self._flat.device != device:
@@ -39,6 +92,7 @@ class GradientAllReducer:
     def _shared_bucket(grads):
         """If the gradients are contiguous, ascending, non-overlapping views of ONE storage with < 16 B of padding between them
         (diff_gaussian_rasterization's backward allocates them that way), return the covering 1-D view, else None."""
+        grads = sorted(grads, key=lambda g: g.storage_offset())
         g0 = grads[0]
         if any((not g.is_contiguous()) or g.dtype != g0.dtype or g.device != g0.device or
                g.untyped_storage().data_ptr() != g0.untyped_storage().data_ptr() for g in grads):
@@ -56,7 +110,16 @@ class GradientAllReducer:
     def all_reduce(self):
         ps = [p for p in self.params if p.grad is not None]
         if not ps or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            if self.sh_params:
+                self._ops().take()                   # nothing to exchange: forget the tracked backward
             return
+        self.last_exchange = "dense"
+        if self.sh_params and self._exchange_sh_compressed(dist.get_world_size(self.group)):
+            self.last_exchange = "compressed-sh"
+            sh_ids = {id(p) for p in self.sh_params}
+            ps = [p for p in ps if id(p) not in sh_ids]
+            if not ps:
+                return
         bucket = self._shared_bucket([p.grad for p in ps])
         if bucket is not None and self.wire_dtype is not None:
             if self._wire is None or self._wire.numel() != bucket.numel() or self._wire.device != bucket.device:

@@ -9,7 +9,9 @@ Injection points; NEW behaviour, the reference has no multi-GPU
   * train.py:370 pins cuda:0           -> HIP_VISIBLE_DEVICES=<LOCAL_RANK> is exported before torch initialises HIP
   * train.py:135-137 camera sampling   -> Scene.getTrainCameras returns this rank's shard cams[rank::world]
   * gaussian_model.py:342-364          -> training_setup registers an optimizer step pre-hook that all-reduces
-                                          the parameter gradients (the optimizer object survives densification)
+                                          the parameter gradients (the optimizer object survives densification); the SH
+                                          gradient (81 % of the bytes) travels in compressed form, dp/reducer.py
+                                          (GOF_DP_DENSE_SH=1: dense all-reduce of everything)
   * gaussian_model.py:685-707          -> densify_and_prune first all-reduces the statistics accumulated since the last
                                           densification (SUM for the accumulators / denom, MAX for max_radii2D / abs-max)
   * train.py:247-250,276-301           -> only rank 0 writes point clouds / checkpoints / TensorBoard
@@ -54,9 +56,16 @@ def main():
         _setup(self, training_args)
 
         def pre_step(optimizer, args, kwargs):
+            # the nn.Parameters are replaced by every densification (gaussian_model.py:532-607): collect them per step
             params = [p for g in optimizer.param_groups for p in g["params"]]
-            GradientAllReducer(params).all_reduce()
+            by_name = {g.get("name"): g["params"][0] for g in optimizer.param_groups if len(g["params"]) == 1}
+            sh = [by_name[n] for n in ("f_dc", "f_rest") if n in by_name]      # gaussian_model.py:351-352
+            compress = len(sh) == 2 and os.environ.get("GOF_DP_DENSE_SH") != "1"
+            GradientAllReducer(params, sh_params=sh if compress else None, track=False).all_reduce()
         self.optimizer.register_step_pre_hook(pre_step)
+        if os.environ.get("GOF_DP_DENSE_SH") != "1":
+            from diff_gaussian_rasterization import _backend as _B
+            _B.track_sh_grad_source(True)
     GaussianModel.training_setup = training_setup
 
     # Densification statistics are accumulated per rank (each rank sees other views) and zeroed by every densification

@@ -217,6 +217,25 @@ int gof_mark_visible(int32_t P, const float* means3D,
                      const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
+/* ---- data-parallel training: compressed exchange of the SH gradient --------------------
+ * No reference counterpart (the reference trains on one GPU).  The SH gradient of one view,
+ * computeColorFromSH's backward (backward.cu:20-139), is an outer product dL_dsh[k] = basis_k(dir) * dL_dRGB with
+ * dL_dRGB = the blend's colour gradient masked by the forward's clamp flags: 12 bytes of information per Gaussian expanded
+ * to 192.  View-sharded ranks all-gather dL_dRGB and expand the sum over views locally instead of all-reducing dL_dsh.
+ * gof_sh_grad_pack: packed[P,3] = dL_dcolors (gof_backward's output) masked as backward.cu:36-38, zero for radii <= 0.
+ * gof_sh_grad_expand: for every Gaussian i and coefficient k < M
+ *     out[i][k] = scale * sum_{v < n_views} basis_k(normalize(means3D[i] - campos[v])) * packed[v][i]   (k < (D+1)^2, else 0)
+ * views summed in index order; coefficient 0 is written to out_dc + i*stride_dc, coefficient k >= 1 to
+ * out_rest + i*stride_rest + 3(k-1) (strides in floats).  One [P,M,3] tensor: out_dc = t, out_rest = t + 3, both strides 3M;
+ * the reference's separate _features_dc [P,1,3] / _features_rest [P,M-1,3] (gaussian_model.py:351-352): strides 3 and 3(M-1).
+ * View v reads packed + v*packed_stride ([P,3]) and campos + v*campos_stride ([3]); device arrays, strides in floats (an
+ * all-gathered buffer of [P+1,3] rows per rank, the last row being the rank's camera centre: both strides 3(P+1)). */
+int gof_sh_grad_pack(int32_t P, const float* dL_dcolors, const void* geom_ws, size_t geom_bytes, const int32_t* radii,
+                     float* packed, void* stream);
+int gof_sh_grad_expand(int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,
+                       const float* campos, int64_t campos_stride, const float* packed, int64_t packed_stride, float scale,
+                       float* out_dc, int64_t stride_dc, float* out_rest, int64_t stride_rest, void* stream);
+
 /* ---- marching tetrahedra (replaces utils/tetmesh.py:47-138, pure torch in the reference) */
 /* Phase 1: classify tets, collect the unique crossing edges (sorted ascending by
  * (min vertex, max vertex), the order torch.unique(dim=0) produces, tetmesh.py:110) and

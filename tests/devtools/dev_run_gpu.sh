@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print(d['value'], d['ms_per_step'])
-print(json.dumps(d['full_loop'],indent=1))"
+( time timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 ) 2>&1 | cut -c1-250
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

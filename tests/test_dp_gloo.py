@@ -71,8 +71,72 @@ def _worker(rank, world, port, ret):
         ok = ok and all(torch.allclose(p.grad, e, rtol=2e-2, atol=2e-2) for p, e in zip(params, expect))
     except RuntimeError as ex:                       # a gloo build without bf16 reductions: the option is exercised on RCCL only
         ok = ok and "BFloat16" in str(ex)
-    # ... and a set that is NOT one ascending allocation falls back to pack / reduce / unpack
-    ok = ok and GradientAllReducer._shared_bucket([params[1].grad, params[0].grad]) is None
+    # ... and a set that does NOT cover one allocation without gaps falls back to pack / reduce / unpack
+    ok = ok and GradientAllReducer._shared_bucket([params[2].grad, params[0].grad]) is None      # params[1] lies between them
+    # compressed SH-gradient exchange (communication logic; the pack / expand kernels are HIP, tests/test_parity_gpu.py): a stand-in
+    # "basis" b_k(campos) = cos(k + campos.sum()), dense gradient of a view = b_k * packed -- the reducer must give every rank
+    # sum_views b_k(campos_view) * packed_view for the SH tensors and the plain sum for the others, in one all-gather + one all-reduce
+    class FakeOps:
+        src = None
+
+        @staticmethod
+        def track(on):
+            pass
+
+        @staticmethod
+        def take():
+            s_, FakeOps.src = FakeOps.src, None
+            return s_
+
+        @staticmethod
+        def pack(src, out):
+            out[:src["P"]] = src["packed"]
+
+        @staticmethod
+        def expand(src, gathered, scale, outs):
+            Pn, M = src["P"], src["M"]
+            tot = torch.zeros(Pn, M, 3)
+            for v in range(gathered.shape[0]):
+                b = torch.cos(torch.arange(M, dtype=torch.float32) + gathered[v, Pn].sum())
+                tot += b[None, :, None] * gathered[v, :Pn][:, None, :]
+            tot *= scale
+            if len(outs) == 1:
+                outs[0].copy_(tot)
+            else:
+                outs[0].copy_(tot[:, :1]); outs[1].copy_(tot[:, 1:])
+
+    def view_of(r):
+        gg = torch.Generator().manual_seed(900 + r)
+        return torch.randn(P, 3, generator=gg), torch.randn(3, generator=gg)
+
+    def dense_sh(packed, campos):
+        b = torch.cos(torch.arange(16, dtype=torch.float32) + campos.sum())
+        return b[None, :, None] * packed[:, None, :]
+    want_sh = sum(dense_sh(*view_of(r)) for r in range(world))
+    for split in (False, True):
+        xyz = torch.randn(P, 3, generator=g).requires_grad_(True)
+        xyz.grad = local[0].clone()
+        packed, campos = view_of(rank)
+        if split:
+            shp = [torch.zeros(P, 1, 3, requires_grad=True), torch.zeros(P, 15, 3, requires_grad=True)]
+            shp[0].grad = dense_sh(packed, campos)[:, :1].contiguous(); shp[1].grad = dense_sh(packed, campos)[:, 1:].contiguous()
+        else:
+            shp = [torch.zeros(P, 16, 3, requires_grad=True)]
+            shp[0].grad = dense_sh(packed, campos)
+        red3 = GradientAllReducer([xyz] + shp, sh_params=shp, sh_ops=FakeOps, average=split)
+        FakeOps.src = {"P": P, "M": 16, "packed": packed, "campos": campos}
+        red3.all_reduce()
+        div = world if split else 1
+        got = torch.cat([p.grad for p in shp], 1)
+        ok = ok and red3.last_exchange == "compressed-sh" and torch.allclose(got, want_sh / div, atol=1e-5)
+        ok = ok and torch.allclose(xyz.grad, expect[0] / div, atol=1e-6)
+        # no tracked backward (or more than one): the dense path reduces everything
+        xyz.grad = local[0].clone()
+        for p_, part in zip(shp, ([dense_sh(packed, campos)] if not split else [dense_sh(packed, campos)[:, :1].contiguous(), dense_sh(packed, campos)[:, 1:].contiguous()])):
+            p_.grad = part
+        red3.all_reduce()
+        got = torch.cat([p.grad for p in shp], 1)
+        ok = ok and red3.last_exchange == "dense" and torch.allclose(got, want_sh / div, atol=1e-5)
     # densification statistics
     acc = torch.full((P, 1), float(rank + 1)); acc_abs = acc.clone(); denom = torch.ones(P, 1)
     radii = torch.full((P,), float(rank)); absmax = torch.full((P, 1), float(10 - rank))

@@ -1,0 +1,93 @@
+"""GPU, two ranks on ONE device (gloo carries the collectives; the driver's multi-GPU runs use RCCL with the same code path):
+the data-parallel training step with the real kernels -- rasterizer forward/backward per rank on its own view, then the gradient
+exchange of dp.GradientAllReducer in both forms (dense all-reduce of everything; SH gradient compressed to 12 B per Gaussian and
+view + all-reduce of the rest).  Both must leave identical gradients on both ranks."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, ret):
+    for p in (os.path.join(ROOT, "gaussian-opacity-fields_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import synthetic_scenes as S
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from dp import GradientAllReducer
+    from test_parity_gpu import _orbit_camera
+    base = S.scene_lego_like(P=20000, W=200, H=150, seed=8)                   # identical replica on every rank
+    base["opacities"][:] = 0.5
+    cam = _orbit_camera(200, 150, 0.69, 0.7 + 2.1 * rank, 0.5 - 0.6 * rank)    # one view per rank
+    sd = to_dev({**base, **cam})
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    from diff_gaussian_rasterization import _backend as B
+    # ONE forward/backward per rank (the backward's atomic accumulation order differs from run to run, so the two exchange forms
+    # are applied to copies of the same local gradients)
+    B.track_sh_grad_source(True)
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    color, _ = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                                     opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+    dL = torch.randn(color.shape, generator=torch.Generator().manual_seed(3 + rank)).to(color.device)
+    color.backward(dL)
+    local = {k: params[k].grad.clone() for k in names}
+    src = B.take_sh_grad_source()
+    results = {}
+    for mode in ("dense", "compressed", "compressed-mean"):
+        for k in names:
+            params[k].grad = local[k].clone()
+        red = GradientAllReducer(list(params.values()), sh_params=None if mode == "dense" else [params["shs"]], average=mode.endswith("mean"),
+                                 track=False)
+        B._sh_track.update(count=1, src=src)                                   # as if the backward had just run
+        red.all_reduce()
+        torch.cuda.synchronize()
+        results[mode] = ({k: params[k].grad.clone() for k in names}, red.last_exchange, local["shs"])
+    ok = results["dense"][1] == "dense" and results["compressed"][1] == "compressed-sh"
+    msg = []
+    for k in names:
+        a, b, c = results["dense"][0][k], results["compressed"][0][k], results["compressed-mean"][0][k]
+        # two ranks: a + b is the only possible order, so the two forms agree bit for bit
+        if not torch.equal(a, b):
+            ok = False; msg.append("%s: dense vs compressed max diff %.3e" % (k, (a - b).abs().max().item()))
+        if not torch.allclose(c, a / world, rtol=1e-6, atol=0):
+            ok = False; msg.append("%s: mean" % k)
+    # the exchange really added the other rank's view: the reduced SH gradient differs from the local one
+    ok = ok and not torch.equal(results["compressed"][0]["shs"], results["compressed"][2])
+    # every rank holds the same reduced gradients
+    chk = torch.stack([results["compressed"][0][k].double().sum() for k in names]).cpu()
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    ok = ok and all(torch.equal(g, gathered[0]) for g in gathered)
+    ret[rank] = (bool(ok), "; ".join(msg))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_dense_and_compressed_gradient_exchange_agree():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret.get(r, (False, "no result"))[0] for r in range(world)), dict(ret)

@@ -14,6 +14,8 @@ Bars (stated per test):
   * K9 (per-Gaussian backward) on bit-identical inputs -- 1e-5 relative (it is an ill-conditioned
     function of dL_dview2gaussian, so it is checked in isolation; the end-to-end figure is reported).
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -363,7 +365,7 @@ def test_fused_forward_matches_the_two_stage_forward_and_recovers_from_a_small_c
 
 
 def test_parameter_gradients_share_one_allocation_for_the_dp_reducer():
-    """The backward carves the gradients of (means3D, sh, opacity, scales, rotations) from ONE buffer in that order; after
+    """The backward carves the gradients of (means3D, opacity, scales, rotations, sh) from ONE buffer in that order; after
     autograd they are still views of it, so dp.GradientAllReducer all-reduces the bucket in place (no pack / unpack)."""
     from diff_gaussian_rasterization import GaussianRasterizer
     from dp import GradientAllReducer
@@ -377,6 +379,73 @@ def test_parameter_gradients_share_one_allocation_for_the_dp_reducer():
     bucket = GradientAllReducer._shared_bucket(grads)
     assert bucket is not None and bucket.numel() >= sum(g.numel() for g in grads)
     assert all(g.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr() for g in grads)
+
+
+def _orbit_camera(W, H, fovx, theta, phi, radius=4.03):
+    focal = W / (2 * math.tan(fovx / 2))
+    fovy = 2 * math.atan(H / (2 * focal))
+    c = radius * np.array([math.cos(phi) * math.sin(theta), -math.sin(phi), math.cos(phi) * math.cos(theta)])
+    fwd = -c / np.linalg.norm(c)
+    right = np.cross(np.array([0.0, -1.0, 0.0]), fwd); right /= np.linalg.norm(right)
+    R_c2w = np.stack([right, np.cross(fwd, right), fwd], 1)
+    return S.camera(W, H, fovx, fovy, R=R_c2w, T=-R_c2w.T @ c)
+
+
+@pytest.mark.parametrize("degree", [3, 1, 0])
+def test_sh_gradient_compressed_exchange_equals_the_sum_of_the_dense_gradients(degree):
+    """Data-parallel exchange of the SH gradient (gof_sh_grad_pack / gof_sh_grad_expand): three views of the same Gaussians, as
+    three ranks would render them.  Expanding the three packed colour gradients (12 B per Gaussian and view) gives bit for bit
+    (g_view0 + g_view1) + g_view2 of the dense dL_dsh tensors K9 produced -- every product basis_k(dir) * dL_dRGB is the one K9
+    forms, and the views are summed in index order.  Also: the split (features_dc, features_rest) output layout of the
+    reference's parameters, the mean (scale 1/n), and take_sh_grad_source()'s exactly-one-backward rule."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    base = S.scene_lego_like(P=6000, W=160, H=120, seed=4, sh_degree=degree)
+    base["opacities"][:] = 0.6
+    base["shs"][:500] *= 30.0                                # saturated colours: clamp flags set (backward.cu:36-38)
+    cams = [_orbit_camera(160, 120, 0.69, th, ph) for th, ph in ((0.7, 0.5), (-1.9, 0.2), (2.8, -0.6))]
+    B.track_sh_grad_source(True)
+    try:
+        dense, rows, P = [], [], 6000
+        for i, cam in enumerate(cams):
+            sd = to_dev({**base, **cam})
+            params = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+            means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+            color, radii = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                                                 opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+            dL = torch.randn(color.shape, generator=torch.Generator().manual_seed(50 + i)).to(color.device)
+            color.backward(dL)
+            src = B.take_sh_grad_source()
+            assert src is not None and src["P"] == P and src["M"] == 16 and src["degree"] == degree
+            assert B.take_sh_grad_source() is None           # consumed
+            row = torch.full((P + 1, 3), float("nan"), device=color.device)
+            B.sh_grad_pack(src, row)
+            row[P] = sd["campos"]
+            assert (row[:P][radii <= 0] == 0).all() and torch.isfinite(row).all()
+            dense.append(params["shs"].grad.clone()); rows.append(row)
+        assert (radii <= 0).any() and (dense[0][:, 0].abs().sum(1) == 0).any()
+        gathered = torch.stack(rows).contiguous()
+        want = (dense[0] + dense[1]) + dense[2]
+        out = torch.full_like(want, float("nan"))
+        B.sh_grad_expand(src, gathered, 1.0, [out])
+        assert torch.equal(out, want)
+        if degree < 3:
+            assert (out[:, (degree + 1) ** 2:] == 0).all()
+        dc = torch.full((P, 1, 3), float("nan"), device=out.device); rest = torch.full((P, 15, 3), float("nan"), device=out.device)
+        B.sh_grad_expand(src, gathered, 1.0, [dc, rest])
+        assert torch.equal(torch.cat((dc, rest), 1), want)
+        B.sh_grad_expand(src, gathered, 1.0 / 3, [out])
+        torch.testing.assert_close(out, want / 3, rtol=2e-6, atol=0)
+        B.sh_grad_expand(src, gathered[1:2].contiguous(), 1.0, [out])          # a single view reproduces K9's tensor
+        assert torch.equal(out, dense[1])
+        # two backwards since the last exchange: the compressed form does not apply
+        for _ in range(2):
+            params["shs"].grad = None
+            c2, _ = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                                          opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+            c2.sum().backward()
+        assert B.take_sh_grad_source() is None
+    finally:
+        B.track_sh_grad_source(False)
 
 
 def test_integrate_with_no_visible_gaussian_and_with_no_point_in_view():
