@@ -5,6 +5,7 @@
 // buffer management (reference rasterize_points.cu:28-122).  No torch types, no global state,
 // every launch on the caller's stream.
 #include "gof_common.h"
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -434,12 +435,20 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     // preprocess_bwd<true> (SH rows tiled through LDS) writes every element of dL_dsh itself: no memset for it
     const bool k9_tiled = a->shs && dL_dsh && a->M == 16 && ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
     { GOF_PROFILE("backward_memsets", stream);
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dmeans2D, 0, 3 * P * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dcolors, 0, 3 * P * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), stream));
-    if (dL_dcov3D) GOF_HIP_CHECK(hipMemsetAsync(dL_dcov3D, 0, 6 * P * sizeof(float), stream));
-    if (dL_dsh && a->M > 0 && !k9_tiled) GOF_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, 3 * P * (size_t)a->M * sizeof(float), stream));
-    GOF_HIP_CHECK(hipMemsetAsync(dL_dview2gaussian, 0, 10 * P * sizeof(float), stream)); }
+      // exactly adjacent buffers (the Python binding carves dL_dview2gaussian | dL_dcov3D | dL_dmeans2D | dL_dcolors from one
+      // allocation) are cleared by ONE memset: each launch costs ~5 us of queue time, the bytes themselves 0.01 ms
+      struct Range { char* p; size_t n; } r[6];
+      int nr = 0;
+      auto add = [&](void* ptr, size_t floats) { if (ptr && floats) { r[nr].p = static_cast<char*>(ptr); r[nr].n = floats * sizeof(float); nr++; } };
+      add(dL_dmeans2D, 3 * P); add(dL_dcolors, 3 * P); add(dL_dopacity, P); add(dL_dcov3D, 6 * P); add(dL_dview2gaussian, 10 * P);
+      if (dL_dsh && a->M > 0 && !k9_tiled) add(dL_dsh, 3 * P * (size_t)a->M);
+      std::sort(r, r + nr, [](const Range& x, const Range& y) { return x.p < y.p; });
+      for (int i = 0; i < nr; ) {
+          char* p0 = r[i].p; size_t n = r[i].n; int j = i + 1;
+          while (j < nr && r[j].p == p0 + n) { n += r[j].n; j++; }
+          GOF_HIP_CHECK(hipMemsetAsync(p0, 0, n, stream));
+          i = j;
+      } }
 
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);

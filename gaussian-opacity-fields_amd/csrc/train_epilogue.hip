@@ -344,21 +344,33 @@ loss_geom_kernel(int W, int H, const float* __restrict__ rendering, const float*
     if (threadIdx.x == 0) { partial_dn[tile] = e; partial_dist[tile] = d; }
 }
 
-// one block: fixed-order sums of the four partial arrays, then the scalar composition of train.py:161, 188 in fp32
+// one block of 1024 threads: fixed-order sums of the four partial arrays, then the scalar composition of train.py:161, 188 in fp32
 // terms = {loss, Ll1, ssim, rgb_loss, depth_normal_loss, distortion_loss}
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 loss_final_kernel(const float* __restrict__ p_ssim, const float* __restrict__ p_l1, const float* __restrict__ p_dn,
                   const float* __restrict__ p_dist, int tiles, float n_rgb, float n_pix, float w_l1, float lambda_dssim,
                   float lambda_dn, float lambda_dist, float* __restrict__ terms)
 {
-    __shared__ float s_red[4][4];
+    __shared__ float s_red[4][16];
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < 3 * tiles; i += 256) { v[0] += p_ssim[i]; v[1] += p_l1[i]; }
-    for (int i = threadIdx.x; i < tiles; i += 256) { v[2] += p_dn[i]; v[3] += p_dist[i]; }
-    float tot[4];
+    for (int i = threadIdx.x; i < 3 * tiles; i += 1024) { v[0] += p_ssim[i]; v[1] += p_l1[i]; }
+    for (int i = threadIdx.x; i < tiles; i += 1024) { v[2] += p_dn[i]; v[3] += p_dist[i]; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 4; k++) tot[k] = block_sum_256(v[k], s_red[k]);
+    for (int k = 0; k < 4; k++) {
+        float x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) s_red[k][wave] = x;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        float tot[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float x = 0.f;
+            for (int w = 0; w < 16; w++) x += s_red[k][w];       // fixed order: deterministic
+            tot[k] = x;
+        }
         const float Ll1 = tot[1] / n_rgb, ssim = tot[0] / n_rgb, dn = tot[2] / n_pix, dist = tot[3] / n_pix;
         const float rgb = w_l1 * Ll1 + lambda_dssim * (1.0f - ssim);
         terms[0] = rgb + dn * lambda_dn + dist * lambda_dist;
@@ -555,7 +567,7 @@ int gof_train_loss(int32_t W, int32_t H, const float* rendering, const float* gt
       hipLaunchKernelGGL(loss_geom_kernel, grid1, dim3(256), 0, stream, W, H, rendering, world_view_transform, inv_fx, inv_fy, ncx, ncy,
                          (float)(lambda_depth_normal / n_pix), (float)(lambda_distortion / n_pix), p_dn, p_dist, gN, dL_drendering);
       GOF_LAUNCH_CHECK(stream, 0);
-      hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, p_ssim, p_l1, p_dn, p_dist, (int)tiles, (float)n_rgb,
+      hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, stream, p_ssim, p_l1, p_dn, p_dist, (int)tiles, (float)n_rgb,
                          (float)n_pix, (float)(1.0 - lambda_dssim), (float)lambda_dssim, (float)lambda_depth_normal,
                          (float)lambda_distortion, terms);
       GOF_LAUNCH_CHECK(stream, 0);

@@ -251,8 +251,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_opacity = bucket[offs[1]:offs[1] + sizes[1]].view(P, 1)
     g_scales = bucket[offs[2]:offs[2] + sizes[2]].view(P, 3); g_rot = bucket[offs[3]:offs[3] + sizes[3]].view(P, 4)
     g_sh = bucket[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
-    g_means2D = torch.empty((P, 3), **f); g_colors = torch.empty((P, 3), **f)
-    g_cov3D = torch.empty((P, 6), **f); g_v2g = torch.empty((P, 10), **f)
+    # what the blend ACCUMULATES into (and the dead dL_dcov3D) must be zero-filled: one allocation, no padding, so that the library
+    # clears it with a single memset (widest rows first: every segment stays 8-byte aligned)
+    acc = torch.empty(22 * P, **f)
+    g_v2g = acc[:10 * P].view(P, 10); g_cov3D = acc[10 * P:16 * P].view(P, 6)
+    g_means2D = acc[16 * P:19 * P].view(P, 3); g_colors = acc[19 * P:22 * P].view(P, 3)
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):

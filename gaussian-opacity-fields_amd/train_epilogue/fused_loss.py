@@ -24,6 +24,7 @@ class _TrainingLoss(torch.autograd.Function):
         terms, dL = B.train_loss(rendering, gt_image, _taps(B.SSIM_WINDOW), wvt, fx, fy, lambda_dssim, lambda_depth_normal,
                                  lambda_distortion, ctx.needs_input_grad[0])
         ctx.save_for_backward(dL)
+        ctx.set_materialize_grads(False)                     # no zero-filled gradients for the five logging outputs
         outs = tuple(terms[i] for i in range(6))
         ctx.mark_non_differentiable(*outs[1:])               # the individual terms are for logging (train.py:239-247)
         return outs
@@ -31,7 +32,7 @@ class _TrainingLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         (dL,) = ctx.saved_tensors
-        return (dL * g_loss if dL is not None else None), None, None, None, None, None, None, None
+        return (dL * g_loss if (dL is not None and g_loss is not None) else None), None, None, None, None, None, None, None
 
 
 def training_loss(rendering, gt_image, viewpoint_cam, lambda_dssim=0.2, lambda_depth_normal=0.0, lambda_distortion=0.0):

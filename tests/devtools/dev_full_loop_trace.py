@@ -1,0 +1,12 @@
+"""Kernel list of bench.py's full training iteration with the one-call loss (rocprofv3 --kernel-trace --stats around this script)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in ("", "gaussian-opacity-fields_amd", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import bench
+import synthetic_scenes as S
+from gpu_common import to_dev
+dev = torch.device("cuda", 0)
+sd = to_dev(S.scene_frustum(1_000_000, W=1600, H=1063, focal=1200.0, seed=0), dev)
+print(bench.full_loop(sd, dev, 1600, 1063, steps=10, warmup=2))
