@@ -216,14 +216,22 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     import types
     import train_epilogue as T
     from gpu_common import settings_from
-    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    from diff_gaussian_rasterization import GaussianRasterizer, SplitSH, _backend as B
     raw = {
         "xyz": sd["means3D"].clone(), "f_dc": sd["shs"][:, :1].clone(), "f_rest": sd["shs"][:, 1:].clone(),
         "opacity": torch.logit(sd["opacities"].clamp(1e-4, 1 - 1e-4)), "scaling": torch.log(sd["scales"]), "rotation": sd["rotations"].clone(),
     }
     lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 5e-2, "scaling": 5e-3, "rotation": 1e-3}
-    params = {k: torch.nn.Parameter(v.contiguous()) for k, v in raw.items()}
-    opt = T.FusedAdam([{"params": [p], "lr": lrs[k], "name": k} for k, p in params.items()], lr=0.0, eps=1e-15)   # gaussian_model.py:349-360
+    params, opt = {}, None
+
+    def reset():
+        """Every leg starts from the same parameters and a fresh optimizer state (the legs would otherwise time different scenes:
+        ~13 Adam steps against a random target image change the workload)."""
+        nonlocal opt
+        params.clear()
+        params.update({k: torch.nn.Parameter(v.clone().contiguous()) for k, v in raw.items()})
+        opt = T.FusedAdam([{"params": [p], "lr": lrs[k], "name": k} for k, p in params.items()], lr=0.0, eps=1e-15)   # gaussian_model.py:349-360
+    reset()
     rast = GaussianRasterizer(settings_from(sd))
     means2D = torch.zeros_like(params["xyz"], requires_grad=True)
     gt = torch.rand((3, H, W), generator=torch.Generator().manual_seed(7)).to(dev)
@@ -232,8 +240,10 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     lambda_dssim, lambda_dn, lambda_dist = 0.2, 0.05, 100.0        # arguments/__init__.py defaults
     filter_3D = (sd["scales"].min(dim=1, keepdim=True).values * 0.1).contiguous()           # a small 3D smoothing filter (compute_3D_filter's role)
 
-    def iteration(one_call_loss=False):
-        shs = torch.cat((params["f_dc"], params["f_rest"]), dim=1)                           # get_features (gaussian_model.py:173-176)
+    def iteration(one_call_loss=False, split_sh=False):
+        # get_features (gaussian_model.py:173-176): the concatenation as the reference forms it, or -- with the launcher's default
+        # rebinding -- the two stored tensors handed over as they are (SplitSH)
+        shs = SplitSH(params["f_dc"], params["f_rest"]) if split_sh else torch.cat((params["f_dc"], params["f_rest"]), dim=1)
         A = T.activations                                                                    # gaussian_renderer/__init__.py:60,70-71
         rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=shs,
                                 opacities=A.opacity_with_3D_filter(params["opacity"], params["scaling"], filter_3D),
@@ -266,6 +276,7 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
         iteration()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    reset()
     for _ in range(warmup):
         iteration(True)
     torch.cuda.synchronize()
@@ -274,6 +285,16 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
         iteration(True)
     torch.cuda.synchronize()
     ms_one = 1e3 * (time.perf_counter() - t0) / steps
+    reset()
+    for _ in range(warmup):
+        iteration(True, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration(True, True)
+    torch.cuda.synchronize()
+    ms_split = 1e3 * (time.perf_counter() - t0) / steps
+    reset()
     B.profile_enable(True)                    # epilogue kernel durations: three more iterations with the library's HIP events
     for _ in range(3):
         iteration()
@@ -288,7 +309,10 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
            "epilogue_kernels_ms": ep,
            "one_call_loss": {"ms_per_iter": round(ms_one, 4), "iters_per_s": round(1e3 / ms_one, 2),
                              "what": "the same iteration with train.py:150-188 evaluated by train_epilogue.training_loss (gof_train_loss, "
-                                     "five launches) instead of the inline torch composition; needs the 7-line train.py change of INTEGRATION.md"}}
+                                     "five launches) instead of the inline torch composition; needs the 7-line train.py change of INTEGRATION.md"},
+           "one_call_loss_split_sh": {"ms_per_iter": round(ms_split, 4), "iters_per_s": round(1e3 / ms_split, 2),
+                                      "what": "... and the SH coefficients read from _features_dc / _features_rest directly (SplitSH, the launcher's "
+                                              "default rebinding of GaussianModel.get_features) instead of their per-iteration concatenation"}}
     if ep.get("adam_step"):
         out["adam_GBps"] = round(28.0 * n_floats / (ep["adam_step"] * 1e-3) / 1e9, 1)     # p,g,m,v read + p,m,v written
     return out

@@ -18,15 +18,15 @@ namespace gof {
 // ---- kernels / helpers defined in the other translation units -------------------------------------
 
 __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
-                               const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                               const float* rotations, const float* opacities, const float* shs, const float* shs_rest, const float* cov3D_precomp,
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
                                int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out, float4* fconic_out,
                                uint32_t* tiles_touched, uint2* rect_out, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
-template <bool TILED>
-__global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs,
+template <int MODE>
+__global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs, const float* shs_rest,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
-                               const float* dL_dv2g, const float* dL_dcolor, float* dL_dmeans, float* dL_dsh,
+                               const float* dL_dv2g, const float* dL_dcolor, float* dL_dmeans, float* dL_dsh, float* dL_dsh_rest,
                                float* dL_dscales, float* dL_drots);
 __global__ void preprocess_points(int PN, const float* points3D, Cam cam, int W, int H, float focal_x, float focal_y,
                                   float2* points2D, float* depths, uint32_t* tiles_touched);
@@ -194,6 +194,7 @@ static int validate(const GofRasterArgs* a)
         set_error("a required pointer is NULL"); return GOF_E_INVALID; }
     if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return GOF_E_INVALID; }
     if (a->shs && (a->M <= 0 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M)) { set_error("SH degree %d does not fit M=%d", a->D, a->M); return GOF_E_INVALID; }
+    if (a->shs_rest && (!a->shs || a->M != 16)) { set_error("shs_rest (separate DC / higher-band SH tensors) needs shs and M == 16, got M=%d", a->M); return GOF_E_INVALID; }
     if (!a->cov3D_precomp && (!a->scales || !a->rotations)) { set_error("scales/rotations or cov3D_precomp required"); return GOF_E_INVALID; }
     if (!a->view2gaussian_precomp && (!a->scales || !a->rotations)) { set_error("scales/rotations required to compute view2gaussian"); return GOF_E_INVALID; }
     return GOF_OK;
@@ -260,7 +261,7 @@ using namespace gof;
 extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
-int gof_abi_version(void) { return 1; }
+int gof_abi_version(void) { return 2; }
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
@@ -276,7 +277,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
     GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));
     { GOF_PROFILE("preprocess_fwd", stream);
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
-                       a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs,
+                       a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox, g.fconic,
                        g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags); }
@@ -412,7 +413,8 @@ size_t gof_backward_scratch_bytes(int32_t P) { (void)P; return 0; }
 int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes,
                  const void* binning_ws, size_t binning_bytes, const void* image_ws, size_t image_bytes, const float* dL_dout,
                  float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian, void* scratch, size_t scratch_bytes, void* stream_)
+                 float* dL_dsh_rest, float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian, void* scratch, size_t scratch_bytes,
+                 void* stream_)
 {
     (void)scratch; (void)scratch_bytes;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -421,6 +423,8 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     if (a->P == 0) return GOF_OK;
     if (!dL_dout || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_dview2gaussian ||
         (a->M > 0 && a->shs && !dL_dsh) || !radii) { set_error("a gradient / radii pointer is NULL"); return GOF_E_INVALID; }
+    const bool split_sh = a->shs_rest != nullptr;
+    if (split_sh != (dL_dsh_rest != nullptr)) { set_error("dL_dsh_rest must be given exactly when args->shs_rest is"); return GOF_E_INVALID; }
     if (!a->scales || !a->rotations) { set_error("backward needs scales and rotations (backward.cu:621)"); return GOF_E_INVALID; }
     if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
         set_error("workspace too small"); return GOF_E_WORKSPACE; }
@@ -433,7 +437,7 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     // torch::zeros of the binding (rasterize_points.cu:161-170): needed for what blend_backward ACCUMULATES into and for the dead
     // dL_dcov3D; preprocess_bwd writes every element of dL_dmeans3D / dL_dscales / dL_drotations (zeros for culled Gaussians)
     // preprocess_bwd<true> (SH rows tiled through LDS) writes every element of dL_dsh itself: no memset for it
-    const bool k9_tiled = a->shs && dL_dsh && a->M == 16 && ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
+    const bool k9_tiled = split_sh || (a->shs && dL_dsh && a->M == 16 && ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0);
     { GOF_PROFILE("backward_memsets", stream);
       // exactly adjacent buffers (the Python binding carves dL_dview2gaussian | dL_dcov3D | dL_dmeans2D | dL_dcolors from one
       // allocation) are cleared by ONE memset: each launch costs ~5 us of queue time, the bytes themselves 0.01 ms
@@ -459,12 +463,13 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     }
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     GOF_PROFILE("preprocess_bwd", stream);
-    if (k9_tiled)
-        hipLaunchKernelGGL(preprocess_bwd<true>, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
-                           g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales, dL_drotations);
-    else
-        hipLaunchKernelGGL(preprocess_bwd<false>, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, radii, a->shs,
-                           g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dscales, dL_drotations);
+#define GOF_K9_LAUNCH(MODE) hipLaunchKernelGGL(preprocess_bwd<MODE>, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, \
+        radii, a->shs, a->shs_rest, g.clamped, a->scales, a->rotations, cam, dL_dview2gaussian, dL_dcolors, dL_dmeans3D, dL_dsh, dL_dsh_rest,     \
+        dL_dscales, dL_drotations)
+    if (split_sh) GOF_K9_LAUNCH(2);
+    else if (k9_tiled) GOF_K9_LAUNCH(1);
+    else GOF_K9_LAUNCH(0);
+#undef GOF_K9_LAUNCH
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }

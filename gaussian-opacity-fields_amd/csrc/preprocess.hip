@@ -20,13 +20,15 @@ __constant__ float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.315
 __constant__ float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
 
 
-// SH -> RGB (forward.cu:20-71). sh points at this Gaussian's [M][3] block.
-__device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float* __restrict__ shp, uint32_t& clamp_bits)
+// SH -> RGB (forward.cu:20-71).  sh0 points at this Gaussian's coefficient 0, shp at where its coefficient block would start so
+// that coefficient k >= 1 is shp[3k..3k+2] (the same address as sh0 for one [M][3] block; _features_rest's row minus 3 floats
+// when DC and higher bands are separate tensors).
+__device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float* __restrict__ sh0, const float* __restrict__ shp, uint32_t& clamp_bits)
 {
     V3 dir = pos - campos;
     dir = dir / sqrtf(dot3(dir, dir));
     const V3* sh = reinterpret_cast<const V3*>(shp);
-    V3 result = SH_C0 * sh[0];
+    V3 result = SH_C0 * reinterpret_cast<const V3*>(sh0)[0];
     if (deg > 0) {
         const float x = dir.x, y = dir.y, z = dir.z;
         result = result - SH_C1 * y * sh[1] + SH_C1 * z * sh[2] - SH_C1 * x * sh[3];
@@ -203,6 +205,7 @@ __global__ void __launch_bounds__(256)
 preprocess_fwd(int P, int D, int M,
                const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
                const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+               const float* __restrict__ shs_rest,
                const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
                const float* __restrict__ v2g_precomp, Cam cam,
                int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
@@ -298,7 +301,9 @@ preprocess_fwd(int P, int D, int M,
         uint32_t cb = 0;
         if (colors_precomp == nullptr) {
             const V3 campos = { cam.campos[0], cam.campos[1], cam.campos[2] };
-            const V3 rgb = sh_to_rgb(D, p_orig, campos, shs + (size_t)idx * M * 3, cb);
+            const float* sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
+            const float* shp = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
+            const V3 rgb = sh_to_rgb(D, p_orig, campos, sh0, shp, cb);
             r.f[REC_RGB] = rgb.x; r.f[REC_RGB + 1] = rgb.y; r.f[REC_RGB + 2] = rgb.z;
         } else {
             r.f[REC_RGB] = colors_precomp[3 * (size_t)idx]; r.f[REC_RGB + 1] = colors_precomp[3 * (size_t)idx + 1]; r.f[REC_RGB + 2] = colors_precomp[3 * (size_t)idx + 2];
@@ -449,25 +454,54 @@ __device__ __forceinline__ void sh_backward(int deg, V3 pos, V3 campos, const fl
 // thread works on its own LDS row, and culled Gaussians / coefficients above the active degree leave zeros in the tile -- so the
 // host skips the 192 B/Gaussian memset of dL_dsh as well.
 constexpr int K9_ROW = 49;
-template <bool TILED>
+// MODE 0: rows read / written in place; 1: TILED; 2: TILED with DC and higher bands in separate tensors (shs = [P,1,3],
+// shs_rest = [P,15,3] and the same for the gradient): the LDS row is columns 0-2 | 3-47 of the two tiles.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 preprocess_bwd(int P, int D, int M,
                const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
+               const float* __restrict__ shs_rest,
                const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
                Cam cam, const float* __restrict__ dL_dv2g, const float* __restrict__ dL_dcolor,
-               float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drots)
+               float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest, float* __restrict__ dL_dscales,
+               float* __restrict__ dL_drots)
 {
+    constexpr bool TILED = MODE != 0;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     __shared__ float s_sh[TILED ? 256 * K9_ROW : 1];
     const int b0 = blockIdx.x * 256;
     const int rows = min(256, P - b0);
-    if (TILED) {
+    if (MODE == 1) {
         const float4* src = reinterpret_cast<const float4*>(shs + (size_t)b0 * 48);
         for (int i = threadIdx.x; i < rows * 12; i += 256) {
             const float4 v = src[i];
             const int f = i * 4, g = f / 48, k = f - g * 48;
             float* d = &s_sh[g * K9_ROW + k];
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    if (MODE == 2) {
+        const float* dc = shs + (size_t)b0 * 3;
+        for (int i = threadIdx.x; i < rows * 3; i += 256) {
+            const int g = i / 3, k = i - g * 3;
+            s_sh[g * K9_ROW + k] = dc[i];
+        }
+        const float* rest = shs_rest + (size_t)b0 * 45;
+        const int n4 = (reinterpret_cast<uintptr_t>(rest) & 15) ? 0 : (rows * 45) >> 2;       // 16-byte loads when the tensor allows
+        const float4* src = reinterpret_cast<const float4*>(rest);
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = src[i];
+            const float q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int f = i * 4 + e, g = f / 45, k = f - g * 45;
+                s_sh[g * K9_ROW + 3 + k] = q[e];
+            }
+        }
+        for (int f = n4 * 4 + threadIdx.x; f < rows * 45; f += 256) {
+            const int g = f / 45, k = f - g * 45;
+            s_sh[g * K9_ROW + 3 + k] = rest[f];
         }
         __syncthreads();
     }
@@ -572,7 +606,7 @@ preprocess_bwd(int P, int D, int M,
 #pragma unroll
         for (int k = 0; k < 48; k++) my_row[k] = 0.0f;                       // culled Gaussian: zero gradient row
     }
-    if (TILED) {
+    if (MODE == 1) {
         __syncthreads();
         float4* dst = reinterpret_cast<float4*>(dL_dsh + (size_t)b0 * 48);
         for (int i = threadIdx.x; i < rows * 12; i += 256) {
@@ -581,11 +615,35 @@ preprocess_bwd(int P, int D, int M,
             dst[i] = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
+    if (MODE == 2) {
+        __syncthreads();
+        float* dc = dL_dsh + (size_t)b0 * 3;
+        for (int i = threadIdx.x; i < rows * 3; i += 256) {
+            const int g = i / 3, k = i - g * 3;
+            dc[i] = s_sh[g * K9_ROW + k];
+        }
+        float* rest = dL_dsh_rest + (size_t)b0 * 45;
+        const int n4 = (reinterpret_cast<uintptr_t>(rest) & 15) ? 0 : (rows * 45) >> 2;
+        float4* dst = reinterpret_cast<float4*>(rest);
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float q[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int f = i * 4 + e, g = f / 45, k = f - g * 45;
+                q[e] = s_sh[g * K9_ROW + 3 + k];
+            }
+            dst[i] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        for (int f = n4 * 4 + threadIdx.x; f < rows * 45; f += 256) {
+            const int g = f / 45, k = f - g * 45;
+            rest[f] = s_sh[g * K9_ROW + 3 + k];
+        }
+    }
 }
-template __global__ void preprocess_bwd<false>(int, int, int, const float*, const int32_t*, const float*, const uint8_t*, const float*, const float*,
-                                               Cam, const float*, const float*, float*, float*, float*, float*);
-template __global__ void preprocess_bwd<true>(int, int, int, const float*, const int32_t*, const float*, const uint8_t*, const float*, const float*,
-                                              Cam, const float*, const float*, float*, float*, float*, float*);
+#define GOF_K9_INST(MODE) template __global__ void preprocess_bwd<MODE>(int, int, int, const float*, const int32_t*, const float*, const float*, \
+    const uint8_t*, const float*, const float*, Cam, const float*, const float*, float*, float*, float*, float*, float*);
+GOF_K9_INST(0) GOF_K9_INST(1) GOF_K9_INST(2)
+#undef GOF_K9_INST
 
 // ---------------------------------------------------------------------------------------------------
 // K10: query points (forward.cu:722-766)

@@ -91,8 +91,71 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_cov3Ds_precomp, grad_view2gaussian_precomp, None)
 
 
+class SplitSH:
+    """The SH coefficients as the reference STORES them -- ``_features_dc`` (P,1,3) and ``_features_rest`` (P,15,3),
+    scene/gaussian_model.py:351-352 -- handed to ``GaussianRasterizer`` as ``shs=SplitSH(dc, rest)`` instead of their
+    concatenation (``GaussianModel.get_features``, gaussian_model.py:173-176: 192 B per Gaussian copied forward and its gradient
+    split back every iteration, 0.22 ms at 1M Gaussians).  The kernels read / write the two tensors directly
+    (``GofRasterArgs.shs_rest``); results are bit-identical to passing the concatenation.  NEW, not part of the reference API;
+    launch/run_reference_script.py rebinds ``get_features`` to return one.  Any other use of the object (``.shape``,
+    ``.transpose(...)``: gaussian_renderer/__init__.py:84-85 with ``pipe.convert_SHs_python``) sees the concatenated tensor."""
+
+    def __init__(self, features_dc, features_rest):
+        self.dc, self.rest = features_dc, features_rest
+
+    def cat(self):
+        return torch.cat((self.dc, self.rest), dim=1)
+
+    def native(self):
+        return self.dc.dim() == 3 and self.rest.dim() == 3 and self.dc.shape[1:] == (1, 3) and self.rest.shape[1:] == (15, 3)
+
+    def __getattr__(self, name):              # only reached for attributes this class does not define
+        return getattr(self.cat(), name)
+
+
+class _RasterizeGaussiansSplitSH(torch.autograd.Function):
+    """_RasterizeGaussians with the SH input as two tensors (SplitSH); same forward / backward entry points."""
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh_dc, sh_rest, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, raster_settings):
+        rs = raster_settings
+        empty = torch.Tensor([])
+        args = (rs.bg,) + _view_args(rs, means3D, empty, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, (sh_dc, sh_rest))
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _call_with_snapshot(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest,
+                              geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs = ctx.raster_settings
+        (means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        args = (rs.bg, means3D, radii, torch.Tensor([]), scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size,
+                rs.subpixel_offset, grad_out_color, (sh_dc, sh_rest), rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
+                binningBuffer, imgBuffer, rs.debug)
+        (grad_means2D, _gc, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations,
+         grad_view2gaussian_precomp) = _call_with_snapshot(_C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        return (grad_means3D, grad_means2D, grad_sh[0], grad_sh[1], grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, grad_view2gaussian_precomp, None)
+
+
+def _split_or_cat(shs):
+    """SplitSH -> (dc, rest) when the kernels take it as it is (SH degree-3 storage), else its concatenation."""
+    if isinstance(shs, SplitSH):
+        return (shs.dc, shs.rest) if shs.native() else shs.cat()
+    return shs
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         view2gaussian_precomp, raster_settings):
+    if isinstance(sh, tuple):
+        return _RasterizeGaussiansSplitSH.apply(means3D, means2D, sh[0], sh[1], opacities, scales, rotations, cov3Ds_precomp,
+                                                view2gaussian_precomp, raster_settings)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      view2gaussian_precomp, raster_settings)
 
@@ -124,7 +187,7 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, view2gaussian_precomp=None):
         shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp = _normalise_optionals(
-            shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp)
+            _split_or_cat(shs), colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    view2gaussian_precomp, self.raster_settings)
 
@@ -133,7 +196,7 @@ class GaussianRasterizer(nn.Module):
         """Opacity-field query: no autograd (reference :239-305).  Returns
         ``(color, alpha_integrated, color_integrated, radii)``."""
         shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp = _normalise_optionals(
-            shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp)
+            _split_or_cat(shs), colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp)
         rs = self.raster_settings
         args = (rs.bg, points3D) + _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                               view2gaussian_precomp, shs)

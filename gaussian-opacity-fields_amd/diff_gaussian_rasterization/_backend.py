@@ -28,7 +28,7 @@ class GofRasterArgs(C.Structure):
         ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
         ("view2gaussian_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
-        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p),
+        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p), ("shs_rest", C.c_void_p),
     ]
 
 
@@ -51,7 +51,7 @@ def _load():
     lib.gof_forward_render.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_forward_fused.restype = C.c_int
-    lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 9 + [vp, sz, vp]
+    lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 10 + [vp, sz, vp]
     lib.gof_integrate_prepare_points.argtypes = [A, i32, vp, vp, sz, C.POINTER(u32), vp]
     lib.gof_integrate_run.argtypes = [A, u32, vp, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_integrate_view.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
@@ -134,8 +134,20 @@ class _View:
         k["proj"] = _dev_f32(projmatrix, dev, "projmatrix")
         k["campos"] = _dev_f32(campos, dev, "campos")
         k["subpix"] = _dev_f32(subpixel_offset, dev, "subpixel_offset")
-        k["sh"] = _dev_f32(sh, dev, "sh")
-        self.M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0   # rasterize_points.cu:87-91
+        # sh: [P,M,3] as the reference passes it, or the pair (features_dc [P,1,3], features_rest [P,15,3]) as the reference STORES
+        # it (scene/gaussian_model.py:351-352; GofRasterArgs.shs_rest) -- no 192 B/Gaussian concatenation per iteration
+        self.split_sh = isinstance(sh, (tuple, list))
+        if self.split_sh:
+            dc, rest = sh
+            if dc.dim() != 3 or rest.dim() != 3 or tuple(dc.shape) != (self.P, 1, 3) or tuple(rest.shape) != (self.P, 15, 3):
+                raise RuntimeError("separate SH tensors must be (P,1,3) and (P,15,3), got %s and %s" % (tuple(dc.shape), tuple(rest.shape)))
+            k["sh"] = _dev_f32(dc, dev, "sh (DC)")
+            k["sh_rest"] = _dev_f32(rest, dev, "sh (higher bands)")
+            self.M = 16
+        else:
+            k["sh"] = _dev_f32(sh, dev, "sh")
+            k["sh_rest"] = None
+            self.M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0   # rasterize_points.cu:87-91
         a = self.args = GofRasterArgs()
         a.P, a.D, a.M, a.W, a.H = self.P, int(degree), self.M, self.W, self.H
         a.tan_fovx, a.tan_fovy = float(tan_fovx), float(tan_fovy)
@@ -147,6 +159,7 @@ class _View:
         a.cov3D_precomp = _ptr(k["cov3D"]); a.view2gaussian_precomp = _ptr(k["v2g"])
         a.viewmatrix = _ptr(k["view"]); a.projmatrix = _ptr(k["proj"]); a.campos = _ptr(k["campos"])
         a.subpixel_offset = _ptr(k["subpix"])
+        a.shs_rest = _ptr(k["sh_rest"]) if k["sh_rest"] is not None else None
 
     def ref(self):
         return C.byref(self.args)
@@ -242,7 +255,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # are carved from ONE allocation in that order, 16-byte aligned segments: a data-parallel trainer can all-reduce the
     # bucket in place (dp/reducer.py) instead of packing 236 B per Gaussian into a bucket and back -- or only its first four
     # segments when the SH gradient travels in compressed form (sh_grad_pack / sh_grad_expand below).
-    sizes = [3 * P, P, 3 * P, 4 * P, 3 * M * P]
+    sizes = [3 * P, P, 3 * P, 4 * P] + ([3 * P, 45 * P] if v.split_sh else [3 * M * P])
     offs, tot = [], 0
     for n in sizes:
         offs.append(tot)
@@ -250,7 +263,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     bucket = torch.empty(tot, **f)
     g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_opacity = bucket[offs[1]:offs[1] + sizes[1]].view(P, 1)
     g_scales = bucket[offs[2]:offs[2] + sizes[2]].view(P, 3); g_rot = bucket[offs[3]:offs[3] + sizes[3]].view(P, 4)
-    g_sh = bucket[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
+    if v.split_sh:        # gradients in the layout of the inputs: (dL_dfeatures_dc [P,1,3], dL_dfeatures_rest [P,15,3])
+        g_sh = (bucket[offs[4]:offs[4] + sizes[4]].view(P, 1, 3), bucket[offs[5]:offs[5] + sizes[5]].view(P, 15, 3))
+    else:
+        g_sh = bucket[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
     # what the blend ACCUMULATES into (and the dead dL_dcov3D) must be zero-filled: one allocation, no padding, so that the library
     # clears it with a single memset (widest rows first: every segment stays 8-byte aligned)
     acc = torch.empty(22 * P, **f)
@@ -264,7 +280,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             _check(lib.gof_backward(v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),
                                     _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D),
-                                    _ptr(g_sh), _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g),
+                                    _ptr(g_sh[0] if v.split_sh else g_sh), _ptr(g_sh[1]) if v.split_sh else None,
+                                    _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g),
                                     _ptr(scratch), nscratch, _stream()))
         if _sh_track["on"] and M > 0:
             _sh_track["count"] += 1

@@ -67,6 +67,13 @@ def rebind_train_epilogue():
     GaussianModel.get_scaling_with_3D_filter = property(T.activations.get_scaling_with_3D_filter)
     GaussianModel.get_opacity_with_3D_filter = property(T.activations.get_opacity_with_3D_filter)
     GaussianModel.get_rotation = property(T.activations.get_rotation)
+    # get_features (gaussian_model.py:173-176) concatenates _features_dc and _features_rest -- 192 B per Gaussian copied, and the
+    # gradient split back, every iteration.  render() / integrate() hand the result straight to the rasterizer
+    # (gaussian_renderer/__init__.py:94,194), which reads the two stored tensors directly when given a SplitSH; any other use of
+    # the object (pipe.convert_SHs_python, :84-85) sees the concatenation.  GOF_CAT_FEATURES=1 keeps the reference's property.
+    if os.environ.get("GOF_CAT_FEATURES") != "1":
+        from diff_gaussian_rasterization import SplitSH
+        GaussianModel.get_features = property(lambda self: SplitSH(self._features_dc, self._features_rest))
 
 
 def rebind_integrate_with_view_cache():

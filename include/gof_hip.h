@@ -70,6 +70,10 @@ typedef struct GofRasterArgs {
     const float* projmatrix;            /* [16] full projection, same convention */
     const float* campos;                /* [3]                                   */
     const float* subpixel_offset;       /* [H,W,2]; must be valid (integrateCUDA reads it, forward.cu:845) */
+    const float* shs_rest;              /* NULL (default): `shs` is [P,M,3].  Non-NULL: the SH coefficients as the reference STORES
+                                           them (scene/gaussian_model.py:351-352) -- `shs` = _features_dc [P,1,3], `shs_rest` =
+                                           _features_rest [P,M-1,3] -- so that the caller need not concatenate 192 B per Gaussian
+                                           (GaussianModel.get_features, gaussian_model.py:173-176) every iteration.  M == 16 only. */
 } GofRasterArgs;
 
 /* ---- error text ----------------------------------------------------------------------- */
@@ -144,7 +148,8 @@ int gof_backward(const GofRasterArgs* args,
                  float* dL_dopacity,        /* [P]    */
                  float* dL_dmeans3D,        /* [P,3]  */
                  float* dL_dcov3D,          /* [P,6] or NULL */
-                 float* dL_dsh,             /* [P,M,3] or NULL when M == 0 */
+                 float* dL_dsh,             /* [P,M,3] or NULL when M == 0; [P,1,3] when args->shs_rest is given */
+                 float* dL_dsh_rest,        /* [P,M-1,3] when args->shs_rest is given, else NULL */
                  float* dL_dscales,         /* [P,3]  */
                  float* dL_drotations,      /* [P,4]  */
                  float* dL_dview2gaussian,  /* [P,10] */

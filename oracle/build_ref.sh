@@ -13,7 +13,7 @@ REF=/root/reference/submodules/diff-gaussian-rasterization
 OUT="$HERE/_ref"
 [ -d "$REF" ] || { echo "build_ref.sh: $REF not present, skipping"; exit 0; }
 mkdir -p "$OUT"
-if [ -f "$OUT/libgof_cudaref.so" ] && [ -f "$OUT/libgof_cudaref_nofma.so" ] && [ -f "$OUT/libgof_knnref_nofma.so" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/ref_capi.cpp" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/build_ref.sh" ] && [ "$OUT/libgof_knnref.so" -nt "$HERE/ref_knn_capi.cpp" ]; then
+if [ -f "$OUT/libgof_cudaref.so" ] && [ -f "$OUT/libgof_cudaref_nofma.so" ] && [ -f "$OUT/libgof_knnref_nofma.so" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/ref_capi.cpp" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/../include/gof_hip.h" ] && [ "$OUT/libgof_cudaref.so" -nt "$HERE/build_ref.sh" ] && [ "$OUT/libgof_knnref.so" -nt "$HERE/ref_knn_capi.cpp" ]; then
   echo "oracle/_ref up to date"; exit 0
 fi
 TMP="$(mktemp -d "$OUT/tmp.XXXXXX")"

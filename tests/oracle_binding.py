@@ -22,7 +22,7 @@ class GofRasterArgs(C.Structure):
         ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
         ("view2gaussian_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
-        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p),
+        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p), ("shs_rest", C.c_void_p),   # shs_rest: product only, NULL here
     ]
 
 

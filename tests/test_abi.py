@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported():
 def test_size_queries_are_host_only_and_monotone():
     from diff_gaussian_rasterization import _backend as B
     L = B.lib
-    assert L.gof_abi_version() >= 1
+    assert L.gof_abi_version() >= 2
     assert L.gof_geom_bytes(0) > 0
     assert L.gof_geom_bytes(1000) < L.gof_geom_bytes(100000)
     assert L.gof_geom_bytes(1_000_000) >= 1_000_000 * (64 + 16 + 4 + 4 + 4 + 1)
@@ -61,7 +61,7 @@ def test_struct_layout_matches_header():
         fields.extend(n.strip() for n in names[1:])
     assert [f[0] for f in B.GofRasterArgs._fields_] == fields
     assert [f[0] for f in ob.GofRasterArgs._fields_] == fields
-    assert ctypes.sizeof(B.GofRasterArgs) == ctypes.sizeof(ob.GofRasterArgs) == 11 * 4 + 4 + 13 * 8
+    assert ctypes.sizeof(B.GofRasterArgs) == ctypes.sizeof(ob.GofRasterArgs) == 11 * 4 + 4 + 14 * 8
 
 
 def test_train_epilogue_struct_and_host_queries():

@@ -40,7 +40,7 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
     import utils.loss_utils as ref_loss
     import utils.depth_utils as ref_depth
     from scene.gaussian_model import GaussianModel
-    props = {p_: getattr(GaussianModel, p_) for p_ in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation")}
+    props = {p_: getattr(GaussianModel, p_) for p_ in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation", "get_features")}
     assert all(isinstance(v, property) for v in props.values())          # they are properties in the reference too
     orig = {"ssim": ref_loss.ssim, "d2n": ref_depth.depth_to_normal, "d2p": ref_depth.depths_to_points,
             "setup": GaussianModel.training_setup, "f3d": GaussianModel.compute_3D_filter, "stats": GaussianModel.add_densification_stats}
@@ -53,6 +53,16 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
         assert GaussianModel.training_setup is not orig["setup"]
         for prop in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation"):
             assert isinstance(getattr(GaussianModel, prop), property) and getattr(GaussianModel, prop).fget is getattr(T.activations, prop)
+        # get_features: the two stored tensors as they are; every other use of the object sees the reference's concatenation
+        import torch
+        import types
+        from diff_gaussian_rasterization import SplitSH
+        fake = types.SimpleNamespace(_features_dc=torch.randn(5, 1, 3), _features_rest=torch.randn(5, 15, 3))
+        got = GaussianModel.get_features.fget(fake)
+        want = props["get_features"].fget(fake)
+        assert isinstance(got, SplitSH) and got.native() and got.dc is fake._features_dc and got.rest is fake._features_rest
+        assert got.shape == want.shape and torch.equal(got.transpose(1, 2).view(-1, 3, 16), want.transpose(1, 2).view(-1, 3, 16))   # gaussian_renderer/__init__.py:84
+        assert not SplitSH(torch.randn(5, 1, 3), torch.randn(5, 8, 3)).native()       # fewer stored bands: the rasterizer concatenates
         # same call signatures as the functions they replace
         for new, old in ((T.ssim, orig["ssim"]), (T.depth_to_normal, orig["d2n"]), (T.depths_to_points, orig["d2p"]),
                          (T.compute_3D_filter, orig["f3d"]), (T.add_densification_stats, orig["stats"])):

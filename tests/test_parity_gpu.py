@@ -448,6 +448,73 @@ def test_sh_gradient_compressed_exchange_equals_the_sum_of_the_dense_gradients(d
         B.track_sh_grad_source(False)
 
 
+@pytest.mark.parametrize("P,degree", [(6000, 3), (257, 1), (1, 0)])
+def test_split_sh_tensors_are_bit_identical_to_their_concatenation(P, degree):
+    """GofRasterArgs.shs_rest / SplitSH: the SH coefficients passed as the reference stores them (_features_dc [P,1,3] and
+    _features_rest [P,15,3], scene/gaussian_model.py:351-352) instead of GaussianModel.get_features' concatenation.  Forward image,
+    radii and every gradient are bit-identical; the SH gradient arrives in the layout of the inputs.  Also the opacity-field
+    query, the tail block of preprocess_bwd (P not a multiple of 256) and lower active degrees (zero rows above them)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, SplitSH
+    sc = S.scene_frustum(P, W=160, H=120, focal=130.0, seed=11, sh_degree=degree)       # anisotropic Gaussians, ~12 % culled
+    sd = to_dev(sc)
+    dL = None
+    out = {}
+    for mode in ("cat", "split"):
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+        dc = sd["shs"][:, :1].clone().requires_grad_(True)
+        rest = sd["shs"][:, 1:].clone().requires_grad_(True)
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        shs = torch.cat((dc, rest), dim=1) if mode == "cat" else SplitSH(dc, rest)
+        color, radii = GaussianRasterizer(settings_from(sd))(means3D=leaves["means3D"], means2D=means2D, shs=shs, opacities=leaves["opacities"],
+                                                             scales=leaves["scales"], rotations=leaves["rotations"])
+        if dL is None:
+            dL = torch.randn(color.shape, generator=torch.Generator().manual_seed(5)).to(color.device)
+        color.backward(dL)
+        out[mode] = dict(color=color.detach(), radii=radii, dc=dc.grad, rest=rest.grad, **{k: v.grad for k, v in leaves.items()})
+    assert torch.equal(out["cat"]["color"], out["split"]["color"]) and torch.equal(out["cat"]["radii"], out["split"]["radii"])
+    # the SH gradient has no atomics behind it (one thread per Gaussian from dL_dcolor): compare through the colour gradient's
+    # run-to-run noise -- dL_dcolor itself is accumulated atomically by the blend, so the two RUNS differ in the last bits;
+    # the kernel-level bit-equality is asserted below on one and the same backward
+    for k in ("dc", "rest", "means3D", "opacities", "scales", "rotations"):
+        a, b = out["cat"][k], out["split"][k]
+        assert a.shape == b.shape and b.is_contiguous()
+        # preprocess_bwd's geometric outputs amplify the blend's atomic-order noise (test_backward_is_deterministic_enough: 2e-2)
+        tol = 2e-2 if k in ("means3D", "scales", "rotations") else 2e-5
+        torch.testing.assert_close(b, a, rtol=0, atol=tol * max(a.abs().max().item(), 1e-30))
+    if degree < 3:
+        assert (out["split"]["rest"][:, (degree + 1) ** 2 - 1:] == 0).all()
+    # one and the same backward state through both layouts of preprocess_bwd: raw entry point, twice, bit for bit
+    from diff_gaussian_rasterization import _backend as B
+    res = product_forward_raw(sd)
+    res_s = product_forward_raw({**sd, "shs": (sd["shs"][:, :1].contiguous(), sd["shs"][:, 1:].contiguous())})
+    assert torch.equal(res["color"], res_s["color"]) and res["R"] == res_s["R"]
+    a = res["args"]; b = res_s["args"]
+
+    def bw(args, r):
+        (bg, means3D, colors, opac, scales, rot, smod, cov, v2g, vm, pm, tfx, tfy, ks, sub, H, W, sh, deg, campos, pre, dbg) = args
+        return B.rasterize_gaussians_backward(bg, means3D, r["radii"], colors, scales, rot, smod, cov, v2g, vm, pm, tfx, tfy, ks, sub, dL,
+                                              sh, deg, campos, r["geom"], r["R"], r["binning"], r["img"], False)
+    g_cat = bw(a, res)
+    g_split = bw(b, res_s)
+    gsh_cat, gsh_split = g_cat[5], g_split[5]
+    assert isinstance(gsh_split, tuple) and gsh_split[0].shape == (P, 1, 3) and gsh_split[1].shape == (P, 15, 3)
+    # dL_dcolors (index 1) is the atomically accumulated input of the SH backward: where the two runs agree on it bit for bit, so must the SH rows
+    same = (g_cat[1] == g_split[1]).all(dim=1)
+    assert same.any() or P == 1
+    assert torch.equal(torch.cat(gsh_split, dim=1)[same], gsh_cat[same])
+    torch.testing.assert_close(torch.cat(gsh_split, dim=1), gsh_cat, rtol=0, atol=1e-4 * max(gsh_cat.abs().max().item(), 1e-30))
+    # opacity-field query
+    pts = torch.from_numpy(S.tetra_points(sc)[:4000].astype(np.float32)).to(sd["means3D"].device)
+    r = GaussianRasterizer(settings_from(sd))
+    q_cat = r.integrate(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    q_split = r.integrate(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"],
+                          shs=SplitSH(sd["shs"][:, :1].contiguous(), sd["shs"][:, 1:].contiguous()), scales=sd["scales"], rotations=sd["rotations"])
+    assert all(torch.equal(x, y) for x, y in zip(q_cat, q_split))
+    # any other use of a SplitSH sees the concatenation (gaussian_renderer/__init__.py:84-85)
+    sp = SplitSH(sd["shs"][:, :1], sd["shs"][:, 1:])
+    assert sp.shape == sd["shs"].shape and torch.equal(sp.transpose(1, 2), sd["shs"].transpose(1, 2))
+
+
 def test_integrate_with_no_visible_gaussian_and_with_no_point_in_view():
     """Degenerate inputs of the opacity-field query: every Gaussian culled (behind the camera) -> points inside the image get
     alpha 0 and the background colour, points outside keep the initial 1; and a point set entirely outside the image."""
