@@ -71,12 +71,10 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     }
     // the wave's output range [first, first + total): offsets are an exclusive scan in this order, so they are contiguous
     const uint32_t first = __shfl(off, 0);
-    const uint32_t last_off = __shfl(off, 63), last_cnt = __shfl(cnt, 63);
     // lanes past P (last wave only) carry off = 0: give them the end of the range so the search never selects them
     const int valid_lanes = min(64, P - (i - lane));
     const uint32_t end = __shfl(off, valid_lanes - 1) + __shfl(cnt, valid_lanes - 1);
     if (i >= P) off = end;
-    (void)last_off; (void)last_cnt;
     for (uint32_t p = first + lane; __ballot(p < end) != 0ull; p += 64) {
         int lo = 0, hi = 63;
 #pragma unroll

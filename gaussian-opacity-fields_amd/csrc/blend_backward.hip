@@ -93,10 +93,6 @@ __device__ __forceinline__ void row_sum16_transposed(const float* g, bool b0, bo
     }
 }
 
-#ifndef GOF_BW_BUTTERFLY
-#define GOF_BW_BUTTERFLY 1
-#endif
-
 __global__ void __launch_bounds__(256)
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
@@ -320,7 +316,6 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                 // rows (16 lanes = 8x2 pixels) in which no pixel contributed hold exact zeros: skip their LDS adds
                 const uint64_t cmask64 = __ballot(contrib);
                 const bool row_hit = ((cmask64 >> (lane & 48u)) & 0xFFFFull) != 0ull;
-#if GOF_BW_BUTTERFLY
                 float w4[4];
                 row_sum16_transposed(g, (lane & 1u) != 0u, (lane & 2u) != 0u, w4);
                 const float g16 = row_sum(g[16]);
@@ -333,15 +328,6 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     unsafeAtomicAdd(&s_acc[16][j], g16);
                     s_touched[j] = 1u;
                 }
-#else
-#pragma unroll
-                for (int k = 0; k < NGRAD; k++) g[k] = row_sum(g[k]);
-                if ((lane & 15u) == 15u && row_hit) {
-#pragma unroll
-                    for (int k = 0; k < NGRAD; k++) unsafeAtomicAdd(&s_acc[k][j], g[k]);
-                    s_touched[j] = 1u;
-                }
-#endif
             }
         }
         __syncthreads();

@@ -112,28 +112,17 @@ struct ProfileScope {
 // thread -> pixel map inside a 16x16 tile.  Each wave64 covers an 8x8 pixel quadrant (lane l -> x = l % 8,
 // y = l / 8): a compact footprint intersects fewer splats than the reference's 16x4 strip, and a 16-lane DPP
 // row is an 8x2 pixel block.  Per-pixel results do not depend on the map.
-#ifndef GOF_WAVE_8X8
-#define GOF_WAVE_8X8 1
-#endif
 __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t& lx, uint32_t& ly)
 {
-#if GOF_WAVE_8X8
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     lx = (lane & 7u) + 8u * (wave & 1u);
     ly = (lane >> 3) + 8u * (wave >> 1);
-#else
-    lx = tid % TILE_X; ly = tid / TILE_X;
-#endif
 }
 
 // inverse of tile_pixel: thread id of the pixel (lx, ly) of a tile
 __device__ __forceinline__ uint32_t tile_thread(uint32_t lx, uint32_t ly)
 {
-#if GOF_WAVE_8X8
     return (((lx >> 3) + 2u * (ly >> 3)) << 6) + ((ly & 7u) << 3) + (lx & 7u);
-#else
-    return ly * TILE_X + lx;
-#endif
 }
 
 // Contributor masks: for every pixel of a tile one bit per tile-list position, set by blend_forward when that

@@ -295,21 +295,13 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             else { T = pt_T[pi]; acc = pt_acc[pi]; }
             const float rx = (float)(((double)xy.x - W / 2.) / (double)focal_x);
             const float ry = (float)(((double)xy.y - H / 2.) / (double)focal_y);
-            // one flat loop over the set bits of the pixel's 8 mask words: lanes advance through their own words independently,
-            // so a wave iterates max-over-lanes(total bits), not sum-over-words(max-over-lanes(bits of the word))
-#ifndef GOF_POINT_LOOP_FLAT
-#define GOF_POINT_LOOP_FLAT 0     // measured: word-synchronous 12.3 ms vs flat 12.8 ms (S5M, 45M points)
-#endif
+            // the set bits of the pixel's 8 mask words, the wave moving from word to word together (a flat per-lane loop over all
+            // words, lanes advancing independently, measured slower: 12.8 vs 12.3 ms at S5M with 45M points)
             int w = 0;
             uint32_t mask = s_used[0][lp];
             while (true) {
-#if GOF_POINT_LOOP_FLAT
-                while (mask == 0u && w < 7) { w++; mask = s_used[w][lp]; }
-                if (mask == 0u) break;
-#else
                 if (__ballot(mask != 0u) == 0ull) { if (++w >= 8) break; mask = s_used[w][lp]; continue; }
                 if (mask == 0u) continue;
-#endif
                 const int bit = __ffs((int)mask) - 1;
                 mask &= mask - 1;
                 const int j = w * 32 + bit;

@@ -433,7 +433,6 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
         const uint32_t nunits = rs_units(n);
         const size_t hwords = (size_t)RS_DIGITS * nunits;
         const dim3 grid(nunits), block(256);
-#ifndef GOF_RS_CLASSIC
         // measured on MI355X: 1M pairs x 4 passes 0.142 -> 0.107 ms, but 8.8M pairs x 2 passes 0.178 -> 0.199 ms (with ~1000 resident
         // blocks the look-back chains get long): the single-kernel passes are used where launch latency dominates
         if (nunits <= OS_MAX_UNITS && npass <= OS_MAX_PASSES) {
@@ -456,7 +455,6 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
             *vals_res = vi;
             return hipGetLastError();
         }
-#endif
         uint32_t* hist = tmp;
         uint32_t* scan_tmp = tmp + hwords;
         for (int shift = 0; shift < end_bit; shift += 8) {
