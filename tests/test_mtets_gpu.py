@@ -60,3 +60,32 @@ def test_matches_oracle_on_grids_and_degenerate_fields(n):
     z = sdf.copy(); z[::3] = 0.0
     got = run(verts, tets, z, scales); want = ob.marching_tets(verts, tets, z, scales)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[4], want[4])
+
+
+def test_more_than_32Mi_tets_face_order_follows_the_references_chunking():
+    """utils/tetmesh.py:55-95 processes more than 32 Mi tets in torch.chunk pieces, which fixes the ORDER of the faces (chunk by
+    chunk, inside a chunk the 1-triangle tets first).  47M tets = 2 chunks whose boundary is not a multiple of the kernels' 4096-tet
+    blocks; bit-exact against the oracle (which restates the chunk loop) -- edges, positions and every face."""
+    n = (200, 199, 201)
+    # 6 tets per cell of an n0 x n1 x n2 vertex grid, built on the GPU (the numpy helper takes 25 s at this size)
+    ax = [torch.arange(k, device="cuda", dtype=torch.float32) for k in n]
+    X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+    verts = torch.stack([X, Y, Z], -1).reshape(-1, 3).cpu().numpy()
+    idx = torch.arange(n[0] * n[1] * n[2], device="cuda").reshape(n)
+    c = [idx[i:n[0] - 1 + i, j:n[1] - 1 + j, k:n[2] - 1 + k].reshape(-1) for i in (0, 1) for j in (0, 1) for k in (0, 1)]
+    v000, v001, v010, v011, v100, v101, v110, v111 = c
+    tets = torch.stack([torch.stack(t, 1) for t in ((v000, v100, v110, v111), (v000, v100, v101, v111), (v000, v010, v110, v111),
+                                                     (v000, v010, v011, v111), (v000, v001, v101, v111), (v000, v001, v011, v111))], 1)
+    tets = tets.reshape(-1, 4).cpu().numpy()
+    del X, Y, Z, idx, c
+    torch.cuda.empty_cache()
+    assert len(tets) > 32 * 1024 * 1024
+    rng = np.random.default_rng(11)
+    centre = np.array(n, np.float32) / 2
+    sdf = (0.37 * min(n) - np.linalg.norm(verts - centre, axis=1) + rng.normal(0, 0.2, len(verts)).astype(np.float32)).astype(np.float32)
+    scales = rng.uniform(0.1, 1, len(verts)).astype(np.float32)
+    got = run(verts, tets, sdf, scales)
+    want = ob.marching_tets(verts, tets, sdf, scales)
+    assert len(want[4]) > 100_000
+    for a, b in zip(got, [want[0], want[1], want[2][..., None], want[3][..., None], want[4]]):
+        assert np.array_equal(a, b)
