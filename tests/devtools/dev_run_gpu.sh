@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-( time timeout 900 python -m pytest tests/test_mtets_gpu.py -m gpu -q -x --tb=short 2>&1 | cut -c1-300 | tail -6 ) 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_train_epilogue_gpu.py -m gpu -q -x -k "end_to_end" --tb=short 2>&1 | cut -c1-400 | tail -8

@@ -575,15 +575,22 @@ def test_fused_adam_unaligned_and_tail_elements():
         assert (p.detach() - q.detach()).abs().max().item() <= 1e-5 * 1e-2 + 1e-6 * q.detach().abs().max().item()
 
 
-def test_end_to_end_training_iterations_reduce_the_loss():
-    """The whole stack in the reference's training-iteration shape (train.py:125-190, 263-265): HIP activations -> rasterizer ->
+_E2E_LOSSES = {}
+
+
+@pytest.mark.parametrize("variant", ["unchanged-train.py", "one-call-loss+split-sh"])
+def test_end_to_end_training_iterations_reduce_the_loss(variant):
+    """(variant 2: the same iteration with train_epilogue.training_loss and the SH coefficients passed as stored, SplitSH -- the loss
+    curves of the two variants must agree closely: same mathematics, other kernels.)
+    The whole stack in the reference's training-iteration shape (train.py:125-190, 263-265): HIP activations -> rasterizer ->
     L1 + D-SSIM + depth-normal + distortion loss (HIP ssim / depth_to_normal) -> backward -> FusedAdam.  Fit a perturbed copy of a
     small scene to the image of the original: the loss must fall steadily (a sign / layout error anywhere in the chain shows here)."""
     import math
     import train_epilogue as T
     import synthetic_scenes as S
     from gpu_common import to_dev, settings_from
-    from diff_gaussian_rasterization import GaussianRasterizer
+    from diff_gaussian_rasterization import GaussianRasterizer, SplitSH
+    fused = variant != "unchanged-train.py"
     sd = to_dev(S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=31, sigma_px=4.0))
     W, H = sd["W"], sd["H"]
     rast = GaussianRasterizer(settings_from(sd))
@@ -605,9 +612,17 @@ def test_end_to_end_training_iterations_reduce_the_loss():
     losses = []
     for it in range(80):
         means2D = torch.zeros_like(params["xyz"], requires_grad=True)
-        rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=torch.cat((params["f_dc"], params["f_rest"]), dim=1),
+        shs = SplitSH(params["f_dc"], params["f_rest"]) if fused else torch.cat((params["f_dc"], params["f_rest"]), dim=1)
+        rendering, radii = rast(means3D=params["xyz"], means2D=means2D, shs=shs,
                                 opacities=A.opacity_with_3D_filter(params["opacity"], params["scaling"], filter_3D),
                                 scales=A.scaling_with_3D_filter(params["scaling"], filter_3D), rotations=A.rotation(params["rotation"]))
+        if fused:
+            loss = T.training_loss(rendering, gt, view, 0.2, 0.05, 10.0).loss
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.item())
+            continue
         image = rendering[:3]
         rgb_loss = 0.8 * T.l1_loss(image, gt) + 0.2 * (1.0 - T.ssim(image, gt))
         depth_normal = T.depth_to_normal(view, rendering[6][None])[0].permute(2, 0, 1)
@@ -622,5 +637,9 @@ def test_end_to_end_training_iterations_reduce_the_loss():
     assert all(math.isfinite(l_) for l_ in losses)
     first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
     assert last < 0.7 * first, (first, last)
+    _E2E_LOSSES[variant] = losses
+    if len(_E2E_LOSSES) == 2:           # both variants ran in this session: same curve up to rounding amplified over 80 Adam steps
+        a, b = (np.array(_E2E_LOSSES[k]) for k in ("unchanged-train.py", "one-call-loss+split-sh"))
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and np.abs(a - b).max() <= 0.02 * a[0], (a[:3], b[:3], np.abs(a - b).max())
     # the screen-space gradient carrier received the densification signal: x, y signed, z = sum of absolute values (>= 0)
     assert means2D.grad is not None and (radii > 0).any() and (means2D.grad[:, 2] >= 0).all() and means2D.grad[:, 2].max() > 0
