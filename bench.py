@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark of BASELINE.json: train iters/s (forward + backward of the
 rasterizer, one view per step) on the synthetic S1M scene (1M Gaussians, 1600x1063, SH degree 3),
-N GPUs data-parallel over views with an RCCL all-reduce of the Gaussian parameter gradients.
+N GPUs data-parallel over views with an RCCL exchange of the Gaussian parameter gradients per step (the SH gradient as an
+all-gather of 12 B per Gaussian and view expanded locally, the other 44 B all-reduced; dp/reducer.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     -- achieved vs peak HBM bandwidth of the dominant kernel, timed with HIP events

@@ -61,27 +61,33 @@ class GradientAllReducer:
             self._sh_ops = _HipOps
         return self._sh_ops
 
-    def _exchange_sh_compressed(self, world):
-        """All-gather the packed colour gradients (+ camera centres) and expand the sum over views into the SH gradients.
-        Returns False (nothing done) when the compressed form is not applicable this step."""
+    def _sh_begin(self, world):
+        """Pack this view's colour gradient (+ camera centre) and START the all-gather.  Returns (src, gathered, work, grads), or
+        None when the compressed form is not applicable this step."""
         src = self._ops().take()
         grads = [p.grad for p in self.sh_params]
         if src is None or any(g is None for g in grads):
-            return False
+            return None
         P, M = src["P"], src["M"]
         if sum(g.numel() for g in grads) != 3 * M * P or not all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
-            return False
+            return None
         dev = grads[0].device
         mine = torch.empty((P + 1, 3), dtype=torch.float32, device=dev)
         self._ops().pack(src, mine)
         mine[P].copy_(src["campos"].reshape(3))
         gathered = torch.empty((world, P + 1, 3), dtype=torch.float32, device=dev)
         if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            work = dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
         else:                                        # gloo (CPU tests, single-GPU development runs)
-            dist.all_gather(list(gathered.unbind(0)), mine, group=self.group)
+            work = dist.all_gather(list(gathered.unbind(0)), mine, group=self.group, async_op=True)
+        return src, gathered, work, grads
+
+    def _sh_finish(self, pending, world):
+        """Wait for the all-gather only and expand the sum over views into the SH gradients (the all-reduce of the other
+        gradients, issued behind the all-gather, keeps running on the communication stream meanwhile)."""
+        src, gathered, work, grads = pending
+        work.wait()
         self._ops().expand(src, gathered, 1.0 / world if self.average else 1.0, grads)
-        return True
 
     def _ensure(self, n, device, dtype):
         if self._flat is None or self._flat.numel() != n or self._flat.device != device:
@@ -113,37 +119,55 @@ class GradientAllReducer:
             if self.sh_params:
                 self._ops().take()                   # nothing to exchange: forget the tracked backward
             return
+        world = dist.get_world_size(self.group)
         self.last_exchange = "dense"
-        if self.sh_params and self._exchange_sh_compressed(dist.get_world_size(self.group)):
+        pending = self._sh_begin(world) if self.sh_params else None
+        if pending is not None:
             self.last_exchange = "compressed-sh"
             sh_ids = {id(p) for p in self.sh_params}
             ps = [p for p in ps if id(p) not in sh_ids]
-            if not ps:
-                return
+        finish_dense = self._dense_begin(ps, world) if ps else None
+        if pending is not None:
+            self._sh_finish(pending, world)
+        if finish_dense is not None:
+            finish_dense()
+
+    def _dense_begin(self, ps, world):
+        """Start the all-reduce of the gradients of `ps`; returns the callable that completes it."""
         bucket = self._shared_bucket([p.grad for p in ps])
         if bucket is not None and self.wire_dtype is not None:
             if self._wire is None or self._wire.numel() != bucket.numel() or self._wire.device != bucket.device:
                 self._wire = torch.empty(bucket.numel(), dtype=self.wire_dtype, device=bucket.device)
             self._wire.copy_(bucket)
-            dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=self.group)
-            bucket.copy_(self._wire)
-            if self.average:
-                bucket.div_(dist.get_world_size(self.group))
-            return
+            work = dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+            def finish():
+                work.wait()
+                bucket.copy_(self._wire)
+                if self.average:
+                    bucket.div_(world)
+            return finish
         if bucket is not None:                       # the rasterizer's backward carved them from one allocation: reduce in place
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
-                bucket.div_(dist.get_world_size(self.group))
-            return
+            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+            def finish():
+                work.wait()
+                if self.average:
+                    bucket.div_(world)
+            return finish
         grads = [p.grad.reshape(-1) for p in ps]
         n = sum(g.numel() for g in grads)
         flat = self._ensure(n, grads[0].device, grads[0].dtype)
         views = list(torch.split(flat, [g.numel() for g in grads]))
         torch._foreach_copy_(views, grads)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        if self.average:
-            flat.div_(dist.get_world_size(self.group))
-        torch._foreach_copy_(grads, views)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        def finish():
+            work.wait()
+            if self.average:
+                flat.div_(world)
+            torch._foreach_copy_(grads, views)
+        return finish
 
 
 def all_reduce_densification_stats(xyz_gradient_accum, xyz_gradient_accum_abs, denom, max_radii2D, xyz_gradient_accum_abs_max=None,
