@@ -167,6 +167,54 @@ ssim_bwd_kernel(int W, int H, const float* __restrict__ img1, const float* __res
     }
 }
 
+
+// ---- l1_loss (utils/loss_utils.py:17-18): mean |a - b| and its gradient ---------------------------------------------------
+constexpr int L1_BLOCK_ELEMS = 8192;       // 256 threads x 8 float4
+__global__ void __launch_bounds__(256)
+l1_fwd_kernel(uint64_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial)
+{
+    __shared__ float s_red[4];
+    const uint64_t start = (uint64_t)blockIdx.x * L1_BLOCK_ELEMS;
+    float acc = 0.0f;
+    const bool vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0 && start + L1_BLOCK_ELEMS <= n;
+    if (vec) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const uint64_t i = start + (uint64_t)(it * 256 + threadIdx.x) * 4;
+            const float4 x = *reinterpret_cast<const float4*>(a + i), y = *reinterpret_cast<const float4*>(b + i);
+            acc += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+        }
+    } else {
+        for (uint64_t i = start + threadIdx.x; i < start + L1_BLOCK_ELEMS && i < n; i += 256) acc += fabsf(a[i] - b[i]);
+    }
+    const float tot = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// one block: fixed-order sum of the partials, times 1/n
+__global__ void __launch_bounds__(256)
+l1_final_kernel(const float* __restrict__ partial, int nb, float inv_n, float* __restrict__ out)
+{
+    __shared__ float s_red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) v += partial[i];
+    const float tot = block_sum_256(v, s_red);
+    if (threadIdx.x == 0) out[0] = tot * inv_n;
+}
+
+// d mean|a - b| / da = sign(a - b) / n, scaled by the incoming gradient (a device scalar)
+__global__ void __launch_bounds__(256)
+l1_bwd_kernel(uint64_t n, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g_out, float inv_n,
+              float* __restrict__ dL_da)
+{
+    const float g = g_out[0] * inv_n;
+    const uint64_t start = (uint64_t)blockIdx.x * L1_BLOCK_ELEMS;
+    for (uint64_t i = start + threadIdx.x; i < start + L1_BLOCK_ELEMS && i < n; i += 256) {
+        const float d = a[i] - b[i];
+        dL_da[i] = g * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : d));          // torch.sign: 0 at 0
+    }
+}
+
 // ---- depth -> points -> normals ----------------------------------------------------------------------
 struct DepthCam { float r[9]; float o[3]; };   // c2w rotation (row-major) and origin
 
@@ -481,6 +529,35 @@ int gof_ssim_backward(int32_t planes, int32_t W, int32_t H, const float* img1, c
     const dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, planes);
     { GOF_PROFILE("ssim_backward", stream);
       hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, stream, W, H, img1, img2, win, dmaps, plane_scale, dL_dimg1, planes, 0.0f, 0.0f);
+      GOF_LAUNCH_CHECK(stream, 0); }
+    return GOF_OK;
+}
+
+size_t gof_l1_scratch_bytes(uint64_t n) { return (((n + L1_BLOCK_ELEMS - 1) / L1_BLOCK_ELEMS) * sizeof(float) + 255) & ~(size_t)255; }
+
+int gof_l1_forward(uint64_t n, const float* a, const float* b, float* out_mean, void* scratch, size_t scratch_bytes, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0 || !a || !b || !out_mean || !scratch) { set_error("l1: empty input or NULL pointer"); return GOF_E_INVALID; }
+    if (scratch_bytes < gof_l1_scratch_bytes(n)) { set_error("l1 scratch too small"); return GOF_E_WORKSPACE; }
+    const uint64_t nb = (n + L1_BLOCK_ELEMS - 1) / L1_BLOCK_ELEMS;
+    if (nb > 0x7fffffffull) { set_error("l1: too many elements"); return GOF_E_INVALID; }
+    float* partial = static_cast<float*>(scratch);
+    { GOF_PROFILE("l1_forward", stream);
+      hipLaunchKernelGGL(l1_fwd_kernel, dim3((uint32_t)nb), dim3(256), 0, stream, n, a, b, partial);
+      GOF_LAUNCH_CHECK(stream, 0);
+      hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, stream, partial, (int)nb, (float)(1.0 / (double)n), out_mean);
+      GOF_LAUNCH_CHECK(stream, 0); }
+    return GOF_OK;
+}
+
+int gof_l1_backward(uint64_t n, const float* a, const float* b, const float* grad_out, float* dL_da, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0 || !a || !b || !grad_out || !dL_da) { set_error("l1: empty input or NULL pointer"); return GOF_E_INVALID; }
+    const uint64_t nb = (n + L1_BLOCK_ELEMS - 1) / L1_BLOCK_ELEMS;
+    { GOF_PROFILE("l1_backward", stream);
+      hipLaunchKernelGGL(l1_bwd_kernel, dim3((uint32_t)nb), dim3(256), 0, stream, n, a, b, grad_out, (float)(1.0 / (double)n), dL_da);
       GOF_LAUNCH_CHECK(stream, 0); }
     return GOF_OK;
 }

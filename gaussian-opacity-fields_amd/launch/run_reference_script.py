@@ -37,6 +37,7 @@ def rebind_train_epilogue():
     try:
         import utils.loss_utils as ref_loss
         ref_loss.ssim = T.ssim
+        ref_loss.l1_loss = T.l1_loss
     except ImportError:
         pass
     try:

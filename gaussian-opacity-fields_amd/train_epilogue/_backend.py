@@ -30,6 +30,11 @@ def _declare():
     lib.gof_depth_to_normal.argtypes = [i32, i32, vp, vp, f32, f32, vp, vp, vp]
     lib.gof_depth_to_normal_backward.argtypes = [i32, i32, vp, vp, f32, f32, vp, vp, vp, vp]
     lib.gof_adam_step.argtypes = [i32, C.POINTER(GofAdamTensor), C.c_double, C.c_double, C.c_double, vp]
+    lib.gof_l1_scratch_bytes.restype = sz
+    lib.gof_l1_scratch_bytes.argtypes = [C.c_uint64]
+    lib.gof_l1_forward.argtypes = [C.c_uint64, vp, vp, vp, vp, sz, vp]
+    lib.gof_l1_backward.argtypes = [C.c_uint64, vp, vp, vp, vp, vp]
+    lib.gof_l1_forward.restype = lib.gof_l1_backward.restype = C.c_int
     lib.gof_train_loss_scratch_bytes.restype = sz
     lib.gof_train_loss_scratch_bytes.argtypes = [i32, i32]
     lib.gof_train_loss.argtypes = [i32, i32, vp, vp, W11, vp, f32, f32, C.c_double, C.c_double, C.c_double, vp, vp, vp, sz, vp]
@@ -92,6 +97,21 @@ def depth_to_normal_backward(depth_hw, wvt, fx, fy, g_normals, g_points):
     out = torch.empty((H, W), dtype=torch.float32, device=depth_hw.device)
     _check(lib.gof_depth_to_normal_backward(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, g_normals.data_ptr(),
                                             g_points.data_ptr() if g_points is not None else None, out.data_ptr(), _stream()))
+    return out
+
+
+def l1_forward(a, b):
+    n = a.numel()
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    nb = lib.gof_l1_scratch_bytes(n)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=a.device)
+    _check(lib.gof_l1_forward(n, a.data_ptr(), b.data_ptr(), out.data_ptr(), scratch.data_ptr(), nb, _stream()))
+    return out.reshape(())
+
+
+def l1_backward(a, b, grad_out):
+    out = torch.empty_like(a)
+    _check(lib.gof_l1_backward(a.numel(), a.data_ptr(), b.data_ptr(), grad_out.data_ptr(), out.data_ptr(), _stream()))
     return out
 
 

@@ -1,7 +1,9 @@
 """Mirror of the reference's utils/loss_utils.py (same names, arguments and results) with SSIM on HIP kernels.
 
     reference                          here
-    l1_loss, l2_loss  (:17-21)         unchanged torch one-liners (two launches; nothing to fuse without train.py's help)
+    l1_loss           (:17-18)         one forward launch (+ a deterministic reduction) and one backward launch instead of
+                                        sub / abs / mean and their autograd (6 launches)
+    l2_loss           (:20-21)         unchanged torch one-liner (not used by train.py)
     ssim / _ssim      (:30-63)         one forward launch (+ a deterministic reduction) and one backward launch
                                         instead of 5 depthwise conv2d + ~15 elementwise kernels and their autograd
 """
@@ -10,7 +12,28 @@ import torch
 from . import _backend as B
 
 
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return B.l1_forward(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = B.l1_backward(a, b, g.to(torch.float32).contiguous()) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        return (ga if ctx.needs_input_grad[0] else None), (-ga if ctx.needs_input_grad[1] else None)
+
+
 def l1_loss(network_output, gt):
+    """utils/loss_utils.py:17-18: torch.abs((network_output - gt)).mean().  Same-shape float32 tensors (what train.py:156,328 pass)
+    take the two HIP launches; broadcasting / other dtypes take the reference's expression as torch ops on the same device.
+    Like every mirror of this package there is no CPU path: host tensors raise."""
+    if network_output.device.type != "cuda" or gt.device != network_output.device:
+        raise RuntimeError("l1_loss: both tensors must be on the same ROCm device (got %s and %s); the gfx950 backend has no CPU path"
+                           % (network_output.device, gt.device))
+    if network_output.shape == gt.shape and network_output.dtype == gt.dtype == torch.float32 and network_output.numel() > 0:
+        return _L1.apply(network_output.contiguous(), gt.contiguous())
     return torch.abs((network_output - gt)).mean()
 
 

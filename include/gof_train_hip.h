@@ -59,6 +59,13 @@ int gof_depth_to_normal_backward(int32_t W, int32_t H, const float* depth, const
                                  float fx, float fy, const float* dL_dnormals, const float* dL_dpoints,
                                  float* dL_ddepth, void* stream);
 
+/* ---- l1_loss (utils/loss_utils.py:17-18: torch.abs(a - b).mean(); train.py:156 and the evaluation loop :328) -------------
+ *      out_mean (device, 1 float) = sum|a - b| / n with a fixed summation order; backward: dL_da = grad_out[0] * sign(a - b) / n
+ *      (grad_out a device scalar; the gradient w.r.t. b is its negative). */
+size_t gof_l1_scratch_bytes(uint64_t n);
+int gof_l1_forward(uint64_t n, const float* a, const float* b, float* out_mean, void* scratch, size_t scratch_bytes, void* stream);
+int gof_l1_backward(uint64_t n, const float* a, const float* b, const float* grad_out, float* dL_da, void* stream);
+
 /* ---- the loss of one training iteration (train.py:150-188) as ONE call ("fused L1 + SSIM + depth-normal
  *      + distortion loss kernels").  train.py composes it inline from ~60 torch launches and their autograd:
  *          Ll1 = l1_loss(image, gt); rgb_loss = (1 - l_dssim) Ll1 + l_dssim (1 - ssim(image, gt))                 :156-161

@@ -1,14 +1,6 @@
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/v12
-rm -rf $O; mkdir -p $O
-python bench.py 2>/dev/null | tail -1 > $O/bench.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-loop > $O/prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python $R/tests/devtools/dev_pmc.py > $O/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python $R/tests/devtools/dev_pmc.py > $O/pmc_w.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_v -- python $R/tests/devtools/dev_pmc.py > $O/pmc_v.log 2>&1
-cd $R
-find $O -name "*kernel_trace.csv" -delete
-find $O -name "*.csv" | head -20
-cut -c1-400 $O/bench.json
+timeout 900 python -m pytest tests/test_train_epilogue_gpu.py -m gpu -q -x -k "l1_loss or composition or end_to_end or mirrors" --tb=short 2>&1 | cut -c1-400 | tail -8
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+f=d['full_loop']; print(d['value'], f['ms_per_iter'], f['one_call_loss']['ms_per_iter'], f['one_call_loss_split_sh']['ms_per_iter'])"

@@ -42,13 +42,13 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
     from scene.gaussian_model import GaussianModel
     props = {p_: getattr(GaussianModel, p_) for p_ in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation", "get_features")}
     assert all(isinstance(v, property) for v in props.values())          # they are properties in the reference too
-    orig = {"ssim": ref_loss.ssim, "d2n": ref_depth.depth_to_normal, "d2p": ref_depth.depths_to_points,
+    orig = {"ssim": ref_loss.ssim, "l1": ref_loss.l1_loss, "d2n": ref_depth.depth_to_normal, "d2p": ref_depth.depths_to_points,
             "setup": GaussianModel.training_setup, "f3d": GaussianModel.compute_3D_filter, "stats": GaussianModel.add_densification_stats}
     L = _load_launcher()
     L.rebind_train_epilogue()
     import train_epilogue as T
     try:
-        assert ref_loss.ssim is T.ssim and ref_depth.depth_to_normal is T.depth_to_normal and ref_depth.depths_to_points is T.depths_to_points
+        assert ref_loss.l1_loss is T.l1_loss and ref_loss.ssim is T.ssim and ref_depth.depth_to_normal is T.depth_to_normal and ref_depth.depths_to_points is T.depths_to_points
         assert GaussianModel.compute_3D_filter is T.compute_3D_filter and GaussianModel.add_densification_stats is T.add_densification_stats
         assert GaussianModel.training_setup is not orig["setup"]
         for prop in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation"):
@@ -64,11 +64,11 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
         assert got.shape == want.shape and torch.equal(got.transpose(1, 2).view(-1, 3, 16), want.transpose(1, 2).view(-1, 3, 16))   # gaussian_renderer/__init__.py:84
         assert not SplitSH(torch.randn(5, 1, 3), torch.randn(5, 8, 3)).native()       # fewer stored bands: the rasterizer concatenates
         # same call signatures as the functions they replace
-        for new, old in ((T.ssim, orig["ssim"]), (T.depth_to_normal, orig["d2n"]), (T.depths_to_points, orig["d2p"]),
+        for new, old in ((T.ssim, orig["ssim"]), (T.l1_loss, orig["l1"]), (T.depth_to_normal, orig["d2n"]), (T.depths_to_points, orig["d2p"]),
                          (T.compute_3D_filter, orig["f3d"]), (T.add_densification_stats, orig["stats"])):
             assert list(inspect.signature(new).parameters) == list(inspect.signature(old).parameters), (new, old)
     finally:
-        ref_loss.ssim, ref_depth.depth_to_normal, ref_depth.depths_to_points = orig["ssim"], orig["d2n"], orig["d2p"]
+        ref_loss.ssim, ref_loss.l1_loss, ref_depth.depth_to_normal, ref_depth.depths_to_points = orig["ssim"], orig["l1"], orig["d2n"], orig["d2p"]
         GaussianModel.training_setup, GaussianModel.compute_3D_filter, GaussianModel.add_densification_stats = orig["setup"], orig["f3d"], orig["stats"]
         for k_, v_ in props.items():
             setattr(GaussianModel, k_, v_)

@@ -174,6 +174,40 @@ def test_train_loss_composition_matches_oracle():
             _close(gp[c].cpu().numpy(), go[c].numpy(), 1e-4, "d loss / d rendering[%d]" % c)
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 53), (1,), (3, 1063, 1600), (8193,), (2, 3, 40, 33)])
+def test_l1_loss_matches_oracle_and_torch_autograd(shape):
+    """utils/loss_utils.py:17-18 on two HIP launches: value within 2e-6 of the oracle's (a sum of up to 5.1M terms in another order),
+    gradient = grad * sign(a - b) / n exactly as torch's autograd on the same GPU (bit for bit), ties (a == b) give 0."""
+    import train_epilogue as T
+    g = torch.Generator().manual_seed(sum(shape))
+    a = torch.rand(shape, generator=g)
+    b = torch.rand(shape, generator=g)
+    b.view(-1)[::7] = a.view(-1)[::7]
+    ad = a.to(DEV).requires_grad_(True)
+    bd = b.to(DEV)
+    v = T.l1_loss(ad, bd)
+    assert v.shape == () and v.dtype == torch.float32
+    (v * 1.7).backward()
+    assert v.item() == pytest.approx(O.l1_loss(a, b).item(), rel=2e-6)
+    at = a.to(DEV).requires_grad_(True)
+    (torch.abs(at - bd).mean() * 1.7).backward()
+    torch.testing.assert_close(ad.grad, at.grad, rtol=2e-7, atol=0)
+    assert (ad.grad.view(-1)[::7] == 0).all()
+    # golden value from the reference's own function
+    if shape == (3, 37, 53):
+        x = torch.from_numpy(G["ssim_a_x"]).to(DEV); y = torch.from_numpy(G["ssim_a_y"]).to(DEV)
+        assert T.l1_loss(x, y).item() == pytest.approx(float(G["l1_a_value"]), rel=2e-6)
+    # gradient w.r.t. the second argument, no-grad evaluation (train.py:328), broadcasting takes the torch expression, host tensors raise
+    b2 = b.to(DEV).requires_grad_(True)
+    T.l1_loss(a.to(DEV), b2).backward()
+    torch.testing.assert_close(b2.grad, -ad.grad / 1.7, rtol=1e-6, atol=0)
+    with torch.no_grad():
+        assert T.l1_loss(ad, bd).item() == v.item()
+    assert T.l1_loss(ad.detach(), bd.view(-1)[:1].reshape([1] * len(shape))).item() == pytest.approx(torch.abs(a - b.view(-1)[0]).mean().item(), rel=1e-5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        T.l1_loss(a, b)
+
+
 # ---- training_loss: train.py:150-188 as one operator (gof_train_loss) -----------------------------------------------
 GL = np.load(os.path.join(ROOT, "tests", "golden", "ref_train_loss_golden.npz"))
 TERMS = ("loss", "Ll1", "ssim", "rgb_loss", "depth_normal_loss", "distortion_loss")
