@@ -55,6 +55,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        dist.all_reduce(torch.zeros(1, device=dev))      # the communicator exists before a collective is issued from the autograd thread
 
     import synthetic_scenes as S
     from gpu_common import to_dev, settings_from

@@ -410,7 +410,8 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 
 size_t gof_backward_scratch_bytes(int32_t P) { (void)P; return 0; }
 
-int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes,
+// stages: 1 = zero-fill + blend_backward (K8), 2 = preprocess_bwd (K9), 3 = both
+static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes,
                  const void* binning_ws, size_t binning_bytes, const void* image_ws, size_t image_bytes, const float* dL_dout,
                  float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dsh_rest, float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian, void* scratch, size_t scratch_bytes,
@@ -438,6 +439,7 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     // dL_dcov3D; preprocess_bwd writes every element of dL_dmeans3D / dL_dscales / dL_drotations (zeros for culled Gaussians)
     // preprocess_bwd<true> (SH rows tiled through LDS) writes every element of dL_dsh itself: no memset for it
     const bool k9_tiled = split_sh || (a->shs && dL_dsh && a->M == 16 && ((reinterpret_cast<uintptr_t>(a->shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0);
+    if (stages & 1) {
     { GOF_PROFILE("backward_memsets", stream);
       // exactly adjacent buffers (the Python binding carves dL_dview2gaussian | dL_dcov3D | dL_dmeans2D | dL_dcolors from one
       // allocation) are cleared by ONE memset: each launch costs ~5 us of queue time, the bytes themselves 0.01 ms
@@ -461,6 +463,8 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
                            im.n_contrib, dL_dout, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian, d.gx, d.ntiles);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
+    }
+    if (!(stages & 2)) return GOF_OK;
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     GOF_PROFILE("preprocess_bwd", stream);
 #define GOF_K9_LAUNCH(MODE) hipLaunchKernelGGL(preprocess_bwd<MODE>, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, a->D, a->M, a->means3D, \
@@ -473,6 +477,21 @@ int gof_backward(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
+
+#define GOF_BACKWARD_ENTRY(NAME, STAGES)                                                                                                          \
+int NAME(const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes, const void* binning_ws,                \
+         size_t binning_bytes, const void* image_ws, size_t image_bytes, const float* dL_dout, float* dL_dmeans2D, float* dL_dcolors,             \
+         float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscales, float* dL_drotations,    \
+         float* dL_dview2gaussian, void* scratch, size_t scratch_bytes, void* stream)                                                             \
+{                                                                                                                                                 \
+    return backward_impl(STAGES, a, R, radii, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, dL_dout, dL_dmeans2D,        \
+                         dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dsh_rest, dL_dscales, dL_drotations, dL_dview2gaussian,      \
+                         scratch, scratch_bytes, stream);                                                                                         \
+}
+GOF_BACKWARD_ENTRY(gof_backward, 3)
+GOF_BACKWARD_ENTRY(gof_backward_blend, 1)
+GOF_BACKWARD_ENTRY(gof_backward_preprocess, 2)
+#undef GOF_BACKWARD_ENTRY
 
 int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float* points3D, void* point_ws, size_t point_bytes,
                                  uint32_t* num_integrated_host, void* stream_)

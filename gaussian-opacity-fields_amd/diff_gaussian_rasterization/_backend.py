@@ -52,6 +52,8 @@ def _load():
     lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_forward_fused.restype = C.c_int
     lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 10 + [vp, sz, vp]
+    lib.gof_backward_blend.argtypes = lib.gof_backward_preprocess.argtypes = lib.gof_backward.argtypes
+    lib.gof_backward_blend.restype = lib.gof_backward_preprocess.restype = C.c_int
     lib.gof_integrate_prepare_points.argtypes = [A, i32, vp, vp, sz, C.POINTER(u32), vp]
     lib.gof_integrate_run.argtypes = [A, u32, vp, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_integrate_view.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
@@ -277,21 +279,30 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         with torch.cuda.device(dev):
             nscratch = lib.gof_backward_scratch_bytes(P)
             scratch = v.bytes_tensor(nscratch) if nscratch else None
-            _check(lib.gof_backward(v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
-                                    binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),
-                                    _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D),
-                                    _ptr(g_sh[0] if v.split_sh else g_sh), _ptr(g_sh[1]) if v.split_sh else None,
-                                    _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g),
-                                    _ptr(scratch), nscratch, _stream()))
-        if _sh_track["on"] and M > 0:
-            _sh_track["count"] += 1
-            _sh_track["src"] = {"dL_dcolors": g_colors, "geom": geomBuffer, "radii": radii, "means3D": v.keep["means3D"], "campos": v.keep["campos"],
-                                "degree": int(degree), "M": M, "P": P}
+            call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
+                    binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),
+                    _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D),
+                    _ptr(g_sh[0] if v.split_sh else g_sh), _ptr(g_sh[1]) if v.split_sh else None,
+                    _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g), _ptr(scratch), nscratch, _stream())
+            track = _sh_track["on"] and M > 0
+            src = None
+            if track:
+                _sh_track["count"] += 1
+                src = _sh_track["src"] = {"dL_dcolors": g_colors, "geom": geomBuffer, "radii": radii, "means3D": v.keep["means3D"],
+                                          "campos": v.keep["campos"], "degree": int(degree), "M": M, "P": P}
+            if track and _sh_track["ready_cb"] is not None:
+                # the colour gradient is final after the blend stage: let the data-parallel reducer start its exchange while
+                # preprocess_bwd is still to run (dp/reducer.py)
+                _check(lib.gof_backward_blend(*call))
+                _sh_track["ready_cb"](src)
+                _check(lib.gof_backward_preprocess(*call))
+            else:
+                _check(lib.gof_backward(*call))
     return g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_v2g
 
 
 # ---- data-parallel training: the SH gradient in compressed form (include/gof_hip.h: gof_sh_grad_pack / gof_sh_grad_expand) ----
-_sh_track = {"on": False, "count": 0, "src": None}
+_sh_track = {"on": False, "count": 0, "src": None, "ready_cb": None}
 
 
 def track_sh_grad_source(on=True):
@@ -299,6 +310,14 @@ def track_sh_grad_source(on=True):
     forward's clamp flags, the camera centre).  dp/reducer.py enables it; nothing is kept otherwise."""
     _sh_track["on"] = bool(on)
     _sh_track["count"], _sh_track["src"] = 0, None
+    if not on:
+        _sh_track["ready_cb"] = None
+
+
+def set_sh_grad_ready_callback(fn):
+    """fn(src) is called inside every tracked backward right after the blend stage (the colour gradient of the view is final, the
+    parameter gradients are not yet computed); None removes it."""
+    _sh_track["ready_cb"] = fn
 
 
 def take_sh_grad_source():

@@ -26,12 +26,14 @@ def shard_views(views: List, rank: int, world: int) -> List:
 
 class GradientAllReducer:
     def __init__(self, params: Iterable[torch.Tensor], average: bool = False, group=None, wire_dtype=None, sh_params=None, sh_ops=None,
-                 track: bool = True):
+                 track: bool = True, early_gather: bool = True):
         """sh_params: the SH parameter(s) among `params` whose gradient may travel in compressed form -- one [P,M,3] tensor, or
         the reference's pair (_features_dc [P,1,3], _features_rest [P,M-1,3]).  Used only when their gradient since the last
         exchange stems from exactly one rasterizer backward (else the dense path runs).  sh_ops: the pack / expand
         implementation (default: the HIP kernels behind diff_gaussian_rasterization._backend).  track=False: the caller has
-        switched the rasterizer's tracking on itself (a reducer built per step must not reset it).
+        switched the rasterizer's tracking on itself (a reducer built per step must not reset it).  early_gather: start the
+        all-gather of the colour gradient from INSIDE the rasterizer's backward, between its blend and preprocess stages, so that
+        the collective runs while preprocess_bwd (and whatever autograd still has to do) executes.
         wire_dtype: None (default) = all-reduce the fp32 gradients as they are.  torch.bfloat16 halves the bytes on the xGMI
         links (the collective is exposed at the end of the step) at the price of bf16-rounded gradient sums --
         an opt-in for training runs, never used by bench.py's headline."""
@@ -46,8 +48,21 @@ class GradientAllReducer:
             raise ValueError("sh_params: one [P,M,3] tensor or the pair (features_dc, features_rest)")
         self._sh_ops = sh_ops
         self.last_exchange = None                    # "dense" | "compressed-sh": what the last all_reduce() did (tests, logging)
+        self._early = []                             # all-gathers started from inside the backward since the last exchange
         if self.sh_params and track:
-            self._ops().track(True)
+            self.enable_sh_tracking(early_gather)
+
+    def enable_sh_tracking(self, early_gather=True):
+        ops = self._ops()
+        ops.track(True)
+        if early_gather and hasattr(ops, "set_ready"):
+            ops.set_ready(self._on_colour_gradient)
+
+    def _on_colour_gradient(self, src):
+        """Called by the rasterizer's backward after its blend stage.  EVERY tracked backward starts its all-gather here (also a
+        second one in the same step, whose result is then discarded): the sequence of collectives stays identical on all ranks."""
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self._early.append(self._start_gather(src, dist.get_world_size(self.group)))
 
     def _ops(self):
         if self._sh_ops is None:
@@ -58,20 +73,14 @@ class GradientAllReducer:
                 take = staticmethod(B.take_sh_grad_source)
                 pack = staticmethod(B.sh_grad_pack)
                 expand = staticmethod(B.sh_grad_expand)
+                set_ready = staticmethod(B.set_sh_grad_ready_callback)
             self._sh_ops = _HipOps
         return self._sh_ops
 
-    def _sh_begin(self, world):
-        """Pack this view's colour gradient (+ camera centre) and START the all-gather.  Returns (src, gathered, work, grads), or
-        None when the compressed form is not applicable this step."""
-        src = self._ops().take()
-        grads = [p.grad for p in self.sh_params]
-        if src is None or any(g is None for g in grads):
-            return None
-        P, M = src["P"], src["M"]
-        if sum(g.numel() for g in grads) != 3 * M * P or not all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
-            return None
-        dev = grads[0].device
+    def _start_gather(self, src, world):
+        """Pack this view's colour gradient (+ camera centre) and START the all-gather; returns (src, gathered, work)."""
+        P = src["P"]
+        dev = src["dL_dcolors"].device if "dL_dcolors" in src else src["campos"].device
         mine = torch.empty((P + 1, 3), dtype=torch.float32, device=dev)
         self._ops().pack(src, mine)
         mine[P].copy_(src["campos"].reshape(3))
@@ -80,7 +89,27 @@ class GradientAllReducer:
             work = dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
         else:                                        # gloo (CPU tests, single-GPU development runs)
             work = dist.all_gather(list(gathered.unbind(0)), mine, group=self.group, async_op=True)
-        return src, gathered, work, grads
+        return src, gathered, work
+
+    def _sh_begin(self, world):
+        """The all-gather of this step's colour gradient -- already in flight if the backward started it, started now otherwise.
+        Returns (src, gathered, work, grads), or None when the compressed form is not applicable this step."""
+        src = self._ops().take()
+        early, self._early = self._early, []
+        grads = [p.grad for p in self.sh_params]
+        ok = src is not None and not any(g is None for g in grads)
+        if ok:
+            ok = (sum(g.numel() for g in grads) == 3 * src["M"] * src["P"]
+                  and all(g.is_contiguous() and g.dtype == torch.float32 for g in grads))
+        if early:
+            if ok and len(early) == 1 and early[0][0] is src:
+                return early[0] + (grads,)
+            for _, _, work in early:                 # not usable (several backwards, foreign gradients): complete them, go dense
+                work.wait()
+            return None
+        if not ok:
+            return None
+        return self._start_gather(src, world) + (grads,)
 
     def _sh_finish(self, pending, world):
         """Wait for the all-gather only and expand the sum over views into the SH gradients (the all-reduce of the other

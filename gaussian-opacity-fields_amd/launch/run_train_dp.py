@@ -39,6 +39,7 @@ def main():
     sys.path.append(os.path.join(PKG, "shims"))
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     rank, world = dist.get_rank(), dist.get_world_size()
+    dist.all_reduce(torch.zeros(1, device="cuda"))    # the communicator exists before a collective is issued from the autograd thread
 
     import scene as ref_scene
     from scene.gaussian_model import GaussianModel
@@ -55,17 +56,19 @@ def main():
     def training_setup(self, training_args):
         _setup(self, training_args)
 
+        dense = os.environ.get("GOF_DP_DENSE_SH") == "1"
+        reducer = GradientAllReducer([], track=False)
+
         def pre_step(optimizer, args, kwargs):
             # the nn.Parameters are replaced by every densification (gaussian_model.py:532-607): collect them per step
-            params = [p for g in optimizer.param_groups for p in g["params"]]
+            reducer.params = [p for g in optimizer.param_groups for p in g["params"]]
             by_name = {g.get("name"): g["params"][0] for g in optimizer.param_groups if len(g["params"]) == 1}
             sh = [by_name[n] for n in ("f_dc", "f_rest") if n in by_name]      # gaussian_model.py:351-352
-            compress = len(sh) == 2 and os.environ.get("GOF_DP_DENSE_SH") != "1"
-            GradientAllReducer(params, sh_params=sh if compress else None, track=False).all_reduce()
+            reducer.sh_params = sh if (len(sh) == 2 and not dense) else []
+            reducer.all_reduce()
         self.optimizer.register_step_pre_hook(pre_step)
-        if os.environ.get("GOF_DP_DENSE_SH") != "1":
-            from diff_gaussian_rasterization import _backend as _B
-            _B.track_sh_grad_source(True)
+        if not dense:
+            reducer.enable_sh_tracking()          # + the all-gather starts inside the rasterizer's backward
     GaussianModel.training_setup = training_setup
 
     # Densification statistics are accumulated per rank (each rank sees other views) and zeroed by every densification

@@ -156,6 +156,20 @@ int gof_backward(const GofRasterArgs* args,
                  void* scratch, size_t scratch_bytes,  /* gof_backward_scratch_bytes(P); NULL if 0 */
                  void* stream);
 
+/* The two stages of gof_backward as separate calls with the SAME argument list: gof_backward_blend zero-fills the accumulators
+ * and runs the per-pixel backward (afterwards dL_dmeans2D, dL_dcolors, dL_dopacity and dL_dview2gaussian are final),
+ * gof_backward_preprocess turns them into the parameter gradients.  A data-parallel trainer starts the exchange of the colour
+ * gradient between the two (dp/reducer.py); gof_backward = one after the other. */
+#define GOF_BACKWARD_ARGS                                                                                                          \
+    const GofRasterArgs* args, uint32_t num_rendered, const int32_t* radii, const void* geom_ws, size_t geom_bytes,               \
+    const void* binning_ws, size_t binning_bytes, const void* image_ws, size_t image_bytes, const float* dL_dout,                 \
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,               \
+    float* dL_dsh_rest, float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian, void* scratch, size_t scratch_bytes,   \
+    void* stream
+int gof_backward_blend(GOF_BACKWARD_ARGS);
+int gof_backward_preprocess(GOF_BACKWARD_ARGS);
+#undef GOF_BACKWARD_ARGS
+
 /* ---- integrate (replaces _C.integrate_gaussians_to_points, rasterize_points.cu:234-343) - */
 /* Stage 1 for the query points: preprocessPointsCUDA + scan + count read-back
  * (forward.cu:722-766, rasterizer_impl.cu:681-702).  SYNCHRONISES `stream`. */

@@ -79,9 +79,15 @@ def _worker(rank, world, port, ret):
     class FakeOps:
         src = None
 
+        ready = None
+
         @staticmethod
         def track(on):
             pass
+
+        @staticmethod
+        def set_ready(fn):
+            FakeOps.ready = fn
 
         @staticmethod
         def take():
@@ -125,7 +131,11 @@ def _worker(rank, world, port, ret):
             shp[0].grad = dense_sh(packed, campos)
         red3 = GradientAllReducer([xyz] + shp, sh_params=shp, sh_ops=FakeOps, average=split)
         FakeOps.src = {"P": P, "M": 16, "packed": packed, "campos": campos}
+        if split:                                     # as the rasterizer's backward does between its two stages: the gather starts early
+            FakeOps.ready(FakeOps.src)
+            ok = ok and len(red3._early) == 1
         red3.all_reduce()
+        ok = ok and red3._early == []
         div = world if split else 1
         got = torch.cat([p.grad for p in shp], 1)
         ok = ok and red3.last_exchange == "compressed-sh" and torch.allclose(got, want_sh / div, atol=1e-5)
@@ -134,9 +144,12 @@ def _worker(rank, world, port, ret):
         xyz.grad = local[0].clone()
         for p_, part in zip(shp, ([dense_sh(packed, campos)] if not split else [dense_sh(packed, campos)[:, :1].contiguous(), dense_sh(packed, campos)[:, 1:].contiguous()])):
             p_.grad = part
+        if split:                                     # two backwards since the last exchange: both early gathers are completed and discarded
+            FakeOps.ready({"P": P, "M": 16, "packed": packed, "campos": campos})
+            FakeOps.ready({"P": P, "M": 16, "packed": packed, "campos": campos})
         red3.all_reduce()
         got = torch.cat([p.grad for p in shp], 1)
-        ok = ok and red3.last_exchange == "dense" and torch.allclose(got, want_sh / div, atol=1e-5)
+        ok = ok and red3.last_exchange == "dense" and torch.allclose(got, want_sh / div, atol=1e-5) and red3._early == []
     # densification statistics
     acc = torch.full((P, 1), float(rank + 1)); acc_abs = acc.clone(); denom = torch.ones(P, 1)
     radii = torch.full((P,), float(rank)); absmax = torch.full((P, 1), float(10 - rank))

@@ -38,18 +38,23 @@ def _worker(rank, world, port, ret):
     sd = to_dev({**base, **cam})
     names = ("means3D", "shs", "opacities", "scales", "rotations")
     from diff_gaussian_rasterization import _backend as B
-    # ONE forward/backward per rank (the backward's atomic accumulation order differs from run to run, so the two exchange forms
-    # are applied to copies of the same local gradients)
-    B.track_sh_grad_source(True)
+    # ONE forward/backward per rank (the backward's atomic accumulation order differs from run to run, so every exchange form is
+    # applied to copies of the same local gradients).  The first reducer is the production configuration: tracking on and the
+    # all-gather started from INSIDE the backward, between its blend and preprocess stages.
     params = {k: sd[k].clone().requires_grad_(True) for k in names}
     means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    red_early = GradientAllReducer(list(params.values()), sh_params=[params["shs"]])
     color, _ = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
                                                      opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
     dL = torch.randn(color.shape, generator=torch.Generator().manual_seed(3 + rank)).to(color.device)
     color.backward(dL)
+    started_early = len(red_early._early) == 1
     local = {k: params[k].grad.clone() for k in names}
-    src = B.take_sh_grad_source()
-    results = {}
+    src = B._sh_track["src"]
+    red_early.all_reduce()
+    torch.cuda.synchronize()
+    results = {"early": ({k: params[k].grad.clone() for k in names}, red_early.last_exchange, local["shs"])}
+    B.set_sh_grad_ready_callback(None)
     for mode in ("dense", "compressed", "compressed-mean"):
         for k in names:
             params[k].grad = local[k].clone()
@@ -59,8 +64,12 @@ def _worker(rank, world, port, ret):
         red.all_reduce()
         torch.cuda.synchronize()
         results[mode] = ({k: params[k].grad.clone() for k in names}, red.last_exchange, local["shs"])
-    ok = results["dense"][1] == "dense" and results["compressed"][1] == "compressed-sh"
+    B.track_sh_grad_source(False)
+    ok = results["dense"][1] == "dense" and results["compressed"][1] == "compressed-sh" and results["early"][1] == "compressed-sh" and started_early
     msg = []
+    for k in names:
+        if not torch.equal(results["early"][0][k], results["dense"][0][k]):
+            ok = False; msg.append("%s: gather started inside the backward vs dense" % k)
     for k in names:
         a, b, c = results["dense"][0][k], results["compressed"][0][k], results["compressed-mean"][0][k]
         # two ranks: a + b is the only possible order, so the two forms agree bit for bit
