@@ -274,7 +274,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
 {
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
-    GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));
+    if (a->prefiltered) GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));   // only then written and read
     { GOF_PROFILE("preprocess_fwd", stream);
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,

@@ -21,6 +21,7 @@ namespace gof {
 
 constexpr int SCAN_ITEMS = 16;                       // per thread
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;         // 4096 items per block
+constexpr uint32_t SCAN_DIRECT_MAX = 2048;           // up to this many blocks (8.4M items) the scan runs as two launches
 #ifndef GOF_RS_CHUNK
 #define GOF_RS_CHUNK 1024
 #endif
@@ -82,13 +83,27 @@ scan_sums(uint32_t* __restrict__ sums, uint32_t nb)
     }
     if (threadIdx.x == 0) sums[nb] = carry;
 }
-// out[i] = (inclusive ? in[0..i] : in[0..i)) summed; optional gather: in[idx[i]] instead of in[i]
-template <bool INCLUSIVE, bool GATHER>
+// out[i] = (inclusive ? in[0..i] : in[0..i)) summed; optional gather: in[idx[i]] instead of in[i].
+// DIRECT: `sums` holds the RAW block sums (scan_sums was not run): every workgroup adds up the sums of the workgroups before it
+// itself (at most SCAN_DIRECT_MAX values -- cheaper than a third launch) and the last one leaves the grand total in sums[nb].
+template <bool INCLUSIVE, bool GATHER, bool DIRECT>
 __global__ void __launch_bounds__(256)
-scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, const uint32_t* __restrict__ sums,
+scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ sums,
            uint32_t* __restrict__ out)
 {
     __shared__ uint32_t s_wave[4];
+    uint32_t before = 0;
+    if (DIRECT) {
+        __shared__ uint32_t s_pre[4];
+        uint32_t pre = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) pre += sums[i];
+        for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off, 64);
+        if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = pre;
+        __syncthreads();
+        before = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
+    } else {
+        before = sums[blockIdx.x];
+    }
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
@@ -99,7 +114,8 @@ scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, ui
         s += v[k];
     }
     uint32_t total;
-    uint32_t run = sums[blockIdx.x] + block_exclusive_scan(s, &total, s_wave);
+    uint32_t run = before + block_exclusive_scan(s, &total, s_wave);
+    if (DIRECT && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) sums[gridDim.x] = before + total;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < n) out[base + k] = INCLUSIVE ? run + v[k] : run;
@@ -132,14 +148,14 @@ hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* ou
     if (n == 0) return hipMemsetAsync(tmp, 0, 2 * sizeof(uint32_t), stream);
     if (idx) hipLaunchKernelGGL(scan_block_sums_gather<true>, dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp);
     else hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, stream, in, (uint32_t)n, tmp);
-    hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, tmp, nb);
-    if (idx) {
-        if (inclusive) hipLaunchKernelGGL((scan_apply<true, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out);
-        else hipLaunchKernelGGL((scan_apply<false, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out);
-    } else {
-        if (inclusive) hipLaunchKernelGGL((scan_apply<true, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out);
-        else hipLaunchKernelGGL((scan_apply<false, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out);
-    }
+    const bool direct = nb <= SCAN_DIRECT_MAX;         // few workgroups: each adds up its predecessors' sums itself, two launches
+    if (!direct) hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, tmp, nb);
+#define GOF_SCAN_APPLY(INC, GA)                                                                                                        \
+    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out);   \
+         else hipLaunchKernelGGL((scan_apply<INC, GA, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out); } while (0)
+    if (idx) { if (inclusive) GOF_SCAN_APPLY(true, true); else GOF_SCAN_APPLY(false, true); }
+    else { if (inclusive) GOF_SCAN_APPLY(true, false); else GOF_SCAN_APPLY(false, false); }
+#undef GOF_SCAN_APPLY
     return hipGetLastError();
 }
 

@@ -174,7 +174,7 @@ def _prepare_and_bin(v):
     """Stage 1 shared by forward and integrate: preprocess + scan + instance count."""
     geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
     img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
-    radii = torch.zeros(v.P, dtype=torch.int32, device=v.device)
+    radii = torch.empty(v.P, dtype=torch.int32, device=v.device)       # preprocess_fwd writes every element (0 for culled Gaussians)
     n = C.c_uint32(0)
     _check(lib.gof_forward_prepare(v.ref(), _ptr(geom), geom.numel(), _ptr(img), img.numel(), _ptr(radii), C.byref(n), _stream()))
     rendered = int(n.value)
@@ -218,7 +218,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
             img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
             binning = v.bytes_tensor(lib.gof_binning_bytes(cap, v.W, v.H))
-            radii = torch.zeros(v.P, dtype=torch.int32, device=v.device)
+            radii = torch.empty(v.P, dtype=torch.int32, device=v.device)
             pin = _pinned.get(str(v.device))
             if pin is None:
                 pin = _pinned[str(v.device)] = torch.zeros(4, dtype=torch.int32).pin_memory()
