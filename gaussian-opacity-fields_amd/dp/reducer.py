@@ -24,6 +24,30 @@ def shard_views(views: List, rank: int, world: int) -> List:
     return list(views[rank::world])
 
 
+class ViewShards:
+    """Which training cameras this rank renders, and the way back: train.py keeps ONE list (train.py:106) for both the per-step
+    camera sampling (sharded) and compute_3D_filter (which must see ALL cameras, SURVEY.md 8(e), or the replicas diverge)."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+        self._by_key = {}                    # key (e.g. resolution scale) -> (this rank's cameras, all cameras)
+
+    def shard(self, cams: List, key=1.0) -> List:
+        if self.world == 1:
+            return cams
+        if key not in self._by_key or self._by_key[key][1] is not cams:
+            self._by_key[key] = (shard_views(cams, self.rank, self.world), cams)
+        return self._by_key[key][0]
+
+    def full(self, cameras):
+        """The full list if `cameras` is (a copy of) one of this rank's shards, else `cameras` unchanged."""
+        cams = list(cameras)
+        for mine, everyone in self._by_key.values():
+            if len(cams) == len(mine) and all(a is b for a, b in zip(cams, mine)):
+                return everyone
+        return cameras
+
+
 class GradientAllReducer:
     def __init__(self, params: Iterable[torch.Tensor], average: bool = False, group=None, wire_dtype=None, sh_params=None, sh_ops=None,
                  track: bool = True, early_gather: bool = True):

@@ -12,6 +12,7 @@ Injection points; NEW behaviour, the reference has no multi-GPU
                                           the parameter gradients (the optimizer object survives densification); the SH
                                           gradient (81 % of the bytes) travels in compressed form, dp/reducer.py
                                           (GOF_DP_DENSE_SH=1: dense all-reduce of everything)
+  * gaussian_model.py:262-311          -> compute_3D_filter is fed ALL training cameras on every rank, not the shard train.py holds
   * gaussian_model.py:685-707          -> densify_and_prune first all-reduces the statistics accumulated since the last
                                           densification (SUM for the accumulators / denom, MAX for max_radii2D / abs-max)
   * train.py:247-250,276-301           -> only rank 0 writes point clouds / checkpoints / TensorBoard
@@ -30,10 +31,15 @@ sys.path.insert(0, PKG)
 def main():
     import torch
     import torch.distributed as dist
-    from dp import GradientAllReducer, shard_views
+    from dp import GradientAllReducer, ViewShards
     from dp.reducer import all_reduce_densification_stats
 
     script = os.path.abspath(sys.argv[1])
+    if "--use_decoupled_appearance" in sys.argv:
+        # train.py:109-110 numbers the cameras it holds (camera.idx) and indexes the appearance embeddings with that number; under
+        # view sharding every rank would number its own shard, so the all-reduced embedding gradients would mix different cameras
+        raise NotImplementedError("run_train_dp.py: --use_decoupled_appearance is not supported with view sharding (per-camera "
+                                  "embedding indices are assigned per rank by train.py:109-110)")
     sys.path.insert(0, os.path.dirname(script))
     sys.path.insert(0, PKG)
     sys.path.append(os.path.join(PKG, "shims"))
@@ -46,10 +52,20 @@ def main():
 
     _get_train = ref_scene.Scene.getTrainCameras
 
+    shards = ViewShards(rank, world)
+
     def get_train_sharded(self, scale=1.0):
-        cams = _get_train(self, scale)
-        return shard_views(cams, rank, world) if world > 1 else cams
+        return shards.shard(_get_train(self, scale), scale)
     ref_scene.Scene.getTrainCameras = get_train_sharded
+
+    # compute_3D_filter(cameras=trainCameras) (train.py:118,261,269) receives the shard; the filter depends on ALL training cameras
+    # (per-point minimum depth over the cameras that see it, gaussian_model.py:262-311) and must be identical on every rank: map
+    # the shard back to the full list -- every rank holds all camera poses, no communication needed.
+    full_camera_list = shards.full
+    import train_epilogue.filter_3d as _f3d
+    _f3d.CAMERA_LIST_HOOK = full_camera_list
+    _ref_filter = GaussianModel.compute_3D_filter          # effective with GOF_TORCH_EPILOGUE=1 (the reference's own method stays)
+    GaussianModel.compute_3D_filter = lambda self, cameras: _ref_filter(self, full_camera_list(cameras))
 
     _setup = GaussianModel.training_setup
 

@@ -48,11 +48,19 @@ def filter_3d(xyz, cam_table):
     return out[..., None]
 
 
+# A view-sharded trainer (launch/run_train_dp.py) hands train.py only this rank's cameras; the 3D filter must still be computed
+# from ALL training cameras or the replicas diverge.  The launcher installs a function here that maps the list
+# train.py passes to the full list.
+CAMERA_LIST_HOOK = None
+
+
 @torch.no_grad()
 def compute_3D_filter(self, cameras):
     """Method replacement for GaussianModel.compute_3D_filter(self, cameras)."""
     print("Computing 3D filter")
     xyz = self.get_xyz
+    if CAMERA_LIST_HOOK is not None:
+        cameras = CAMERA_LIST_HOOK(cameras)
     cams = list(cameras)
     key = (id(cameras), len(cams), str(xyz.device))
     cached = getattr(self, "_gof_cam_table", None)

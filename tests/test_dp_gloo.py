@@ -160,6 +160,16 @@ def _worker(rank, world, port, ret):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     ok = ok and sorted(sum(gathered, [])) == views and len(set(map(tuple, gathered))) == world
+    # ViewShards: the rank's cameras for the per-step sampling, the full list back for compute_3D_filter (train.py:106,118)
+    from dp import ViewShards
+    cams = [object() for _ in range(11)]
+    vs = ViewShards(rank, world)
+    mine_c = vs.shard(cams)
+    ok = ok and mine_c == cams[rank::world] and vs.shard(cams) is mine_c
+    ok = ok and vs.full(mine_c.copy()) is cams and vs.full(mine_c) is cams          # train.py keeps a .copy() of the list
+    other = [object() for _ in range(len(mine_c))]
+    ok = ok and vs.full(other) is other and vs.full(cams) is cams                    # anything else passes through unchanged
+    ok = ok and ViewShards(0, 1).shard(cams) is cams
     # view-sharded opacity-field evaluation (extract_mesh.py:17-34): identical to the serial loop over all views
     from dp import evaluate_alpha
     PN, NV = 4001, 7
