@@ -50,16 +50,17 @@ struct MtWs {
     uint32_t* bsum;        // [3][nbp] per-block (4096 tets) counts of {valid, 1-triangle, 2-triangle} -> their exclusive scans
                            // (nbp = #blocks + 1).  There are no per-tet scan arrays: the kernels that need a tet's rank rebuild the
                            // block-local scan from the case bytes (1 B per tet) on top of these block prefixes
-    uint32_t* vt;          // [Tt] ids of the valid tets, ascending (compacted)
-    uint32_t* frank;       // [Tt] per valid tet: its rank among the 1-triangle (resp. 2-triangle) tets before it
+    uint32_t* vt;          // [Tv] ids of the valid tets, ascending (compacted)
+    uint32_t* frank;       // [Tv] per valid tet: its rank among the 1-triangle (resp. 2-triangle) tets before it
     uint32_t* chunk_tab;   // [MT_MAX_CHUNKS + 1][2] #1-triangle / #2-triangle tets before every chunk boundary (tetmesh.py:55-95)
-    uint32_t* e_lo[2];     // [6*Tt] larger vertex id of every edge of every valid tet (emission order) + sort buffer
-    uint32_t* e_hi[2];     // [6*Tt] smaller vertex id
-    uint32_t* uscan;       // [6*Tt+1] exclusive scan of "first occurrence"
-    uint64_t* ukeys;       // [6*Tt] unique keys (min << 32 | max), ascending
-    uint32_t* cscan;       // [6*Tt+1] exclusive scan of "crossing" over unique keys
+    uint32_t* e_lo[2];     // [6*Tv] larger vertex id of every edge of every valid tet (emission order) + sort buffer
+    uint32_t* e_hi[2];     // [6*Tv] smaller vertex id
+    uint32_t* uscan;       // [6*Tv+1] exclusive scan of "first occurrence"
+    uint64_t* ukeys;       // [6*Tv] unique keys (min << 32 | max), ascending
+    uint32_t* cscan;       // [6*Tv+1] exclusive scan of "crossing" over unique keys
     int64_t* counters;     // [8] Tv, U, E, F1, F2
-    uint32_t* tmp;         // scan / sort scratch
+    uint32_t* tmp;         // scan / sort scratch of the edge stage
+    uint32_t* tmp_tet;     // scan scratch of the block counts
     size_t nbp;
 };
 
@@ -71,28 +72,39 @@ static inline void carve(char*& p, T*& ptr, size_t count)
     p += count * sizeof(T);
 }
 
-static size_t mt_layout(int64_t Tt, void* base, MtWs* out)
+// Two caller-owned workspaces: the per-TET part (1 byte per tet + block prefixes; known before anything ran) and the per-VALID-tet
+// part (sized after gof_mtets_classify has returned how many tets the surface crosses -- a fraction of a percent of a
+// Delaunay triangulation, so sizing the edge arrays for the worst case would cost ~200 B per tet).
+static size_t mt_tet_layout(int64_t Tt, void* base, MtWs* w)
 {
-    MtWs w;
+    MtWs tmp;
+    MtWs& o = w ? *w : tmp;
     char* p = static_cast<char*>(base);
-    const size_t n = (size_t)Tt, e = 6 * n;
-    w.nbp = (n + 1 + MT_BLOCK - 1) / MT_BLOCK + 1;
-    carve(p, w.tetcase, n);
-    carve(p, w.bsum, 3 * w.nbp);
-    carve(p, w.vt, n);
-    carve(p, w.frank, n);
-    carve(p, w.chunk_tab, 2 * (MT_MAX_CHUNKS + 1));
-    carve(p, w.e_lo[0], e); carve(p, w.e_lo[1], e);
-    carve(p, w.e_hi[0], e); carve(p, w.e_hi[1], e);
-    carve(p, w.uscan, e + 1);
-    carve(p, w.ukeys, e);
-    carve(p, w.cscan, e + 1);
-    carve(p, w.counters, 8);
+    const size_t n = (size_t)Tt;
+    o.nbp = (n + 1 + MT_BLOCK - 1) / MT_BLOCK + 1;
+    carve(p, o.tetcase, n);
+    carve(p, o.bsum, 3 * o.nbp);
+    carve(p, o.chunk_tab, 2 * (MT_MAX_CHUNKS + 1));
+    carve(p, o.counters, 8);
+    carve(p, o.tmp_tet, scan_tmp_words(o.nbp));
+    return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+}
+static size_t mt_edge_layout(int64_t Tv, void* base, MtWs* w)
+{
+    MtWs tmp;
+    MtWs& o = w ? *w : tmp;
+    char* p = static_cast<char*>(base);
+    const size_t n = (size_t)Tv, e = 6 * n;
+    carve(p, o.vt, n);
+    carve(p, o.frank, n);
+    carve(p, o.e_lo[0], e); carve(p, o.e_lo[1], e);
+    carve(p, o.e_hi[0], e); carve(p, o.e_hi[1], e);
+    carve(p, o.uscan, e + 1);
+    carve(p, o.ukeys, e);
+    carve(p, o.cscan, e + 1);
     size_t words = rs_tmp_words(e);
     if (scan_tmp_words(e + 1) > words) words = scan_tmp_words(e + 1);
-    if (scan_tmp_words(w.nbp) > words) words = scan_tmp_words(w.nbp);
-    carve(p, w.tmp, words);
-    if (out) *out = w;
+    carve(p, o.tmp, words);
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
 
@@ -355,38 +367,72 @@ using namespace gof;
 
 extern "C" {
 
-size_t gof_mtets_ws_bytes(int64_t num_tets) { return mt_layout(num_tets < 0 ? 0 : num_tets, nullptr, nullptr) + ALIGN; }
+size_t gof_mtets_tet_ws_bytes(int64_t num_tets) { return mt_tet_layout(num_tets < 0 ? 0 : num_tets, nullptr, nullptr) + ALIGN; }
+size_t gof_mtets_edge_ws_bytes(int64_t num_valid_tets) { return mt_edge_layout(num_valid_tets < 0 ? 0 : num_valid_tets, nullptr, nullptr) + ALIGN; }
 
-int gof_mtets_count(int64_t V, int64_t Tt, const int64_t* tets, const float* sdf, void* ws, size_t ws_bytes,
-                    int64_t* num_edges_host, int64_t* num_faces_host, void* stream_)
+static int mt_check_sizes(int64_t V, int64_t Tt)
 {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!num_edges_host || !num_faces_host) { set_error("mtets: output pointers are NULL"); return GOF_E_INVALID; }
-    *num_edges_host = 0; *num_faces_host = 0;
     if (Tt < 0 || V < 0 || V >= (1ll << 32)) { set_error("mtets: bad sizes (V must be < 2^32)"); return GOF_E_INVALID; }
     if (6 * Tt + 1 >= (1ll << 32)) { set_error("mtets: too many tets (%lld): 6 * #tets must be < 2^32", (long long)Tt); return GOF_E_INVALID; }
+    return GOF_OK;
+}
+
+int gof_mtets_classify(int64_t V, int64_t Tt, const int64_t* tets, const float* sdf, void* tet_ws, size_t tet_ws_bytes,
+                       int64_t* num_valid_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!num_valid_host) { set_error("mtets: output pointer is NULL"); return GOF_E_INVALID; }
+    *num_valid_host = 0;
+    if (int e = mt_check_sizes(V, Tt)) return e;
     if (Tt == 0) return GOF_OK;
-    if (!tets || !sdf || !ws) { set_error("mtets: NULL input"); return GOF_E_INVALID; }
-    if (ws_bytes < gof_mtets_ws_bytes(Tt)) { set_error("mtets: workspace too small"); return GOF_E_WORKSPACE; }
+    if (!tets || !sdf || !tet_ws) { set_error("mtets: NULL input"); return GOF_E_INVALID; }
+    if (tet_ws_bytes < gof_mtets_tet_ws_bytes(Tt)) { set_error("mtets: tet workspace too small"); return GOF_E_WORKSPACE; }
     MtWs w;
-    mt_layout(Tt, reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(ws))), &w);
+    mt_tet_layout(Tt, reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(tet_ws))), &w);
     const dim3 blk(256);
-    const auto grid = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     const uint32_t nbp = (uint32_t)w.nbp, nb = nbp - 1;
-    hipLaunchKernelGGL(mt_classify, grid(Tt), blk, 0, stream, Tt, tets, sdf, w.tetcase);
+    hipLaunchKernelGGL(mt_classify, dim3((unsigned)((Tt + 255) / 256)), blk, 0, stream, Tt, tets, sdf, w.tetcase);
     GOF_LAUNCH_CHECK(stream, 0);
     GOF_HIP_CHECK(hipMemsetAsync(w.bsum, 0, 3 * (size_t)nbp * sizeof(uint32_t), stream));   // entry nb of each row stays 0 -> its scan = the total
     hipLaunchKernelGGL(mt_count_blocks, dim3(nb), blk, 0, stream, Tt, w.tetcase, w.bsum, nbp);
     GOF_LAUNCH_CHECK(stream, 0);
     for (int k = 0; k < 3; k++)
-        GOF_HIP_CHECK(device_scan_u32(w.bsum + (size_t)k * nbp, nullptr, w.bsum + (size_t)k * nbp, nbp, false, w.tmp, nullptr, stream));
+        GOF_HIP_CHECK(device_scan_u32(w.bsum + (size_t)k * nbp, nullptr, w.bsum + (size_t)k * nbp, nbp, false, w.tmp_tet, nullptr, stream));
     uint32_t host[3];
     for (int k = 0; k < 3; k++)
         GOF_HIP_CHECK(hipMemcpyAsync(&host[k], w.bsum + (size_t)k * nbp + nb, 4, hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
-    const int64_t Tv = host[0], F = (int64_t)host[1] + 2 * (int64_t)host[2];
+    const int64_t cnt[5] = { (int64_t)host[0], 0, 0, (int64_t)host[1], (int64_t)host[2] };
+    GOF_HIP_CHECK(hipMemcpyAsync(w.counters, cnt, sizeof(cnt), hipMemcpyHostToDevice, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    *num_valid_host = host[0];
+    return GOF_OK;
+}
+
+int gof_mtets_count(int64_t V, int64_t Tt, const int64_t* tets, const float* sdf, void* tet_ws, size_t tet_ws_bytes,
+                    void* edge_ws, size_t edge_ws_bytes, int64_t* num_edges_host, int64_t* num_faces_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!num_edges_host || !num_faces_host) { set_error("mtets: output pointers are NULL"); return GOF_E_INVALID; }
+    *num_edges_host = 0; *num_faces_host = 0;
+    if (int e = mt_check_sizes(V, Tt)) return e;
+    if (Tt == 0) return GOF_OK;
+    if (!tets || !sdf || !tet_ws) { set_error("mtets: NULL input"); return GOF_E_INVALID; }
+    if (tet_ws_bytes < gof_mtets_tet_ws_bytes(Tt)) { set_error("mtets: tet workspace too small"); return GOF_E_WORKSPACE; }
+    MtWs w;
+    mt_tet_layout(Tt, reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(tet_ws))), &w);
+    int64_t cnt[5];
+    GOF_HIP_CHECK(hipMemcpyAsync(cnt, w.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t Tv = cnt[0], F = cnt[3] + 2 * cnt[4];
+    if (Tv < 0 || Tv > Tt) { set_error("mtets: the tet workspace holds no classification (run gof_mtets_classify first)"); return GOF_E_INVALID; }
+    const dim3 blk(256);
+    const auto grid = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    const uint32_t nbp = (uint32_t)w.nbp, nb = nbp - 1;
     int64_t U = 0, E = 0;
     if (Tv > 0) {
+        if (!edge_ws || edge_ws_bytes < gof_mtets_edge_ws_bytes(Tv)) { set_error("mtets: edge workspace too small for %lld valid tets", (long long)Tv); return GOF_E_WORKSPACE; }
+        mt_edge_layout(Tv, reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(edge_ws))), &w);
         const int64_t ne = 6 * Tv;
         hipLaunchKernelGGL(mt_compact_valid, dim3(nb), blk, 0, stream, Tt, w.tetcase, w.bsum, nbp, w.vt, w.frank);
         GOF_LAUNCH_CHECK(stream, 0);
@@ -414,7 +460,7 @@ int gof_mtets_count(int64_t V, int64_t Tt, const int64_t* tets, const float* sdf
         GOF_HIP_CHECK(hipStreamSynchronize(stream));
         E = u32;
     }
-    const int64_t cnt[5] = { Tv, U, E, (int64_t)host[1], (int64_t)host[2] };
+    cnt[1] = U; cnt[2] = E;
     GOF_HIP_CHECK(hipMemcpyAsync(w.counters, cnt, sizeof(cnt), hipMemcpyHostToDevice, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
     *num_edges_host = E;
@@ -423,22 +469,24 @@ int gof_mtets_count(int64_t V, int64_t Tt, const int64_t* tets, const float* sdf
 }
 
 int gof_mtets_emit(int64_t V, int64_t Tt, const int64_t* tets, const float* vertices, const float* sdf, const float* scales,
-                   const void* ws, size_t ws_bytes, int64_t num_edges, int64_t num_faces, int64_t* edge_ids, float* edge_pos,
-                   float* edge_sdf, float* edge_scales, int64_t* faces, void* stream_)
+                   const void* tet_ws, size_t tet_ws_bytes, const void* edge_ws, size_t edge_ws_bytes, int64_t num_edges, int64_t num_faces,
+                   int64_t* edge_ids, float* edge_pos, float* edge_sdf, float* edge_scales, int64_t* faces, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     (void)V;
     if (Tt <= 0 || (num_edges == 0 && num_faces == 0)) return GOF_OK;
-    if (!tets || !vertices || !sdf || !scales || !ws || !edge_ids || !edge_pos || !edge_sdf || !edge_scales || !faces) {
+    if (!tets || !vertices || !sdf || !scales || !tet_ws || !edge_ws || !edge_ids || !edge_pos || !edge_sdf || !edge_scales || !faces) {
         set_error("mtets: NULL pointer"); return GOF_E_INVALID; }
-    if (ws_bytes < gof_mtets_ws_bytes(Tt)) { set_error("mtets: workspace too small"); return GOF_E_WORKSPACE; }
+    if (tet_ws_bytes < gof_mtets_tet_ws_bytes(Tt)) { set_error("mtets: tet workspace too small"); return GOF_E_WORKSPACE; }
     MtWs w;
-    mt_layout(Tt, reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(ws))), &w);
+    mt_tet_layout(Tt, reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(tet_ws))), &w);
     int64_t cnt[5];
     GOF_HIP_CHECK(hipMemcpyAsync(cnt, w.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
     const int64_t U = cnt[1];
     if (cnt[2] != num_edges || cnt[3] + 2 * cnt[4] != num_faces) { set_error("mtets: counts do not match the workspace (run gof_mtets_count first)"); return GOF_E_INVALID; }
+    if (cnt[0] > 0 && edge_ws_bytes < gof_mtets_edge_ws_bytes(cnt[0])) { set_error("mtets: edge workspace too small"); return GOF_E_WORKSPACE; }
+    mt_edge_layout(cnt[0], reinterpret_cast<void*>(align_up(reinterpret_cast<size_t>(edge_ws))), &w);
     const dim3 blk(256);
     const auto grid = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
     if (U > 0) {

@@ -43,7 +43,8 @@ def _load():
     lib.gof_last_error.restype = C.c_char_p
     lib.gof_abi_version.restype = C.c_int
     for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]),
-                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32]), ("gof_mtets_ws_bytes", [i64])):
+                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32]), ("gof_mtets_tet_ws_bytes", [i64]),
+                       ("gof_mtets_edge_ws_bytes", [i64])):
         f = getattr(lib, name)
         f.restype = sz
         f.argtypes = args
@@ -68,14 +69,15 @@ def _load():
     lib.gof_sh_grad_pack.argtypes = [i32, vp, vp, sz, vp, vp, vp]
     lib.gof_sh_grad_expand.argtypes = [i32, i32, i32, i32, vp, vp, i64, vp, i64, C.c_float, vp, i64, vp, i64, vp]
     lib.gof_sh_grad_pack.restype = lib.gof_sh_grad_expand.restype = C.c_int
-    lib.gof_mtets_count.argtypes = [i64, i64, vp, vp, vp, sz, C.POINTER(i64), C.POINTER(i64), vp]
-    lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
+    lib.gof_mtets_classify.argtypes = [i64, i64, vp, vp, vp, sz, C.POINTER(i64), vp]
+    lib.gof_mtets_count.argtypes = [i64, i64, vp, vp, vp, sz, vp, sz, C.POINTER(i64), C.POINTER(i64), vp]
+    lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.gof_debug_fetch.restype = i64
     lib.gof_debug_fetch.argtypes = [C.c_char_p, A, u32, vp, vp, vp, vp, sz, vp]
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
     for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
-                 "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_integrate_points_packed", "gof_integrate_pack_geom", "gof_mark_visible", "gof_mtets_count", "gof_mtets_emit"):
+                 "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_integrate_points_packed", "gof_integrate_pack_geom", "gof_mark_visible", "gof_mtets_classify", "gof_mtets_count", "gof_mtets_emit"):
         getattr(lib, name).restype = C.c_int
     return lib
 

@@ -256,21 +256,27 @@ int gof_sh_grad_expand(int32_t P, int32_t D, int32_t M, int32_t n_views, const f
                        float* out_dc, int64_t stride_dc, float* out_rest, int64_t stride_rest, void* stream);
 
 /* ---- marching tetrahedra (replaces utils/tetmesh.py:47-138, pure torch in the reference) */
-/* Phase 1: classify tets, collect the unique crossing edges (sorted ascending by
- * (min vertex, max vertex), the order torch.unique(dim=0) produces, tetmesh.py:110) and
- * count faces.  SYNCHRONISES `stream`; returns the counts to the host. */
-size_t gof_mtets_ws_bytes(int64_t num_tets);
-int gof_mtets_count(int64_t num_verts, int64_t num_tets,
-                    const int64_t* tets /* [Tt,4] */, const float* sdf /* [V] */,
-                    void* ws, size_t ws_bytes,
+/* Three calls over two caller-owned workspaces.
+ * Phase 0, gof_mtets_classify: the 4-bit case of every tet (1 byte per tet) and the number of tets the surface crosses, returned
+ *   to the host (SYNCHRONISES `stream`).  tet_ws: gof_mtets_tet_ws_bytes(num_tets) -- about 1 byte per tet.
+ * Phase 1, gof_mtets_count: collect the unique crossing edges (sorted ascending by (min vertex, max vertex), the order
+ *   torch.unique(dim=0) produces, tetmesh.py:110) and count faces; SYNCHRONISES, returns the counts.  edge_ws:
+ *   gof_mtets_edge_ws_bytes(num_valid_tets of phase 0) -- about 200 bytes per VALID tet (may be NULL when there is none).
+ * Phase 2, gof_mtets_emit: edge end-point ids [E,2] (int64), end-point positions [E,2,3], end-point sdf [E,2], end-point scales
+ *   [E,2] and faces [F,3] (int64) in the reference's order (per 32 Mi-tet chunk all 1-triangle tets first, then the 2-triangle
+ *   tets; tetmesh.py:55-95, 126-136).
+ * Vertex ids must be < 2^32 and 6 * num_tets < 2^32. */
+size_t gof_mtets_tet_ws_bytes(int64_t num_tets);
+size_t gof_mtets_edge_ws_bytes(int64_t num_valid_tets);
+int gof_mtets_classify(int64_t num_verts, int64_t num_tets, const int64_t* tets /* [Tt,4] */, const float* sdf /* [V] */,
+                       void* tet_ws, size_t tet_ws_bytes, int64_t* num_valid_tets_host, void* stream);
+int gof_mtets_count(int64_t num_verts, int64_t num_tets, const int64_t* tets, const float* sdf,
+                    void* tet_ws, size_t tet_ws_bytes, void* edge_ws, size_t edge_ws_bytes,
                     int64_t* num_edges_host, int64_t* num_faces_host, void* stream);
-/* Phase 2: emit edge end-point ids [E,2] (int64), end-point positions [E,2,3], end-point
- * sdf [E,2], end-point scales [E,2] and faces [F,3] (int64) in the reference's order
- * (all 1-triangle tets first, then the 2-triangle tets; tetmesh.py:126-136). */
 int gof_mtets_emit(int64_t num_verts, int64_t num_tets,
                    const int64_t* tets, const float* vertices /* [V,3] */,
                    const float* sdf, const float* scales /* [V] */,
-                   const void* ws, size_t ws_bytes,
+                   const void* tet_ws, size_t tet_ws_bytes, const void* edge_ws, size_t edge_ws_bytes,
                    int64_t num_edges, int64_t num_faces,
                    int64_t* edge_ids, float* edge_pos, float* edge_sdf, float* edge_scales,
                    int64_t* faces, void* stream);
