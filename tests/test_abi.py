@@ -80,3 +80,27 @@ def test_train_epilogue_struct_and_host_queries():
     assert L.gof_ssim_forward(0, 8, 8, None, None, None, None, None, None, 0, None) < 0
     assert L.gof_depth_to_normal(8, 8, None, None, 1.0, 1.0, None, None, None) < 0
     assert len(TB.window_taps()) == 11 and abs(sum(TB.window_taps()) - 1.0) < 1e-6
+
+
+def test_headers_are_plain_c():
+    """The boundary is a C ABI: every header under include/ must compile as C99 on its own (no C++ constructs, no torch / HIP types),
+    and together (no clashing declarations)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    inc = os.path.join(ROOT, "include")
+    headers = sorted(glob.glob(os.path.join(inc, "*.h")))
+    assert len(headers) >= 3
+    for h in headers:
+        r = subprocess.run([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-pedantic", "-Werror", "-x", "c", h], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "all.c")
+        with open(src, "w") as f:
+            f.write("".join('#include "%s"\n' % os.path.basename(h) for h in headers) + "int main(void) { return gof_abi_version() > 0 ? 0 : 1; }\n")
+        r = subprocess.run([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-I", inc, src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
