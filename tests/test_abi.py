@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "gof_hip.h")
 LIB = os.path.join(ROOT, "gaussian-opacity-fields_amd", "lib", "libgof_hip.so")
