@@ -106,3 +106,43 @@ def test_headers_are_plain_c():
             f.write("".join('#include "%s"\n' % os.path.basename(h) for h in headers) + "int main(void) { return gof_abi_version() > 0 ? 0 : 1; }\n")
         r = subprocess.run([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-I", inc, src], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_a_c_client_links_against_the_library():
+    """What the reference's maintainer would do from C / cgo / JNI: include the headers, link libgof_hip.so, call it.  Host-only
+    entry points (workspace sizes, ABI version, argument validation) run without a GPU."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    lib_dir = os.path.join(ROOT, "gaussian-opacity-fields_amd", "lib")
+    code = r"""
+#include <stdio.h>
+#include "gof_hip.h"
+#include "gof_train_hip.h"
+#include "gof_knn_hip.h"
+int main(void) {
+    GofRasterArgs a = {0};
+    size_t g1 = gof_geom_bytes(1000), g2 = gof_geom_bytes(2000);
+    if (!(g2 > g1 && gof_image_bytes(1600, 1063) > 0 && gof_binning_bytes(1000000u, 1600, 1063) > 0)) return 2;
+    if (gof_abi_version() < 3) return 3;
+    a.P = 10; a.W = 0; a.H = 16;                                   /* invalid: reported, not crashed */
+    unsigned int n = 0;
+    if (gof_forward_prepare(&a, (void*)0, 0, (void*)0, 0, (int*)0, &n, (void*)0) >= 0) return 4;
+    if (gof_last_error()[0] == 0) return 5;
+    if (gof_mtets_tet_ws_bytes(1000000) >= gof_mtets_tet_ws_bytes(1000000) + gof_mtets_edge_ws_bytes(1000000)) return 6;
+    printf("abi %d geom %zu\n", gof_abi_version(), g1);
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "client.c"), os.path.join(d, "client")
+        with open(src, "w") as f:
+            f.write(code)
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", lib_dir, "-lgof_hip",
+                            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([exe], capture_output=True, text=True, env={**os.environ, "LD_LIBRARY_PATH": lib_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")})
+        assert r.returncode == 0 and r.stdout.startswith("abi "), (r.returncode, r.stdout, r.stderr)
