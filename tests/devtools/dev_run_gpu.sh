@@ -1,4 +1,8 @@
 cd $GRAFT_REPO_ROOT
-( time timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 ) 2>&1 | cut -c1-250
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-( time python bench.py > gpurun_out/bench_final.json ) 2>&1 | tail -3
+for g in 200000 5000000; do
+python bench.py --gaussians $g --no-cpu-baseline --no-full-loop 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print($g, d['value'], d['ms_per_step'], d['config']['num_rendered'], {k:round(v['avg_ms'],3) for k,v in d['roofline']['kernels'].items()})"
+done
+python tests/devtools/dev_integrate_cache_bench.py 2>&1 | tail -6
