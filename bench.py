@@ -26,8 +26,8 @@ import torch         # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1063)
@@ -38,11 +38,32 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (RANK unset): re-run this command line under torch.distributed.run with one
+    process per GPU (the same line the driver uses for N > 1) and hand its exit code back.  The ranks find RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment and take the branch below."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL over dmabuf IPC (the host driver supports nothing else)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus N` "
+                         "or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     distributed = world > 1
     # GOF_BENCH_SHARE_GPU=1 (development only): run the N-rank flow on fewer GPUs than ranks, with gloo instead of RCCL
     share = os.environ.get("GOF_BENCH_SHARE_GPU") == "1"
@@ -78,7 +99,9 @@ def main():
         # GOF_DP_DENSE_SH=1 all-reduces the dense 236 B instead (A/B)
         reducer = GradientAllReducer(list(params.values()), sh_params=None if os.environ.get("GOF_DP_DENSE_SH") == "1" else [params["shs"]])
 
-    def step():
+    ex_events = []                                # (start, end) torch events around the exchange of every timed step
+
+    def step(timed=False):
         for p in params.values():
             p.grad = None
         means2D.grad = None
@@ -86,7 +109,14 @@ def main():
                             scales=params["scales"], rotations=params["rotations"])
         color.backward(dL)
         if distributed:
-            reducer.all_reduce()
+            if timed:                                 # the exchange ends with work.wait() on the current stream: events on it bracket the exposed part
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reducer.all_reduce()
+                e1.record()
+                ex_events.append((e0, e1))
+            else:
+                reducer.all_reduce()
         return radii
 
     def fence():
@@ -97,16 +127,22 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # HIP events around every kernel launch, recorded by the library on its launch stream INSIDE the timed region, on every 4th
-    # step: each event pair drains the queue between two kernels (measured: 0.085 ms per fully instrumented step, 2.3 %)
+    # ---- the timed region: exactly `steps` steps, no instrumentation inside (the exchange events are two stream markers) ----
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if rank == 0:
-            B.profile_enable(i % 4 == 0)
-        step()
+        step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    exchange_ms = (sum(a.elapsed_time(b) for a, b in ex_events) / len(ex_events)) if ex_events else None
+    # ---- per-kernel durations: a SEPARATE pass of instrumented steps (HIP events recorded by the library on its launch stream
+    # around every launch; each event pair drains the queue between two kernels, so this pass is ~2 % slower than the timed one) ----
     kernel_times = None
+    prof_steps = max(4, min(16, args.steps))
+    if rank == 0:
+        B.profile_enable(True)
+    for _ in range(prof_steps):
+        step()
+    fence()
     if rank == 0:
         kernel_times = B.profile_report()
         B.profile_enable(False)
@@ -114,6 +150,11 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if exchange_ms is not None:
+            t = torch.tensor([exchange_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_ms = float(t.item())
+        assert dist.get_world_size() == args.gpus
 
     ms_per_step = 1e3 * elapsed / args.steps
     iters_per_s = world * args.steps / elapsed        # views (= training iterations of the reference) per second, whole job
@@ -121,10 +162,10 @@ def main():
     out = None
     if rank == 0:
         # ---- per-stage timing with HIP events on the launch stream + roofline of the dominant HBM kernel ----
-        stage = stage_times(B, sd, dL, dev, kernel_times, args.steps)
+        stage = stage_times(B, sd, dL, dev, kernel_times, prof_steps)
         out = {
             "metric": "train iters/sec (fwd+bwd of the rasterizer, 1 view/GPU/step), S1M synthetic",
-            "value": round(iters_per_s, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(iters_per_s, 3), "unit": "iters/s", "n_gpus": (dist.get_world_size() if distributed else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "S1M: %d Gaussians @ %dx%d, SH degree 3, kernel_size %.2f, fwd+bwd%s" % (
@@ -133,6 +174,15 @@ def main():
                 "fwd_ms": round(stage["fwd_ms"], 4), "bwd_ms": round(stage["bwd_ms"], 4), "parallelism": "dp%d (views)" % world},
             "roofline": stage["roofline"],
         }
+        if distributed:
+            n = world
+            kind = reducer.last_exchange
+            wire = (2.0 * (n - 1) / n * 236 * P) if kind == "dense" else (2.0 * (n - 1) / n * 44 * P + (n - 1) * 12.0 * (P + 1))
+            out["exchange"] = {"kind": kind, "ms": round(exchange_ms, 4), "wire_bytes_per_rank": int(wire),
+                               "wire_GBps_per_rank": round(wire / (exchange_ms * 1e-3) / 1e9, 1) if exchange_ms else None,
+                               "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "what": "exposed time of GradientAllReducer.all_reduce() per step (max over ranks), from stream events around it; "
+                                       "the all-gather of the colour gradient starts inside the backward and overlaps preprocess_bwd"}
         if world == 1 and not args.no_full_loop:
             out["full_loop"] = full_loop(sd, dev, W, H)
         if world == 1 and not args.no_cpu_baseline:

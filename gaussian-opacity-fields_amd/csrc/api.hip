@@ -51,7 +51,7 @@ __global__ void point_keys(int PN, const float2* points2D, const uint32_t* offse
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev);
 __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* gids, const float* depths, uint64_t* keys);
 
-__global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* bbox, int W, int H,
+__global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
                               float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
@@ -367,7 +367,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     }
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
                        im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
     GOF_LAUNCH_CHECK(stream, 0);
     GOF_HIP_CHECK(hipEventSynchronize(ev));
@@ -402,7 +402,7 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     if (rc) return rc;
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, g.bbox, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
                        im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;

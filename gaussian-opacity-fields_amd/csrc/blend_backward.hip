@@ -48,6 +48,15 @@ constexpr int NGRAD = 17;   // colour 3, mean2D 3, opacity 1, view2gaussian 10
 constexpr int BATCH = GOF_BW_BATCH;
 static_assert(BATCH == 128 || BATCH == 256, "BATCH must be 128 or 256");
 
+#ifdef GOF_STATS
+// developer-only instrumentation (never in the shipped build): [0] wave iterations of the entry loop, [1] (row, iteration) pairs with
+// an entry to visit, [2] contributing (lane, entry) pairs, [3] word fetches, [4] staged entries
+__device__ unsigned long long g_bw_stats[8];
+#define BSTAT_ADD(i, v) atomicAdd(&g_bw_stats[i], (unsigned long long)(v))
+#else
+#define BSTAT_ADD(i, v)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
@@ -93,6 +102,20 @@ __device__ __forceinline__ void row_sum16_transposed(const float* g, bool b0, bo
     }
 }
 
+// OR over the 16-lane row; every lane of the row gets the result
+__device__ __forceinline__ uint32_t row_or(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);    // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);    // row_mirror
+#ifdef GOF_BW_WAVEWALK                                      // A/B: all four rows of the wave walk the union of the whole wave
+    v |= (uint32_t)__shfl_xor((int)v, 16);
+    v |= (uint32_t)__shfl_xor((int)v, 32);
+#endif
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
@@ -114,13 +137,16 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
     const float rx = (float)(((double)pixfx - W / 2.) / (double)focal_x);
     const float ry = (float)(((double)pixfy - H / 2.) / (double)focal_y);
-    const float pxm = (float)px, pym = (float)py;   // pixf - 0.5 (backward.cu:770), exact
+    const f2 RX = { rx, rx }, RY = { ry, ry }, RXY = { rx, ry }, RYX = { ry, rx };
+    const f2 PXM = { (float)px, (float)py };       // pixf - 0.5 (backward.cu:770), exact
 
     const uint2 range = ranges[tile];
     const uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
 
-    __shared__ float4 s_rec[4][BATCH];
-    __shared__ float4 s_conic[BATCH];
+    // LDS record of a staged entry, arranged as the operand pairs of the packed arithmetic (v = view2gaussian):
+    //   q0 = {v0, v1 | v1, v3}, q1 = {v2, v4 | v2, v6}, q2 = {v4, v7 | v5, v8}   (prelude, as in blend_forward)
+    //   q3 = {CC, w | r, g}, q4 = {b, - | mean2D.x, mean2D.y}, q5 = {conic.x, conic.z | conic.y, conic.y}
+    __shared__ f4 s_rec[6][BATCH];
     __shared__ uint32_t s_id[BATCH];
     __shared__ float s_acc[NGRAD][BATCH];
     __shared__ uint32_t s_touched[BATCH];
@@ -144,6 +170,8 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     bg_dot_dpixel += bg_color[0] * dpx0;
     bg_dot_dpixel += bg_color[1] * dpx1;
     bg_dot_dpixel += bg_color[2] * dpx2;
+    // incoming gradients as the pairs the channel recurrences run on: (colour 0, 1), (colour 2, normal 2), (normal 0, 1)
+    const f2 DP01 = { dpx0, dpx1 }, DP2N2 = { dpx2, dn2 }, DN01 = { dn0, dn1 };
 
     // tile-wide maximum of last_contributor: nothing behind it is ever used
     if (tid == 0) s_max_last = 0;
@@ -158,13 +186,12 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const uint32_t max_last = min(s_max_last, range.y - range.x);
     if (max_last == 0) return;
 
-    float acc0 = 0, acc1 = 0, acc2 = 0;          // accum_rec
-    float lc0 = 0, lc1 = 0, lc2 = 0;             // last_color
-    float an0 = 0, an1 = 0, an2 = 0;             // accum_normal_rec
-    float ln0 = 0, ln1 = 0, ln2 = 0;             // last_normal
-    float last_alpha = 0;
-    const float ddelx_dx = (float)(0.5 * W);
-    const float ddely_dy = (float)(0.5 * H);
+    // accum_rec / accum_normal_rec of backward.cu:824-837, 862-867 for the channel pairs (colour 0, 1), (colour 2, normal 2),
+    // (normal 0, 1).  The reference folds the PREVIOUS pair into them at the start of a pair (last_alpha, last_color); here the
+    // current pair is folded in at its end -- the same operation on the same operands, one iteration earlier, so last_alpha /
+    // last_color / last_normal (7 more loop-carried registers) are not needed.
+    f2 acc01 = { 0, 0 }, acc2n = { 0, 0 }, accn01 = { 0, 0 };
+    const f2 DDEL = { (float)(0.5 * W), (float)(0.5 * H) };        // ddelx_dx, ddely_dy
     // mapped depth (2DGS NDC mapping, forward.cu:545): m(t) = (FAR t - FAR NEAR) / ((FAR-NEAR) t)
     const float MAP_A = (float)(GOF_FAR_PLANE / (GOF_FAR_PLANE - GOF_NEAR_PLANE));
     const float MAP_B = (float)(GOF_FAR_PLANE * GOF_NEAR_PLANE / (GOF_FAR_PLANE - GOF_NEAR_PLANE));
@@ -177,19 +204,19 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
         const uint32_t p0 = (uint32_t)kb * BATCH;
         const int n = (int)min((uint32_t)BATCH, max_last - p0);
         {
-            // staging: BATCH entries by 256 threads -> (256 / BATCH) threads share one 64-byte record
-            constexpr int TPE = TILE_PIX / BATCH;            // threads per entry: 1 or 2
-            constexpr int F4 = 4 / TPE;                      // float4 per thread
-            const uint32_t e = tid / TPE, part = tid % TPE;
-            if ((int)e < n) {
-                const uint32_t id = point_list[range.x + p0 + e];
-                const float4* src = reinterpret_cast<const float4*>(&rec[id]) + part * F4;
-#pragma unroll
-                for (int q = 0; q < F4; q++) s_rec[part * F4 + q][e] = src[q];
-                if (part == 0) {
-                    s_conic[e] = conic[id];
-                    s_id[e] = id;
-                }
+            // staging: one thread per entry reads the 64-byte record + the 2D conic and writes the pair layout
+            if ((int)tid < n) {
+                const uint32_t id = point_list[range.x + p0 + tid];
+                const float4* src = reinterpret_cast<const float4*>(&rec[id]);
+                const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+                const float4 co = conic[id];
+                s_rec[0][tid] = f4{ a.x, a.y, a.y, a.w };
+                s_rec[1][tid] = f4{ a.z, b.x, a.z, b.z };
+                s_rec[2][tid] = f4{ b.x, b.w, b.y, c.x };
+                s_rec[3][tid] = f4{ c.y, c.z, c.w, d.x };
+                s_rec[4][tid] = f4{ d.y, 0.f, d.z, d.w };
+                s_rec[5][tid] = f4{ co.x, co.z, co.y, co.y };
+                s_id[tid] = id;
             }
             const int nw = (n + 31) >> 5;
 #pragma unroll
@@ -199,13 +226,24 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
             if (tid < BATCH) s_touched[tid] = 0;
         }
         __syncthreads();
+        if (tid == 0) BSTAT_ADD(4, n);
 
-        for (int w = ((n + 31) >> 5) - 1; w >= 0; w--) {
-            const uint32_t word = s_cm[w][tid];
-            if (__ballot(word != 0u) == 0ull) continue;            // no pixel of this wave has a contributor in these 32 entries
-            for (int b = 31; b >= 0; b--) {
-                const bool contrib = (word >> b) & 1u;
-                if (__ballot(contrib) == 0ull) continue;
+        // Every 16-lane ROW (a 4x4 pixel block, tile_pixel) walks the union of ITS pixels' contributors on its own: the loop
+        // below runs max-over-rows(|row union|) times per batch instead of |wave union| times, and the lanes of a row stay in
+        // lock step on one entry, which is what the in-row reduction needs.  roww = bits of mask word w some pixel of the row
+        // still has to visit (row-uniform); the highest bit is the next entry (back to front).
+        int w = ((n + 31) >> 5) - 1;
+        uint32_t word = s_cm[w][tid];
+        uint32_t roww = row_or(word);
+        for (;;) {
+            if (__ballot(roww != 0u || w > 0) == 0ull) break;
+            const bool row_active = roww != 0u;                      // a row that is between words idles through this iteration
+            if (lane == 0) BSTAT_ADD(0, 1);
+            if ((lane & 15u) == 0u && row_active) BSTAT_ADD(1, 1);
+            {
+                const int b = 31 - __builtin_clz(roww | 1u);
+                const bool contrib = row_active && ((word >> b) & 1u);
+                roww &= ~(1u << b);
                 const int j = w * 32 + b;
                 const uint32_t contributor = p0 + (uint32_t)j;       // 0-based list position (backward.cu:763)
 
@@ -213,121 +251,129 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
 #pragma unroll
                 for (int k = 0; k < NGRAD; k++) g[k] = 0.f;
                 if (contrib) {
-                    const float4 a = s_rec[0][j], bq = s_rec[1][j], c = s_rec[2][j], d = s_rec[3][j];
-                    const float v[10] = { a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w, c.x, c.y };
-                    const float wgt = c.z;
+                    BSTAT_ADD(2, 1);
+                    const f4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j], q5 = s_rec[5][j];
+                    // fp32 prelude in the forward's operation order (min_value is ill-conditioned in it), two values per instruction
+                    const f2 n01 = (q0.xy * RX + q0.zw * RY) + q1.xy;               // normal[0], normal[1]
+                    const f2 n2b = (q1.zw * RX + q2.xy * RY) + q2.zw;               // normal[2], BB / 2
+                    const f2 rn = RXY * n01;
                     PairEval p;
-                    pair_prelude(v, rx, ry, p);
-                    pair_exact_backward(v, wgt, p);                 // alpha, G, t, q to ~5e-7 of the forward's values (no decision depends on them here)
+                    p.n0 = n01.x; p.n1 = n01.y; p.n2 = n2b.x;
+                    p.AAf = (rn.x + rn.y) + n2b.x;
+                    p.BBf = 2 * n2b.y;
+                    const float wgt = q3.y;
+                    pair_exact_backward_cc(q3.x, wgt, p);           // alpha, G, t, q to ~5e-7 of the forward's values (no decision depends on them here)
                     // Everything below is gradient arithmetic held to a tolerance (the reference rounds every term to fp32 before its
-                    // atomicAdd and accumulates in arbitrary order), not to bit-identity: let the compiler contract mul+add into FMA
-                    // here.  alpha, G, t, q above keep the forward's exact (uncontracted) arithmetic -- they are ill-conditioned.
+                    // atomicAdd and accumulates in arbitrary order), not to bit-identity: FMA contraction allowed, packed where two
+                    // values see the same operation.  alpha, G, t, q above keep the forward's exact (uncontracted) prelude.
                     {
 #pragma clang fp contract(fast)
-                    const float4 con = s_conic[j];
                     const float G = p.G, alpha = p.alpha;
-                    const float dx = d.z - pxm, dy = d.w - pym;
+                    const f2 dxy = q4.zw - PXM;
 
                     const float t = p.t;
                     const float inv_t = __builtin_amdgcn_rcpf(t);
                     const float mapped_max_t = MAP_A - MAP_B * inv_t;
                     const float dmax_t_dd = MAP_B * inv_t * inv_t;
-                    const float len2 = p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2 + 1e-7f;
+                    const f2 sq = n01 * n01;
+                    const float len2 = (sq.x + sq.y) + p.n2 * p.n2 + 1e-7f;
                     const float inv_len = __builtin_amdgcn_rsqf(len2);
-                    const float nn0 = -p.n0 * inv_len, nn1 = -p.n1 * inv_len, nn2 = -p.n2 * inv_len;
+                    const f2 NINV = { -inv_len, -inv_len };
+                    const f2 nn01 = n01 * NINV;
+                    const f2 c2n = { q4.x, p.n2 * NINV.x };         // colour 2 | unit normal 2
 
                     // recurrence of backward.cu:816 (T = T / (1 - alpha)) with the hardware reciprocal (1 ulp) that the background
                     // term needs anyway: <= 1.5 ulp per step instead of 0.5, over ~70 steps -> 1e-5 relative at worst
                     const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * inv_1ma;
                     const float dchannel_dcolor = alpha * T;
+                    const f2 DCD = { dchannel_dcolor, dchannel_dcolor };
 
-                    float dL_dalpha = 0.0f;
-                    {
-                        const float c0 = c.w, c1 = d.x, c2 = d.y;
-                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = c0;
-                        dL_dalpha += (c0 - acc0) * dpx0;
-                        g[0] = dchannel_dcolor * dpx0;
-                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = c1;
-                        dL_dalpha += (c1 - acc1) * dpx1;
-                        g[1] = dchannel_dcolor * dpx1;
-                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = c2;
-                        dL_dalpha += (c2 - acc2) * dpx2;
-                        g[2] = dchannel_dcolor * dpx2;
-                    }
+                    // the six channel terms of dL_dalpha (backward.cu:824-837, 862-867) on three register pairs, then this pair is
+                    // folded into the accumulators for the next one (in front of it)
+                    f2 da2 = (q3.zw - acc01) * DP01;
+                    da2 += (c2n - acc2n) * DP2N2;
+                    da2 += (nn01 - accn01) * DN01;
+                    float dL_dalpha = da2.x + da2.y;
+                    const f2 AL = { alpha, alpha }, OMA = { 1.f - alpha, 1.f - alpha };
+                    acc01 = AL * q3.zw + OMA * acc01;
+                    acc2n = AL * c2n + OMA * acc2n;
+                    accn01 = AL * nn01 + OMA * accn01;
+                    const f2 g01 = DCD * DP01;                      // dL_dcolour 0, 1
+                    const f2 g2d = DCD * DP2N2;                     // dL_dcolour 2 | dL_dnormal_normalized 2
+                    const f2 dnn01 = DCD * DN01;
+                    g[0] = g01.x; g[1] = g01.y; g[2] = g2d.x;
+                    const float dnn2 = g2d.y;
+
                     // distortion: only dL_dmax_t survives (dL_dweight is detached, backward.cu:848-852)
                     const float dL_dmax_t = 2.0f * (T * alpha) * (mapped_max_t * final_A - final_D) * dL_dreg * dmax_t_dd;
 
-                    float dnn0, dnn1, dnn2;
-                    an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nn0;
-                    dL_dalpha += (nn0 - an0) * dn0;
-                    dnn0 = dchannel_dcolor * dn0;
-                    an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = nn1;
-                    dL_dalpha += (nn1 - an1) * dn1;
-                    dnn1 = dchannel_dcolor * dn1;
-                    an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nn2;
-                    dL_dalpha += (nn2 - an2) * dn2;
-                    dnn2 = dchannel_dcolor * dn2;
-
                     // d(-n/|n|): dL_dn = (-dnn + (dnn . n) n / |n|^2) / |n|
-                    const float dL_dlength = (dnn0 * p.n0 + dnn1 * p.n1 + dnn2 * p.n2) * (inv_len * inv_len);
-                    float dL_dn0 = (-dnn0 + dL_dlength * p.n0) * inv_len;
-                    float dL_dn1 = (-dnn1 + dL_dlength * p.n1) * inv_len;
-                    float dL_dn2 = (-dnn2 + dL_dlength * p.n2) * inv_len;
+                    const f2 dd = dnn01 * n01;
+                    const float dL_dlength = ((dd.x + dd.y) + dnn2 * p.n2) * (inv_len * inv_len);
+                    const f2 DLEN = { dL_dlength, dL_dlength }, INV = { inv_len, inv_len };
+                    f2 dLn01 = (DLEN * n01 - dnn01) * INV;
+                    float dL_dn2 = (dL_dlength * p.n2 - dnn2) * inv_len;
 
                     float dL_dt = dL_dmax_t;
                     if (contributor == max_contributor - 1u) dL_dt += dL_dmax_depth;
 
                     dL_dalpha *= T;
-                    last_alpha = alpha;
                     dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
 
                     const float dL_dG = wgt * dL_dalpha;
-                    const float gdx = G * dx;
-                    const float gdy = G * dy;
-                    const float dG_ddelx = -gdx * con.x - gdy * con.y;
-                    const float dG_ddely = -gdy * con.z - gdx * con.y;
-                    g[3] = dL_dG * dG_ddelx * ddelx_dx;
-                    g[4] = dL_dG * dG_ddely * ddely_dy;
-                    g[5] = fabsf(g[3]) + fabsf(g[4]);
+                    // dG_ddelx = -G dx con.x - G dy con.y, dG_ddely = -G dy con.z - G dx con.y   (backward.cu:897-909)
+                    const f2 gd = dxy * f2{ G, G };
+                    const f2 dG = gd * q5.xy + gd.yx * q5.zw;       // negated below
+                    const f2 g34 = dG * DDEL * f2{ -dL_dG, -dL_dG };
+                    g[3] = g34.x; g[4] = g34.y;
+                    g[5] = fabsf(g34.x) + fabsf(g34.y);
                     g[6] = G * dL_dalpha;
 
                     // min_value = CC - (BB/AA)(BB/4), t = -BB/(2AA)
-                    const float qf = (float)p.q;
+                    const float qf = p.qf;
                     const float dL_dmin_value = -0.5f * (dL_dG * G);
                     const float inv2AA = 0.5f * __builtin_amdgcn_rcpf(p.AAf);
                     const float dL_dA = dL_dmin_value * (qf * qf) * 0.25f + dL_dt * qf * inv2AA;
-                    const float dL_dB = -0.5f * (dL_dmin_value * qf) - dL_dt * inv2AA;
-                    dL_dn0 += dL_dA * rx;
-                    dL_dn1 += dL_dA * ry;
+                    const float dL_dB2 = -(dL_dmin_value * qf) - 2.0f * (dL_dt * inv2AA);      // 2 dL_dB
+                    dLn01 += f2{ dL_dA, dL_dA } * RXY;
                     dL_dn2 += dL_dA;
-                    g[7] = dL_dn0 * rx;
-                    g[8] = dL_dn0 * ry + dL_dn1 * rx;
-                    g[9] = dL_dn0 + dL_dn2 * rx;
-                    g[10] = dL_dn1 * ry;
-                    g[11] = dL_dn1 + dL_dn2 * ry;
+                    const f2 g710 = dLn01 * RXY;                    // dL_dv2g 0, 3
+                    const f2 cr = dLn01 * RYX;
+                    const f2 g911 = dLn01 + f2{ dL_dn2, dL_dn2 } * RXY;   // dL_dv2g 2, 4
+                    const f2 g1314 = f2{ dL_dB2, dL_dB2 } * RXY;    // dL_dv2g 6, 7
+                    g[7] = g710.x;
+                    g[8] = cr.x + cr.y;
+                    g[9] = g911.x;
+                    g[10] = g710.y;
+                    g[11] = g911.y;
                     g[12] = dL_dn2;
-                    g[13] = dL_dB * 2 * rx;
-                    g[14] = dL_dB * 2 * ry;
-                    g[15] = dL_dB * 2;
+                    g[13] = g1314.x;
+                    g[14] = g1314.y;
+                    g[15] = dL_dB2;
                     g[16] = dL_dmin_value;
                     }
                 }
-                // rows (16 lanes = 8x2 pixels) in which no pixel contributed hold exact zeros: skip their LDS adds
-                const uint64_t cmask64 = __ballot(contrib);
-                const bool row_hit = ((cmask64 >> (lane & 48u)) & 0xFFFFull) != 0ull;
+                // in-row reduction (16 lanes = the 4x4 pixel block): 16 values transposed, the 17th plainly; lanes 0..3 / lane 15
+                // of the row add the sums into the batch accumulator of the row's entry
                 float w4[4];
                 row_sum16_transposed(g, (lane & 1u) != 0u, (lane & 2u) != 0u, w4);
                 const float g16 = row_sum(g[16]);
-                if ((lane & 12u) == 0u && row_hit) {            // lanes 0..3 of the row: values 4m + (lane & 3)
+                if ((lane & 12u) == 0u && row_active) {             // lanes 0..3 of the row: values 4m + (lane & 3)
                     float* dst = &s_acc[lane & 3u][j];
 #pragma unroll
                     for (int m = 0; m < 4; m++) unsafeAtomicAdd(dst + (size_t)m * 4 * BATCH, w4[m]);
                 }
-                if ((lane & 15u) == 15u && row_hit) {
+                if ((lane & 15u) == 15u && row_active) {
                     unsafeAtomicAdd(&s_acc[16][j], g16);
                     s_touched[j] = 1u;
                 }
+            }
+            if (roww == 0u && w > 0) {                              // this row's word is used up: fetch the next (row-uniform)
+                w--;
+                word = s_cm[w][tid];
+                roww = row_or(word);
+                if ((lane & 15u) == 0u) BSTAT_ADD(3, 1);
             }
         }
         __syncthreads();
@@ -347,5 +393,15 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
         }
     }
 }
+
+#ifdef GOF_STATS
+extern "C" int gof_debug_bw_stats(unsigned long long* out8, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bw_stats), sizeof(g_bw_stats));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 } // namespace gof

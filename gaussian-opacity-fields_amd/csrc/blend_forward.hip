@@ -9,11 +9,13 @@
 // a pixel keeps ~89 candidates, ~72 contribute).  A lock-step loop makes all 64 pixels of a wave pay the
 // exact path whenever ANY of them needs it.  Instead, per staged batch of 256 entries:
 //
-//   phase 1 (cull scan): (a) lane = ENTRY, 64 entries at a time: the entry's conservative footprint box (the box of the
-//     alpha >= 1/255 level-set ellipsoid, computed once per Gaussian in preprocess_fwd, see footprint_bbox) against the
-//     wave's pixel rectangle -> a wave-uniform ballot of the entries that touch the wave at all; (b) lane = PIXEL, scalar
-//     loop over those entries: the pixel's own box test, the fp32 prelude and the error-bounded cull
-//     (pair_certainly_transparent); survivors are recorded as a 256-bit mask of ITS pixel in LDS (s_mask[word][thread]).
+//   phase 1 (cull scan, lane = PIXEL): the entry's FOOTPRINT CONIC g(r) = r^T M r (preprocess_fwd: footprint_bbox; g > 0 <=> the
+//     pixel ray misses the alpha >= 1/255 level-set ellipsoid, raised by the forward-error allowance of the blend's own fp32
+//     arithmetic) evaluated at the pixel's ray: 5 FMAs per (pixel, entry) in Horner form, written as PACKED fp32 over two
+//     consecutive entries (v_pk_fma_f32: the six coefficients are staged SoA in LDS, so one ds_read_b128 broadcast brings one
+//     coefficient of FOUR entries as two ready-made operand pairs), and the candidate bit is the sign of g - margin shifted into
+//     the mask word with one v_alignbit_b32: 4 VALU instructions per (pixel, entry) where the former box test + fp32 prelude +
+//     error-bounded cull took ~40.  Survivors are recorded as a 256-bit mask of the pixel in LDS (s_mask[word][thread]).
 //   phase 2 (per-lane ordered consumption): every lane pops the next set bit of its own mask, reads
 //     that entry's record from LDS with a per-lane address and runs the exact path (fp64 t /
 //     min_value, exp, blend update).  Entries are consumed in ascending list order per pixel, so
@@ -25,8 +27,7 @@
 //  * tile-list entries are staged as whole 64-byte SplatRec lines (one aligned gather per entry,
 //    colour included; the reference re-reads colour from global memory per contributing pair,
 //    forward.cu:561).  LDS layout [4][256] float4: staging writes of 64 consecutive lanes are
-//    contiguous (conflict-free), phase-1 reads are wave-uniform broadcasts.  The LDS copy carries the
-//    entry's cull threshold next to view2gaussian (phase 1 reads 3 x 16 B).
+//    contiguous (conflict-free), phase-2 reads use a per-lane address.
 //  * per-wave exit by ballot(done), workgroup exit by __syncthreads_and(done) (forward.cu:475-477).
 //  * XCD-aware tile order (xcd_tile_id): neighbouring tiles, which gather the same records, run on
 //    the same XCD and share its L2.
@@ -56,9 +57,9 @@ __device__ unsigned long long g_fw_stats[8];
 #define STAT_ADD(i, v)
 #endif
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
 blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-              const float4* __restrict__ bbox, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+              const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
               uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles)
 {
@@ -79,22 +80,29 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
-    // LDS record: q0 = v0..v3, q1 = v4..v7, q2 = {v8, v9, cull threshold, w}, q3 = {r, g, b, -}
-    __shared__ float4 s_rec[4][TILE_PIX];
+    // LDS record of a staged entry, arranged as the operand PAIRS of the packed prelude (v = view2gaussian):
+    //   q0 = {v0, v1 | v1, v3}, q1 = {v2, v4 | v2, v6}, q2 = {v4, v7 | v5, v8}:  (n0, n1) = q0.xy rx + q0.zw ry + q1.xy,
+    //   (n2, BB/2) = q1.zw rx + q2.xy ry + q2.zw;   q3 = {v9 = CC, w, r, g}, s_blue = b
+    __shared__ f4 s_rec[4][TILE_PIX];
+    __shared__ float s_blue[TILE_PIX];
     __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
-    __shared__ float4 s_box[TILE_PIX];
+    // footprint conic, SoA: s_cf[c][entry], c = {m00, 2 m01, m11, 2 m02, 2 m12, m22}; read as float4 = one coefficient of 4 entries
+    __shared__ f4 s_cf[6][TILE_PIX / 4];
     uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    // pixel rectangle of this wave (tile_pixel: wave w covers the 8x8 quadrant (w & 1, w >> 1)), inclusive bounds
-    const float wave_x0 = (float)(tx * TILE_X + 8u * (wave & 1u)), wave_x1 = wave_x0 + 7.0f;
-    const float wave_y0 = (float)(ty * TILE_Y + 8u * (wave >> 1)), wave_y1 = wave_y0 + 7.0f;
+    // evaluation-error margin of the unit-normalised conic (sum |M_ij| = 1): 5 fp32 roundings of partial sums bounded by
+    // max(1, |r|^2), plus the fp32 rounding of the coefficients -> 3e-6 x that bound is > 4x what can occur
+    const f2 RX = { rx, rx }, RY = { ry, ry }, RXY = { rx, ry };
+    const float cone_margin = 3e-6f * fmaxf(1.0f, fmaxf(rx * rx, ry * ry));
+    const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
 
     bool done = !inside;
     float T = 1.0f;
     uint32_t last_contributor = 0, max_contributor = (uint32_t)-1;
-    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, Al = 0;
-    float dist1 = 0, dist2 = 0, distortion = 0;
+    // accumulators kept as the register pairs the packed updates work on (every element sees the reference's operation
+    // sequence: packed fp32 instructions are element-wise IEEE)
+    f2 C01 = { 0, 0 }, C2N2 = { 0, 0 }, N01 = { 0, 0 };      // colour 0,1 | colour 2, normal 2 | normal 0,1
+    f2 D12 = { 0, 0 }, DA = { 0, 0 };                        // dist1, dist2 | distortion, alpha
+    float Dp = 0;
 
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_and(done)) break;
@@ -103,10 +111,15 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const uint32_t id = point_list[k];
             const float4* src = reinterpret_cast<const float4*>(&rec[id]);
             const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-            s_rec[0][tid] = a; s_rec[1][tid] = b;
-            s_rec[2][tid] = make_float4(c.x, c.y, cull_log_threshold(c.z), c.z);
-            s_rec[3][tid] = make_float4(c.w, d.x, d.y, 0.f);
-            s_box[tid] = bbox[id];
+            s_rec[0][tid] = f4{ a.x, a.y, a.y, a.w };
+            s_rec[1][tid] = f4{ a.z, b.x, a.z, b.z };
+            s_rec[2][tid] = f4{ b.x, b.w, b.y, c.x };
+            s_rec[3][tid] = f4{ c.y, c.z, c.w, d.x };
+            s_blue[tid] = d.y;
+            const float4 m0 = fconic[2 * (size_t)id], m1 = fconic[2 * (size_t)id + 1];     // {m00, m01, m11, m02}, {m12, m22, ., .}
+            float* cf = reinterpret_cast<float*>(&s_cf[0][0]) + tid;
+            cf[0 * TILE_PIX] = m0.x; cf[1 * TILE_PIX] = 2.0f * m0.y; cf[2 * TILE_PIX] = m0.z;
+            cf[3 * TILE_PIX] = 2.0f * m0.w; cf[4 * TILE_PIX] = 2.0f * m1.x; cf[5 * TILE_PIX] = m1.y;
         }
         __syncthreads();
         const int nwords_batch = (min(TILE_PIX, toDo) + 31) >> 5;
@@ -126,36 +139,33 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
         const int nw = w0 + ((cn + 31) >> 5);
 
         // ---- phase 1: cull scan ----
-        // (a) lane = ENTRY: 64 entries at a time against the wave's 8x8 pixel rectangle -> a wave-uniform 64-bit mask of the
-        //     entries whose footprint box touches the wave at all (the others cost 1/64 instruction each instead of ~8);
-        // (b) lane = PIXEL, scalar loop over the set bits: the pixel's own box test, the fp32 prelude and the error-bounded cull.
-        for (int w = w0; w < nw; w += 2) {
-            const int je = w * 32 + (int)lane;
-            bool touch = false;
-            if (je < n) {
-                const float4 bx = s_box[je];
-                touch = (wave_x1 >= bx.x) & (wave_x0 <= bx.y) & (wave_y1 >= bx.z) & (wave_y0 <= bx.w);
+        // lane = PIXEL; per mask word 8 groups of 4 consecutive entries, highest first, so that shifting the sign bits in from
+        // the right leaves entry e of the word at bit e.  g = rx (m00 rx + 2 m01 ry + 2 m02) + ry (m11 ry + 2 m12) + m22 - margin;
+        // candidate <=> g <= 0 <=> sign bit (g = +0 has measure zero and lies 4x inside the margin's slack).  Unbounded /
+        // degenerate Gaussians carry all-zero coefficients: g = -margin, always a candidate.
+        for (int w = w0; w < nw; w++) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int g4 = 7; g4 >= 0; g4--) {
+                const int q = w * 8 + g4;
+                const f4 m00 = s_cf[0][q], m01 = s_cf[1][q], m11 = s_cf[2][q], m02 = s_cf[3][q], m12 = s_cf[4][q], m22 = s_cf[5][q];
+                const f2 a_lo = pk_fma(m00.xy, RX, pk_fma(m01.xy, RY, m02.xy));
+                const f2 a_hi = pk_fma(m00.zw, RX, pk_fma(m01.zw, RY, m02.zw));
+                const f2 b_lo = pk_fma(m11.xy, RY, m12.xy);
+                const f2 b_hi = pk_fma(m11.zw, RY, m12.zw);
+                const f2 g_lo = pk_fma(RX, a_lo, pk_fma(RY, b_lo, m22.xy + NEG_MARGIN));
+                const f2 g_hi = pk_fma(RX, a_hi, pk_fma(RY, b_hi, m22.zw + NEG_MARGIN));
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_hi.y), 31);
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_hi.x), 31);
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_lo.y), 31);
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_lo.x), 31);
             }
-            uint64_t m = __ballot(touch);
-            uint32_t word_lo = 0, word_hi = 0;
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1ull;
-                const int j = w * 32 + b;
-                const float4 bx = s_box[j];
-                const bool inbox = !done & (pxf >= bx.x) & (pxf <= bx.y) & (pyf >= bx.z) & (pyf <= bx.w);
-                if (__ballot(inbox) == 0ull) continue;          // only saturated pixels of the wave lie inside
-                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
-                const float v[10] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y };
-                PairEval p;
-                pair_prelude(v, rx, ry, p);
-                const uint32_t pass = (inbox && !pair_certainly_transparent(p, q2.y, q2.z)) ? 1u : 0u;
-                if (b < 32) word_lo |= pass << b; else word_hi |= pass << (b - 32);
-            }
-            s_mask[w][tid] = done ? 0u : word_lo;
-            if (w + 1 < nw) s_mask[w + 1][tid] = done ? 0u : word_hi;
-            if ((tid & 63) == 0) STAT_ADD(0, min(64, n - w * 32));
-            STAT_ADD(1, done ? 0 : __popc(word_lo) + __popc(word_hi));
+            const int valid = n - w * 32;                                    // entries of this word the list covers (>= 1)
+            if (valid < 32) word &= (1u << valid) - 1u;                      // the tail of the LDS batch holds stale entries
+            if (done) word = 0u;
+            s_mask[w][tid] = word;
+            if ((tid & 63) == 0) STAT_ADD(0, min(32, valid));
+            STAT_ADD(1, __popc(word));
         }
 
         // ---- phase 2: every lane consumes its own candidates in list order ----
@@ -175,11 +185,16 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const int j = w * 32 + b;
             const uint32_t contributor = base + (uint32_t)j + 1u;   // 1-based list position (forward.cu:497)
 
-            const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
-            const float v[10] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y };
+            // fp32 prelude (forward.cu:504-513) in the reference's operation order, two values per packed instruction
+            const f4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j];
+            const f2 n01 = (q0.xy * RX + q0.zw * RY) + q1.xy;               // normal[0], normal[1]
+            const f2 n2b = (q1.zw * RX + q2.xy * RY) + q2.zw;               // normal[2], BB / 2
+            const f2 rn = RXY * n01;
             PairEval p;
-            pair_prelude(v, rx, ry, p);
-            pair_exact(v, q2.w, p);
+            p.n0 = n01.x; p.n1 = n01.y; p.n2 = n2b.x;
+            p.AAf = (rn.x + rn.y) + n2b.x;
+            p.BBf = 2 * n2b.y;
+            pair_exact_cc(q3.x, q3.y, p);
             if (p.skip) continue;
             STAT_ADD(3, 1);
             const float alpha = p.alpha, t = p.t;
@@ -187,29 +202,29 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             if (test_T < 0.0001f) { done = true; continue; }
             STAT_ADD(4, 1);
 
-            const float4 q3 = s_rec[3][j];
             const float max_t = t;
             const float mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
             // unit normal -n / |n|: the reference takes an fp64 sqrt and three IEEE divisions (forward.cu:548-549);
             // here one v_rsq_f32 (<= 1 ulp).  Only the normal channels depend on it: they agree with the oracle to
             // ~3e-7 instead of bit for bit; every other output is unaffected.
-            const float inv_len = __builtin_amdgcn_rsqf(p.n0 * p.n0 + p.n1 * p.n1 + p.n2 * p.n2 + 1e-7f);
-            const float nn0 = -p.n0 * inv_len, nn1 = -p.n1 * inv_len, nn2 = -p.n2 * inv_len;
+            const f2 sq = n01 * n01;
+            const float inv_len = __builtin_amdgcn_rsqf((sq.x + sq.y) + p.n2 * p.n2 + 1e-7f);
+            const f2 NINV = { -inv_len, -inv_len };
+            const f2 nn01 = n01 * NINV;
+            const f2 bn2 = { s_blue[j], p.n2 * NINV.x };                    // colour 2 | unit normal 2
 
             const float A = 1 - T;
-            const float error = mapped_max_t * mapped_max_t * A + dist2 - 2 * mapped_max_t * dist1;
-            distortion += error * alpha * T;
-            dist1 += mapped_max_t * alpha * T;
-            dist2 += mapped_max_t * mapped_max_t * alpha * T;
-
-            C0 += q3.x * alpha * T;
-            C1 += q3.y * alpha * T;
-            C2 += q3.z * alpha * T;
-            N0 += nn0 * alpha * T;
-            N1 += nn1 * alpha * T;
-            N2 += nn2 * alpha * T;
+            const float mm = mapped_max_t * mapped_max_t;
+            const float error = mm * A + D12.y - 2 * mapped_max_t * D12.x;
+            const f2 ALPHA = { alpha, alpha }, TT = { T, T };
+            const f2 ea = { error * alpha, alpha };
+            DA += ea * TT;                                                  // distortion += error * alpha * T | alpha channel += alpha * T
+            const f2 m12 = { mapped_max_t, mm };
+            D12 += m12 * ALPHA * TT;                                        // dist1 += m alpha T | dist2 += m m alpha T
+            C01 += q3.zw * ALPHA * TT;
+            C2N2 += bn2 * ALPHA * TT;
+            N01 += nn01 * ALPHA * TT;
             if (T > 0.5f) { Dp = t; max_contributor = contributor; }
-            Al += alpha * T;
             T = test_T;
             last_contributor = contributor;
             cbits |= 1u << b;
@@ -224,6 +239,8 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
 
     if (inside) {
         const size_t HW = (size_t)W * H;
+        const float dist1 = D12.x, dist2 = D12.y;
+        float distortion = DA.x;
         const float distortion_before_normalized = distortion;
         distortion = (float)((double)distortion / ((double)((1 - T) * (1 - T)) + 1e-7));
         final_T[pix_id] = T;
@@ -232,14 +249,14 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
         final_T[pix_id + 3 * HW] = distortion_before_normalized;
         n_contrib[pix_id] = last_contributor;
         n_contrib[pix_id + HW] = max_contributor;
-        out_color[0 * HW + pix_id] = C0 + T * bg_color[0];
-        out_color[1 * HW + pix_id] = C1 + T * bg_color[1];
-        out_color[2 * HW + pix_id] = C2 + T * bg_color[2];
-        out_color[3 * HW + pix_id] = N0;
-        out_color[4 * HW + pix_id] = N1;
-        out_color[5 * HW + pix_id] = N2;
+        out_color[0 * HW + pix_id] = C01.x + T * bg_color[0];
+        out_color[1 * HW + pix_id] = C01.y + T * bg_color[1];
+        out_color[2 * HW + pix_id] = C2N2.x + T * bg_color[2];
+        out_color[3 * HW + pix_id] = N01.x;
+        out_color[4 * HW + pix_id] = N01.y;
+        out_color[5 * HW + pix_id] = C2N2.y;
         out_color[6 * HW + pix_id] = Dp;
-        out_color[7 * HW + pix_id] = Al;
+        out_color[7 * HW + pix_id] = DA.y;
         out_color[8 * HW + pix_id] = distortion;
     }
 }

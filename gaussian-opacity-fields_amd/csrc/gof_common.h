@@ -109,20 +109,22 @@ struct ProfileScope {
 };
 #define GOF_PROFILE(name, stream) gof::ProfileScope _gof_prof_scope_##__LINE__(name, stream)
 
-// thread -> pixel map inside a 16x16 tile.  Each wave64 covers an 8x8 pixel quadrant (lane l -> x = l % 8,
-// y = l / 8): a compact footprint intersects fewer splats than the reference's 16x4 strip, and a 16-lane DPP
-// row is an 8x2 pixel block.  Per-pixel results do not depend on the map.
+// thread -> pixel map inside a 16x16 tile.  Each wave64 covers an 8x8 pixel quadrant and each 16-lane DPP row of it a 4x4
+// pixel block (lane l: row r = l / 16 -> block (r % 2, r / 2) of the quadrant, i = l % 16 -> pixel (i % 4, i / 4) of the block):
+// compact footprints meet the fewest splats -- the backward blend walks the contributor union of a ROW, the forward's wave
+// exit needs all pixels of the quadrant saturated.  Per-pixel results do not depend on the map.
 __device__ __forceinline__ void tile_pixel(uint32_t tid, uint32_t& lx, uint32_t& ly)
 {
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    lx = (lane & 7u) + 8u * (wave & 1u);
-    ly = (lane >> 3) + 8u * (wave >> 1);
+    const uint32_t wave = tid >> 6, row = (tid >> 4) & 3u, i = tid & 15u;
+    lx = (i & 3u) + 4u * (row & 1u) + 8u * (wave & 1u);
+    ly = (i >> 2) + 4u * (row >> 1) + 8u * (wave >> 1);
 }
 
 // inverse of tile_pixel: thread id of the pixel (lx, ly) of a tile
 __device__ __forceinline__ uint32_t tile_thread(uint32_t lx, uint32_t ly)
 {
-    return (((lx >> 3) + 2u * (ly >> 3)) << 6) + ((ly & 7u) << 3) + (lx & 7u);
+    const uint32_t wave = (lx >> 3) + 2u * (ly >> 3), row = ((lx >> 2) & 1u) + 2u * ((ly >> 2) & 1u);
+    return (wave << 6) + (row << 4) + ((ly & 3u) << 2) + (lx & 3u);
 }
 
 // Contributor masks: for every pixel of a tile one bit per tile-list position, set by blend_forward when that
@@ -166,6 +168,14 @@ __device__ __forceinline__ float gexpf(float x)
     y = y + 1.0f;
     return ldexpf(y, (int)n);
 }
+
+// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations per lane and instruction, the only way to the
+// vector unit's peak rate).  Written with vector types so the pairing is by construction, not left to the SLP vectoriser (which
+// is switched off for the library: its shuffles cost more than it gains).  Element-wise results are bit-identical to the scalar
+// operations; a + b * c is NOT fused unless pk_fma is written.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{ a.x + b.x, a.y + b.y, a.z + b.z }; }
@@ -291,6 +301,7 @@ struct PairEval {
     float n0, n1, n2;      // un-normalised view-space normal Sigma' * ray
     float AAf, BBf;        // fp32 values the reference widens to double (forward.cu:511-512)
     double q;              // BB / AA (fp64, correctly rounded)
+    float qf;              // the same quotient in fp32 (backward)
     float t, G, alpha;
     bool skip;
 };
@@ -326,7 +337,11 @@ __device__ __forceinline__ float cull_log_threshold(float w)
 // HW_EXP: exp through v_exp_f32 (<= 1 ulp) instead of the shared deterministic gexpf -- only where alpha is NOT compared with a
 // threshold (the backward: its contributors come from the forward's masks), never in the forward / integrate.
 template <bool HW_EXP = false>
-__device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w, PairEval& p)
+__device__ __forceinline__ void pair_exact_cc(float CC, float w, PairEval& p);
+template <bool HW_EXP = false>
+__device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w, PairEval& p) { pair_exact_cc<HW_EXP>(v[9], w, p); }
+template <bool HW_EXP>
+__device__ __forceinline__ void pair_exact_cc(float CC, float w, PairEval& p)
 {
     const double AA = (double)p.AAf, BB = (double)p.BBf;
     // -BB/(2*AA) == -(BB/AA)/2 exactly (power-of-two scaling commutes with rounding), so one
@@ -335,7 +350,7 @@ __device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w,
     p.q = q;
     p.t = (float)(-q * 0.5);
     p.skip = ((double)p.t <= GOF_NEAR_PLANE);
-    const double min_value = (-q) * (BB * 0.25) + (double)v[9];
+    const double min_value = (-q) * (BB * 0.25) + (double)CC;
     float power = (float)(-0.5 * min_value);
     if (power > 0.0f) power = 0.0f;
     p.G = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gexpf(power);
@@ -346,7 +361,7 @@ __device__ __forceinline__ void pair_exact(const float* __restrict__ v, float w,
 // pair (reciprocal + FMA remainders), the product with BB/4 with its FMA error term, and the cancelling difference CC - product
 // taken hi first (exact by Sterbenz for the pairs that matter: min_value << CC).  min_value carries ~1e-6 absolute error -- the
 // fp64 path's value to ~5e-7 relative in G -- for 13 fp32 instructions instead of ~23 fp64 ones (incl. a quarter-rate division).
-__device__ __forceinline__ void pair_exact_backward(const float* __restrict__ v, float w, PairEval& p)
+__device__ __forceinline__ void pair_exact_backward_cc(float CC, float w, PairEval& p)
 {
     const float ra = __builtin_amdgcn_rcpf(p.AAf);
     float qh = p.BBf * ra;
@@ -355,8 +370,8 @@ __device__ __forceinline__ void pair_exact_backward(const float* __restrict__ v,
     const float b4 = p.BBf * 0.25f;
     const float ph = qh * b4;
     const float pl = fmaf(ql, b4, fmaf(qh, b4, -ph));            // (qh + ql) * b4 = ph + pl
-    const float min_value = (v[9] - ph) - pl;
-    p.q = (double)qh;
+    const float min_value = (CC - ph) - pl;
+    p.qf = qh;
     p.t = -0.5f * qh;
     float power = -0.5f * min_value;
     if (power > 0.0f) power = 0.0f;

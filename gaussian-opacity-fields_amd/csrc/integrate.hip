@@ -21,8 +21,11 @@
 // channel 8 = number of points per pixel INCLUDING the re-count of the tile's last point that
 // the reference's outer while-loop performs when another pixel of the tile holds more than 256
 // points (:1025-1096, see oracle/gof_oracle_integrate.inc).
-// Documented deviation: contributor ids are not truncated to uint16 (:983); identical as long as
-// a tile list has at most 65535 entries.
+// The reference keeps the contributor positions of a pixel as uint16 (:879, 983) and its second pass re-finds them by comparing
+// the running 32-bit list position with the truncated value (:1145): for tile lists longer than 65535 entries a contributor at
+// position c > 65535 makes the second pass evaluate the entry at position c mod 65536 instead (if that lies behind the last
+// matched position; otherwise matching stops for good).  Reproduced: the masks handed to the point pass are the positions the
+// reference's second pass VISITS (visit_bit below) -- identical to the contributor positions for lists of up to 65535 entries.
 //
 // Two launches: integrate_pixels (phase A; depends on the Gaussians and the camera only -- writes the contributor
 // masks into the binning workspace, layout of cmask_base, and the pixel channels 0-2, 6, 7) and integrate_points
@@ -85,6 +88,8 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
     float cT[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
     float C0 = 0, C1 = 0, C2 = 0, Cdepth = 0, Calpha = 0;
     uint32_t contributor = 0, last_contributor = 0, n_local = 0;
+    uint32_t last_matched = 0;      // uint16 emulation (forward.cu:983, 1145): list position of the second pass's last match,
+    bool match_stuck = false;       // and whether a truncated id fell behind it (nothing matches any more)
     bool done = !inside;
 
     for (int b = 0; b < nbatches; b++, toDo -= TILE_PIX) {
@@ -185,7 +190,17 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                 }
                 if (used) {
                     last_contributor = contributor;
-                    word |= 1u << bit;
+                    if (contributor <= 0xFFFFu) {                 // stored exactly: the second pass finds it where it is
+                        word |= 1u << bit;
+                        last_matched = contributor;
+                    } else if (!match_stuck) {                    // stored mod 2^16: matched at THAT position, if still ahead
+                        const uint32_t c16 = contributor & 0xFFFFu;
+                        if (c16 > last_matched) {
+                            last_matched = c16;
+                            uint32_t* vw = cm_tile + (size_t)((c16 - 1u) >> 5) * TILE_PIX + tid;   // this thread's own word of an earlier batch
+                            *vw |= 1u << ((c16 - 1u) & 31u);
+                        } else match_stuck = true;
+                    }
                     n_local += 1;
                     if (n_local >= (uint32_t)MAX_NUM_CONTRIBUTORS * 4) done = true;
                 }

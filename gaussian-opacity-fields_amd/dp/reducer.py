@@ -208,7 +208,10 @@ class GradientAllReducer:
                 if self.average:
                     bucket.div_(world)
             return finish
-        grads = [p.grad.reshape(-1) for p in ps]
+        for p in ps:                                 # a non-contiguous gradient would be COPIED by reshape(-1) and the reduced values lost
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+        grads = [p.grad.view(-1) for p in ps]
         n = sum(g.numel() for g in grads)
         flat = self._ensure(n, grads[0].device, grads[0].dtype)
         views = list(torch.split(flat, [g.numel() for g in grads]))

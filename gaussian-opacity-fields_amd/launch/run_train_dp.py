@@ -16,13 +16,48 @@ Injection points; NEW behaviour, the reference has no multi-GPU
   * gaussian_model.py:685-707          -> densify_and_prune first all-reduces the statistics accumulated since the last
                                           densification (SUM for the accumulators / denom, MAX for max_radii2D / abs-max)
   * train.py:247-250,276-301           -> only rank 0 writes point clouds / checkpoints / TensorBoard
+  * train.py:108-110, 157-159          -> --use_decoupled_appearance: train.py numbers the cameras it holds (camera.idx) and indexes the
+                                          per-camera appearance embedding with that number; here every camera carries its index in
+                                          the FULL (unsharded) train + test list, so all ranks address the same embedding rows and
+                                          the all-reduced embedding / network gradients mean the same thing everywhere
 Identical seeds on every rank (train.py:367-369) keep densify_and_split's sampling identical.
+
+Semantics of one optimiser step with N ranks: N views are rendered (one per rank), their parameter gradients
+are SUMMED (GOF_DP_AVERAGE=1: averaged -- Adam's update is invariant to the scale up to its eps = 1e-15, so the two differ only in
+what a logged gradient norm means) and every rank applies the identical Adam step.  `--iterations` keeps counting optimiser steps:
+a run of I steps consumes N x I views.  The iteration-indexed schedules of train.py (densification window and interval, opacity
+reset, regulariser start, position-LR decay length, test / save / checkpoint iterations) are NOT rescaled by default;
+`--gof_views_per_step_schedule` divides every one of them by N on the command line handed to train.py, so that the run sees the same
+number of VIEWS per schedule stage as the reference's single-GPU recipe (two things train.py hard-codes stay per step: the SH degree
+rises every 1000 steps, train.py:131, and the late 3D-filter refresh runs every 100 steps, train.py:266).  Every rank runs
+prepare_output_and_logger (identical cfg_args; TensorBoard, if present, logs rank-local losses) -- only rank 0 saves models.
+
+GOF_DP_SHARE_GPU=1 (development / single-GPU tests): all ranks use the visible GPU(s) round-robin and gloo carries the collectives.
 """
 import os
 import sys
 
 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)       # before importing torch: every rank sees its GPU as cuda:0
+SHARE_GPU = os.environ.get("GOF_DP_SHARE_GPU") == "1"
+
+
+def pick_visible_device(local_rank, env, share=False):
+    """The HIP_VISIBLE_DEVICES value for this rank (train.py:370 pins cuda:0, so every rank must see exactly its GPU as device 0).
+    A mask the user or scheduler already set (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES, e.g. "4,5,6,7") is
+    indexed, not overwritten."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        vis = [v for v in env.get(var, "").split(",") if v.strip() != ""]
+        if vis:
+            if share:
+                return vis[local_rank % len(vis)]
+            if local_rank >= len(vis):
+                raise RuntimeError("run_train_dp.py: local rank %d but %s=%s lists only %d device(s)" % (local_rank, var, env[var], len(vis)))
+            return vis[local_rank]
+    return "0" if share else str(local_rank)           # ROCR_VISIBLE_DEVICES (if set) re-numbers the devices HIP sees: index into that numbering
+
+
+os.environ["HIP_VISIBLE_DEVICES"] = pick_visible_device(local_rank, os.environ, SHARE_GPU)   # before importing torch
+os.environ.pop("CUDA_VISIBLE_DEVICES", None)              # one mask only: the two would be intersected
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, PKG)
@@ -35,17 +70,18 @@ def main():
     from dp.reducer import all_reduce_densification_stats
 
     script = os.path.abspath(sys.argv[1])
-    if "--use_decoupled_appearance" in sys.argv:
-        # train.py:109-110 numbers the cameras it holds (camera.idx) and indexes the appearance embeddings with that number; under
-        # view sharding every rank would number its own shard, so the all-reduced embedding gradients would mix different cameras
-        raise NotImplementedError("run_train_dp.py: --use_decoupled_appearance is not supported with view sharding (per-camera "
-                                  "embedding indices are assigned per rank by train.py:109-110)")
     sys.path.insert(0, os.path.dirname(script))
     sys.path.insert(0, PKG)
     sys.path.append(os.path.join(PKG, "shims"))
-    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    if SHARE_GPU:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     rank, world = dist.get_rank(), dist.get_world_size()
     dist.all_reduce(torch.zeros(1, device="cuda"))    # the communicator exists before a collective is issued from the autograd thread
+    if "--gof_views_per_step_schedule" in sys.argv:
+        sys.argv.remove("--gof_views_per_step_schedule")
+        sys.argv[2:] = scale_schedule_args(sys.argv[2:], world)
 
     import scene as ref_scene
     from scene.gaussian_model import GaussianModel
@@ -55,8 +91,17 @@ def main():
     shards = ViewShards(rank, world)
 
     def get_train_sharded(self, scale=1.0):
-        return shards.shard(_get_train(self, scale), scale)
+        cams = _get_train(self, scale)
+        if len(cams) < world:
+            # an empty shard would make train.py's randint(0, -1) raise on that rank only, with the others blocked in collectives
+            raise RuntimeError("run_train_dp.py: %d training camera(s) for %d ranks -- every rank needs at least one view" % (len(cams), world))
+        # camera.idx (train.py:108-110) = position in the FULL train + test list, whatever list train.py enumerates on this rank
+        for i, cam in enumerate(list(cams) + list(self.getTestCameras(scale))):
+            cam.__dict__["_gof_global_idx"] = i
+        return shards.shard(cams, scale)
     ref_scene.Scene.getTrainCameras = get_train_sharded
+    from scene.cameras import Camera
+    Camera.idx = property(lambda self: self.__dict__["_gof_global_idx"], lambda self, value: None)    # train.py's per-shard numbering is ignored
 
     # compute_3D_filter(cameras=trainCameras) (train.py:118,261,269) receives the shard; the filter depends on ALL training cameras
     # (per-point minimum depth over the cameras that see it, gaussian_model.py:262-311) and must be identical on every rank: map
@@ -73,7 +118,9 @@ def main():
         _setup(self, training_args)
 
         dense = os.environ.get("GOF_DP_DENSE_SH") == "1"
-        reducer = GradientAllReducer([], track=False)
+        reducer = GradientAllReducer([], track=False, average=os.environ.get("GOF_DP_AVERAGE") == "1")
+        check_every = int(os.environ.get("GOF_DP_CHECK_EVERY", "0"))      # replica-consistency check (debugging / tests): 0 = off
+        steps = [0]
 
         def pre_step(optimizer, args, kwargs):
             # the nn.Parameters are replaced by every densification (gaussian_model.py:532-607): collect them per step
@@ -82,6 +129,9 @@ def main():
             sh = [by_name[n] for n in ("f_dc", "f_rest") if n in by_name]      # gaussian_model.py:351-352
             reducer.sh_params = sh if (len(sh) == 2 and not dense) else []
             reducer.all_reduce()
+            steps[0] += 1
+            if check_every and steps[0] % check_every == 0:
+                check_replicas(optimizer, steps[0])
         self.optimizer.register_step_pre_hook(pre_step)
         if not dense:
             reducer.enable_sh_tracking()          # + the all-gather starts inside the rasterizer's backward
@@ -106,6 +156,73 @@ def main():
     import runpy
     sys.argv = [os.path.join(PKG, "launch", "run_reference_script.py"), script] + sys.argv[2:]
     runpy.run_path(sys.argv[0], run_name="__main__")
+
+
+def check_replicas(optimizer, step):
+    """Every rank must hold bit-identical parameters and (after the exchange) bit-identical gradients: compare order-independent
+    integer checksums of their bit patterns across ranks and name the first tensor that differs."""
+    import torch
+    import torch.distributed as dist
+    names, sums = [], []
+    for g in optimizer.param_groups:
+        for i, p in enumerate(g["params"]):
+            for kind, t in (("param", p), ("grad", p.grad)):
+                if t is None:
+                    continue
+                names.append("%s[%d].%s%s" % (g.get("name", "?"), i, kind, tuple(t.shape)))
+                sums.append(t.detach().contiguous().view(torch.int32).to(torch.int64).sum())
+    mine = torch.stack(sums + [torch.tensor(len(sums), device=sums[0].device)])
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        everyone = torch.empty((world,) + mine.shape, dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(everyone, mine)
+    else:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        everyone = torch.stack(parts)
+    everyone = everyone.cpu()
+    for r in range(1, world):
+        if not torch.equal(everyone[r], everyone[0]):
+            bad = [n for n, a, b in zip(names, everyone[0].tolist(), everyone[r].tolist()) if a != b]
+            raise RuntimeError("run_train_dp.py: replicas diverged at optimiser step %d: rank %d differs from rank 0 in %s" % (step, r, bad[:6] or "the tensor count"))
+
+
+SCHEDULE_OPTIONS = ("--iterations", "--position_lr_max_steps", "--densify_from_iter", "--densify_until_iter", "--densification_interval",
+                    "--opacity_reset_interval", "--distortion_from_iter", "--depth_normal_from_iter")
+SCHEDULE_LISTS = ("--test_iterations", "--save_iterations", "--checkpoint_iterations")
+SCHEDULE_DEFAULTS = {"--iterations": 30_000, "--position_lr_max_steps": 30_000, "--densify_from_iter": 500, "--densify_until_iter": 15_000,
+                     "--densification_interval": 100, "--opacity_reset_interval": 3000, "--distortion_from_iter": 15_000,
+                     "--depth_normal_from_iter": 15_000}      # arguments/__init__.py:79-101
+
+
+def scale_schedule_args(argv, world):
+    """Divide every iteration-indexed option of train.py by the number of views per step (options that are absent are added with
+    the reference's default divided the same way), so that a schedule stage lasts the same number of VIEWS as in the reference."""
+    argv = list(argv)
+    div = lambda v: max(1, int(round(int(v) / world)))     # noqa: E731
+    seen = set()
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a in SCHEDULE_OPTIONS and i + 1 < len(argv):
+            argv[i + 1] = str(div(argv[i + 1]))
+            seen.add(a)
+            i += 2
+        elif a in SCHEDULE_LISTS:
+            i += 1
+            while i < len(argv) and not argv[i].startswith("-"):
+                argv[i] = str(div(argv[i]))
+                i += 1
+        else:
+            i += 1
+    for a, v in SCHEDULE_DEFAULTS.items():
+        if a not in seen:
+            argv += [a, str(div(v))]
+    if not any(a in argv for a in ("--test_iterations",)):
+        argv += ["--test_iterations", str(div(7000)), str(div(30000))]
+    if "--save_iterations" not in argv:
+        argv += ["--save_iterations", str(div(7000)), str(div(30000))]
+    return argv
 
 
 if __name__ == "__main__":

@@ -331,6 +331,37 @@ def test_integrate_bit_exact_on_scene(name):
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
 
 
+def uint16_scene():
+    """ONE 16x16 tile with a ~78 000-entry list of sub-pixel splats of low opacity: a pixel collects its 1024 contributors (the
+    reference's cap) only around list positions 57 000 - 70 000, so for part of the pixels contributor positions exceed 65535 --
+    where the reference's uint16 `contributed_ids` wrap (forward.cu:879, 983) and its second pass evaluates the entries at
+    position mod 65536 instead (forward.cu:1145)."""
+    sc = S.scene_frustum(80_000, W=16, H=16, focal=16.0, seed=21, sigma_px=0.25, zmin=2.0, zmax=4.0)
+    sc["opacities"][:] = 0.03
+    return sc
+
+
+def test_integrate_reproduces_the_uint16_contributor_ids_of_lists_beyond_65535_entries():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = uint16_scene()
+    pts = np.ascontiguousarray(S.tetra_points(sc)[::40], dtype=np.float32)
+    o = ob.OracleScene(sc)
+    oc, oal, ocol, orad = o.integrate(pts)
+    last = o.fetch("n_contrib").reshape(2, 16, 16)[0]
+    assert o.num_rendered() > 70_000 and (last > 65535).sum() >= 20 and (last <= 65535).sum() >= 20     # both regimes present
+    sd = to_dev(sc)
+    r = GaussianRasterizer(settings_from(sd))
+    color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
+                                            opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), orad)
+    c = color.cpu().numpy()
+    assert np.array_equal(bits(c), bits(oc)), [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)]
+    a = alpha.cpu().numpy()
+    assert np.array_equal(bits(a), bits(oal)), (int((bits(a) != bits(oal)).sum()), np.abs(a - oal).max())
+    assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
+
+
 def test_fused_forward_matches_the_two_stage_forward_and_recovers_from_a_small_capacity():
     """gof_forward_fused (no mid-forward sync; binning workspace sized by a learnt capacity, device-side instance count):
     identical image / radii / state to the two-stage forward, gradients through the capacity-sized workspaces identical too,
