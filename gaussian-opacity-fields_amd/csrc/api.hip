@@ -765,6 +765,32 @@ __global__ void unpack_rec(int P, const SplatRec* __restrict__ rec, const float4
 }
 }
 
+// per tile: number of contributing (pixel, list entry) pairs = set bits of the contributor masks blend_forward left, over the
+// words the backward reads (positions below the tile's last contributor)
+__global__ void __launch_bounds__(256)
+count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ cmask,
+                         int W, int H, uint32_t gx, uint32_t ntiles, uint32_t* __restrict__ out)
+{
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    uint32_t lx, ly;
+    tile_pixel(tid, lx, ly);
+    const uint32_t px = (tile % gx) * TILE_X + lx, py = (tile / gx) * TILE_Y + ly;
+    const uint32_t last = (px < (uint32_t)W && py < (uint32_t)H) ? n_contrib[(size_t)W * py + px] : 0u;
+    __shared__ uint32_t s_max, s_sum;
+    if (tid == 0) { s_max = 0; s_sum = 0; }
+    __syncthreads();
+    atomicMax(&s_max, last);
+    __syncthreads();
+    const uint2 range = ranges[tile];
+    const uint32_t max_last = min(s_max, range.y - range.x);
+    const uint32_t* cm = cmask + cmask_base(range.x, tile) * TILE_PIX;
+    uint32_t c = 0;
+    for (uint32_t w = 0; w < (max_last + 31) / 32; w++) c += __popc(cm[(size_t)w * TILE_PIX + tid]);
+    atomicAdd(&s_sum, c);
+    __syncthreads();
+    if (tid == 0) out[tile] = s_sum;
+}
+
 extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uint32_t R, const void* geom_ws, const void* binning_ws,
                                    const void* image_ws, void* dst, size_t dst_bytes, void* stream_)
 {
@@ -792,6 +818,13 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
         if (R) hipLaunchKernelGGL(rebuild_keys, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, b.vals, g.depths, static_cast<uint64_t*>(dst));
         if (hipGetLastError() != hipSuccess) { set_error("rebuild_keys launch failed"); return GOF_E_DEVICE; }
         return (int64_t)R;
+    }
+    else if (n == "contrib_pairs" && binning_ws && image_ws) {
+        if (dst_bytes < (size_t)d.ntiles * 4) { set_error("dst too small"); return GOF_E_INVALID; }
+        hipLaunchKernelGGL(count_contributing_pairs, dim3(d.ntiles), dim3(256), 0, stream, im.ranges, im.n_contrib, b.cmask, a->W, a->H, d.gx, d.ntiles,
+                           static_cast<uint32_t*>(dst));
+        if (hipGetLastError() != hipSuccess) { set_error("count_contributing_pairs launch failed"); return GOF_E_DEVICE; }
+        return (int64_t)d.ntiles;
     }
     else if (n == "ranges" && image_ws) { src = im.ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
     else if (n == "point_ranges" && image_ws) { src = im.point_ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }

@@ -6,15 +6,17 @@
 // MI355X design:
 //  * The reference issues 17 global fp32 atomicAdd per contributing (pixel, splat) pair
 //    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave (an 8x8 pixel quadrant) look at the SAME splat
-//    at the same time, so the 17 partial gradients are reduced in three levels:
-//      1. in registers, per 16-lane row (= 8x2 pixels): a TRANSPOSED (butterfly) reduction of 16 of the values -- the
-//         two quad exchange steps halve the number of live values, two row rotations finish -- plus a plain 4-step
-//         DPP sum of the 17th (row_sum16_transposed / row_sum);
-//      2. lanes 0..3 of every row that contributed add their 4 sums each (and lane 15 the 17th) into a per-batch LDS
-//         accumulator s_acc[17][BATCH] with ds_add_f32: 5 LDS instructions per splat instead of 17;
-//      3. after the batch, thread j flushes entry j with ONE global atomic per component and only if
-//         some pixel of the tile contributed: <= 17 atomics per (tile, splat) instead of up to
-//         17 x 256, issued 64 lanes wide.
+//    at the same time, and the 17 partial gradients are summed IN REGISTERS over the whole wave:
+//      1. per 16-lane row a TRANSPOSED (butterfly) reduction of 16 of the values -- the two quad exchange steps halve the
+//         number of live values, two row rotations finish (row_sum16_transposed) -- plus a plain 4-step DPP sum of the 17th;
+//      2. across the four rows the butterfly continues with two ds_bpermute exchanges (4 -> 2 -> 1 live values), so that
+//         lane (row r, l & 3) ends up with the wave total of value 4r + (l & 3);
+//      3. ONE plain LDS store (16 active lanes) + one for the 17th value put the totals into the wave's own slab
+//         s_slab[wave][17][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
+//         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
+//         entry and wave kept the LDS busy ~70 % of the time);
+//      4. after the batch, thread j adds the slabs of the waves that visited entry j and issues ONE global atomic per
+//         component: <= 17 atomics per (tile, splat) instead of up to 17 x 256, 64 lanes wide.
 //  * Entries behind the last contributor of EVERY pixel of the tile are never staged: the
 //    traversal starts at max-over-tile(last_contributor) (the reference stages the full list and
 //    skips per pixel, backward.cu:763-765).
@@ -40,13 +42,13 @@
 namespace gof {
 
 constexpr int NGRAD = 17;   // colour 3, mean2D 3, opacity 1, view2gaussian 10
-// tile-list entries staged per batch.  128 (not 256) keeps the LDS footprint at ~21 KB so that
-// occupancy is bounded by registers (4 waves/SIMD), not by LDS.
+// tile-list entries staged per batch.  64 keeps the LDS footprint (records 6 KB, masks 2 KB, four per-wave slabs 17 KB) at
+// 26 KB, so that occupancy is bounded by registers (5 waves/SIMD), not by LDS.
 #ifndef GOF_BW_BATCH
-#define GOF_BW_BATCH 128
+#define GOF_BW_BATCH 64
 #endif
 constexpr int BATCH = GOF_BW_BATCH;
-static_assert(BATCH == 128 || BATCH == 256, "BATCH must be 128 or 256");
+static_assert(BATCH == 64 || BATCH == 128, "BATCH must be 64 or 128");
 
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] wave iterations of the entry loop, [1] (row, iteration) pairs with
@@ -109,14 +111,21 @@ __device__ __forceinline__ uint32_t row_or(uint32_t v)
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);    // row_half_mirror
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);    // row_mirror
-#ifdef GOF_BW_WAVEWALK                                      // A/B: all four rows of the wave walk the union of the whole wave
-    v |= (uint32_t)__shfl_xor((int)v, 16);
-    v |= (uint32_t)__shfl_xor((int)v, 32);
-#endif
     return v;
 }
+// OR over the wave as a wave-uniform (scalar) value
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v = row_or(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ float lane_xor(float v, uint32_t lane, uint32_t mask)   // value of lane (lane ^ mask), through the LDS crossbar (no memory access)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane ^ mask) << 2), __float_as_int(v)));
+}
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -148,8 +157,8 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     //   q3 = {CC, w | r, g}, q4 = {b, - | mean2D.x, mean2D.y}, q5 = {conic.x, conic.z | conic.y, conic.y}
     __shared__ f4 s_rec[6][BATCH];
     __shared__ uint32_t s_id[BATCH];
-    __shared__ float s_acc[NGRAD][BATCH];
-    __shared__ uint32_t s_touched[BATCH];
+    __shared__ float s_slab[4][NGRAD][BATCH];          // per wave: the wave totals of the entries it visited in this batch
+    __shared__ uint32_t s_vis[4][BATCH / 32];           // per wave: which entries those are
     __shared__ uint32_t s_cm[BATCH / 32][TILE_PIX];
     __shared__ uint32_t s_max_last;
 
@@ -222,30 +231,24 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
 #pragma unroll
             for (int q = 0; q < BATCH / 32; q++)
                 s_cm[q][tid] = (q < nw) ? cm_tile[((size_t)(p0 >> 5) + q) * TILE_PIX + tid] : 0u;
-            for (int k = tid; k < NGRAD * BATCH; k += TILE_PIX) (&s_acc[0][0])[k] = 0.f;
-            if (tid < BATCH) s_touched[tid] = 0;
         }
         __syncthreads();
         if (tid == 0) BSTAT_ADD(4, n);
 
-        // Every 16-lane ROW (a 4x4 pixel block, tile_pixel) walks the union of ITS pixels' contributors on its own: the loop
-        // below runs max-over-rows(|row union|) times per batch instead of |wave union| times, and the lanes of a row stay in
-        // lock step on one entry, which is what the in-row reduction needs.  roww = bits of mask word w some pixel of the row
-        // still has to visit (row-uniform); the highest bit is the next entry (back to front).
-        int w = ((n + 31) >> 5) - 1;
-        uint32_t word = s_cm[w][tid];
-        uint32_t roww = row_or(word);
-        for (;;) {
-            if (__ballot(roww != 0u || w > 0) == 0ull) break;
-            const bool row_active = roww != 0u;                      // a row that is between words idles through this iteration
-            if (lane == 0) BSTAT_ADD(0, 1);
-            if ((lane & 15u) == 0u && row_active) BSTAT_ADD(1, 1);
-            {
-                const int b = 31 - __builtin_clz(roww | 1u);
-                const bool contrib = row_active && ((word >> b) & 1u);
-                roww &= ~(1u << b);
+        // The wave walks the union of its pixels' contributors back to front (wave-uniform entry index: scalar bit walk over
+        // the OR of the 64 mask words, LDS reads of the record are broadcasts).
+        const uint32_t wave = tid >> 6;
+        for (int w = ((n + 31) >> 5) - 1; w >= 0; w--) {
+            const uint32_t word = s_cm[w][tid];
+            uint32_t todo = wave_or(word);
+            uint32_t visited = todo;
+            while (todo) {
+                const int b = 31 - __builtin_clz(todo);
+                todo &= ~(1u << b);
+                const bool contrib = (word >> b) & 1u;
                 const int j = w * 32 + b;
                 const uint32_t contributor = p0 + (uint32_t)j;       // 0-based list position (backward.cu:763)
+                if (lane == 0) BSTAT_ADD(0, 1);
 
                 float g[NGRAD];
 #pragma unroll
@@ -354,42 +357,48 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     g[16] = dL_dmin_value;
                     }
                 }
-                // in-row reduction (16 lanes = the 4x4 pixel block): 16 values transposed, the 17th plainly; lanes 0..3 / lane 15
-                // of the row add the sums into the batch accumulator of the row's entry
+                // wave total of the 17 values: in-row butterfly, then the butterfly continues across the rows (4 -> 2 -> 1 live values)
                 float w4[4];
                 row_sum16_transposed(g, (lane & 1u) != 0u, (lane & 2u) != 0u, w4);
-                const float g16 = row_sum(g[16]);
-                if ((lane & 12u) == 0u && row_active) {             // lanes 0..3 of the row: values 4m + (lane & 3)
-                    float* dst = &s_acc[lane & 3u][j];
-#pragma unroll
-                    for (int m = 0; m < 4; m++) unsafeAtomicAdd(dst + (size_t)m * 4 * BATCH, w4[m]);
-                }
-                if ((lane & 15u) == 15u && row_active) {
-                    unsafeAtomicAdd(&s_acc[16][j], g16);
-                    s_touched[j] = 1u;
+                float g16 = row_sum(g[16]);
+                {
+                    const bool r0 = (lane & 16u) != 0u, r1 = (lane & 32u) != 0u;
+                    const float k0 = r0 ? w4[1] : w4[0], s0 = r0 ? w4[0] : w4[1];
+                    const float k1 = r0 ? w4[3] : w4[2], s1 = r0 ? w4[2] : w4[3];
+                    const float u0 = k0 + lane_xor(s0, lane, 16u);           // rows (0,1), (2,3): value m = (r & 1)      of w4[0..1]
+                    const float u1 = k1 + lane_xor(s1, lane, 16u);           //                    value m = 2 + (r & 1)  of w4[2..3]
+                    const float k = r1 ? u1 : u0, sn = r1 ? u0 : u1;
+                    const float tot = k + lane_xor(sn, lane, 32u);           // row r holds the wave total of value 4 * m(r) + (lane & 3), m(r) = 2 (r >> 1) + (r & 1) = r
+                    g16 = g16 + lane_xor(g16, lane, 16u);
+                    g16 = g16 + lane_xor(g16, lane, 32u);
+                    if ((lane & 12u) == 0u) s_slab[wave][4u * (lane >> 4) + (lane & 3u)][j] = tot;
+                    if (lane == 63u) s_slab[wave][16][j] = g16;
                 }
             }
-            if (roww == 0u && w > 0) {                              // this row's word is used up: fetch the next (row-uniform)
-                w--;
-                word = s_cm[w][tid];
-                roww = row_or(word);
-                if ((lane & 15u) == 0u) BSTAT_ADD(3, 1);
-            }
+            if (lane == 0) s_vis[wave][w] = visited;
         }
         __syncthreads();
-        // flush: one entry per thread, one global atomic per component, 64 lanes wide
-        if ((int)tid < n && s_touched[tid]) {
-            const size_t id = s_id[tid];
-            unsafeAtomicAdd(&dL_dcolors[id * 3 + 0], s_acc[0][tid]);
-            unsafeAtomicAdd(&dL_dcolors[id * 3 + 1], s_acc[1][tid]);
-            unsafeAtomicAdd(&dL_dcolors[id * 3 + 2], s_acc[2][tid]);
-            unsafeAtomicAdd(&dL_dmean2D[id * 3 + 0], s_acc[3][tid]);
-            unsafeAtomicAdd(&dL_dmean2D[id * 3 + 1], s_acc[4][tid]);
-            unsafeAtomicAdd(&dL_dmean2D[id * 3 + 2], s_acc[5][tid]);
-            unsafeAtomicAdd(&dL_dopacity[id], s_acc[6][tid]);
-            float* gv = dL_dv2g + id * 10;
+        // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, then one global atomic
+        // per component, 64 lanes wide
+        if ((int)tid < n) {
+            const uint32_t qw = tid >> 5, qb = 1u << (tid & 31u);
+            const bool v0 = (s_vis[0][qw] & qb) != 0u, v1 = (s_vis[1][qw] & qb) != 0u, v2 = (s_vis[2][qw] & qb) != 0u, v3 = (s_vis[3][qw] & qb) != 0u;
+            if (v0 | v1 | v2 | v3) {
+                const size_t id = s_id[tid];
+                float* const dst[4] = { dL_dcolors + id * 3, dL_dmean2D + id * 3, dL_dopacity + id, dL_dv2g + id * 10 };
+                constexpr int first[5] = { 0, 3, 6, 7, 17 };
 #pragma unroll
-            for (int k = 0; k < 10; k++) unsafeAtomicAdd(gv + k, s_acc[7 + k][tid]);
+                for (int grp = 0; grp < 4; grp++) {
+#pragma unroll
+                    for (int k = first[grp]; k < first[grp + 1]; k++) {
+                        float a = v0 ? s_slab[0][k][tid] : 0.f;
+                        a += v1 ? s_slab[1][k][tid] : 0.f;
+                        a += v2 ? s_slab[2][k][tid] : 0.f;
+                        a += v3 ? s_slab[3][k][tid] : 0.f;
+                        unsafeAtomicAdd(dst[grp] + (k - first[grp]), a);
+                    }
+                }
+            }
         }
     }
 }

@@ -107,7 +107,10 @@ def main():
     # (per-point minimum depth over the cameras that see it, gaussian_model.py:262-311) and must be identical on every rank: map
     # the shard back to the full list -- every rank holds all camera poses, no communication needed.
     full_camera_list = shards.full
-    import train_epilogue.filter_3d as _f3d
+    import importlib
+    # (not `import train_epilogue.filter_3d as m`: the package re-exports a FUNCTION of that name, which such an import would bind)
+    _f3d = importlib.import_module("train_epilogue.filter_3d")
+    assert hasattr(_f3d, "compute_3D_filter") and hasattr(_f3d, "CAMERA_LIST_HOOK")
     _f3d.CAMERA_LIST_HOOK = full_camera_list
     _ref_filter = GaussianModel.compute_3D_filter          # effective with GOF_TORCH_EPILOGUE=1 (the reference's own method stays)
     GaussianModel.compute_3D_filter = lambda self, cameras: _ref_filter(self, full_camera_list(cameras))
@@ -131,7 +134,7 @@ def main():
             reducer.all_reduce()
             steps[0] += 1
             if check_every and steps[0] % check_every == 0:
-                check_replicas(optimizer, steps[0])
+                check_replicas(optimizer, steps[0], {"filter_3D": getattr(self, "filter_3D", None)})
         self.optimizer.register_step_pre_hook(pre_step)
         if not dense:
             reducer.enable_sh_tracking()          # + the all-gather starts inside the rasterizer's backward
@@ -158,7 +161,7 @@ def main():
     runpy.run_path(sys.argv[0], run_name="__main__")
 
 
-def check_replicas(optimizer, step):
+def check_replicas(optimizer, step, extra=None):
     """Every rank must hold bit-identical parameters and (after the exchange) bit-identical gradients: compare order-independent
     integer checksums of their bit patterns across ranks and name the first tensor that differs."""
     import torch
@@ -171,6 +174,10 @@ def check_replicas(optimizer, step):
                     continue
                 names.append("%s[%d].%s%s" % (g.get("name", "?"), i, kind, tuple(t.shape)))
                 sums.append(t.detach().contiguous().view(torch.int32).to(torch.int64).sum())
+    for name, t in (extra or {}).items():            # replicated state outside the optimizer (the 3D filter)
+        if t is not None:
+            names.append("%s%s" % (name, tuple(t.shape)))
+            sums.append(t.detach().contiguous().view(torch.int32).to(torch.int64).sum())
     mine = torch.stack(sums + [torch.tensor(len(sums), device=sums[0].device)])
     world = dist.get_world_size()
     if dist.get_backend() == "nccl":

@@ -207,3 +207,21 @@ def test_gradient_allreduce_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_the_dp_launcher_installs_the_camera_list_hook_in_the_module_the_filter_reads():
+    """launch/run_train_dp.py must set CAMERA_LIST_HOOK in the MODULE train_epilogue.filter_3d -- the package re-exports a function
+    of the same name, so `import train_epilogue.filter_3d as m` binds that function and the assignment is silently lost (found by
+    the end-to-end 2-rank run: every rank computed the 3D filter from its own camera shard and the replicas drifted apart)."""
+    import importlib
+    import types
+    pkg = os.path.join(ROOT, "gaussian-opacity-fields_amd")
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    import train_epilogue
+    assert isinstance(train_epilogue.filter_3d, types.FunctionType)              # the shadowing that made the bug possible
+    mod = importlib.import_module("train_epilogue.filter_3d")
+    assert isinstance(mod, types.ModuleType) and train_epilogue.compute_3D_filter.__wrapped__.__globals__ is mod.__dict__
+    src = open(os.path.join(pkg, "launch", "run_train_dp.py")).read()
+    assert "import train_epilogue.filter_3d as" not in src.replace("(not `import train_epilogue.filter_3d as m`", "")
+    assert 'importlib.import_module("train_epilogue.filter_3d")' in src

@@ -13,8 +13,9 @@ launch/run_train_dp.py exactly as INTEGRATION.md tells a user to start them.
     epilogue): same PSNR after the first 100 iterations (no densification yet) within 0.3 dB, same final PSNR within 1.5 dB.
   * extract_mesh.py on the trained model (Delaunay by the scipy stand-in, opacity-field queries, HIP marching tetrahedra, the 8-step
     bisection): writes a non-empty mesh; with the per-view integrate cache disabled the mesh is byte-identical.
-  * 2-rank data-parallel training (run_train_dp.py, both ranks on this GPU, gloo): runs, both ranks finish, rank 0 saves a model of
-    the same size on which every parameter is finite, and the final PSNR is within 2.5 dB of the single-process run.
+  * 2-rank data-parallel training (run_train_dp.py, both ranks on this GPU, gloo): both ranks finish, the replicas stay
+    bit-identical throughout (parameters, reduced gradients, 3D filter: checked every 25 steps), both ranks report the same test
+    PSNR, rank 0 saves a finite model, and the final PSNR is within 2.5 dB of the single-process run.
 """
 import hashlib
 import os
@@ -164,11 +165,15 @@ def test_two_rank_data_parallel_training_on_one_gpu(scene, trained, tmp_path_fac
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(PKG, "launch", "run_train_dp.py"), os.path.join(REFPY, "train.py"), "-s", scene, "-m", model] + TRAIN_ARGS
-    out = _run(cmd, _env(GOF_DP_SHARE_GPU="1"), timeout=1500)
+    # GOF_DP_CHECK_EVERY: every 25 optimiser steps the launcher compares bit-pattern checksums of all parameters, their reduced
+    # gradients and the 3D filter across the ranks and fails the run on the first difference (replicas must stay identical)
+    out = _run(cmd, _env(GOF_DP_SHARE_GPU="1", GOF_DP_CHECK_EVERY="25"), timeout=1500)
     assert out.count("Training complete.") == 2
     ps = _psnr(out)
     single = _psnr(out_single)
     assert ps[ITERS] > ps[1] + 6.0 and abs(ps[ITERS] - single[ITERS]) < 2.5, (ps, single)
+    finals = re.findall(r"\[ITER %d\] Evaluating test: L1 \S+ PSNR (\S+)" % ITERS, out)
+    assert len(finals) == 2 and finals[0] == finals[1], finals            # identical replicas render identical test views
     v = _load_ply(os.path.join(model, "point_cloud", "iteration_%d" % ITERS, "point_cloud.ply"))["vertex"]
     for nme in ("x", "opacity", "scale_0", "f_dc_0"):
         assert np.isfinite(v[nme]).all(), nme
