@@ -23,6 +23,20 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 
+PMC_FILE = "r02_pmc_traffic_s1m.json"
+FLOP_PER_PAIR_FWD = 85       # forward.cu:504-575 per contributing pair
+FLOP_PER_PAIR_BWD = 190      # backward.cu:771-952 per contributing pair, incl. its 19 accumulating adds
+
+
+def kernel_sha16():
+    """Hash of the sources of the two blend kernels (+ the shared header): identifies what a committed PMC pass was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("blend_forward.hip", "blend_backward.hip", "gof_common.h"):
+        h.update(open(os.path.join(ROOT, "gaussian-opacity-fields_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,7 +48,8 @@ def parse():
     ap.add_argument("--kernel-size", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the full training-iteration leg (losses + Adam)")
-    ap.add_argument("--cpu-baseline-gaussians", type=int, default=100_000)
+    ap.add_argument("--cpu-baseline-gaussians", type=int, default=1_000_000, help="Gaussians of the cpu_baseline sample (default: the whole workload)")
+    ap.add_argument("--no-integrate", action="store_true", help="skip the opacity-field query leg (BASELINE config 5 shape)")
     return ap.parse_args()
 
 
@@ -185,6 +200,8 @@ def main():
                                        "the all-gather of the colour gradient starts inside the backward and overlaps preprocess_bwd"}
         if world == 1 and not args.no_full_loop:
             out["full_loop"] = full_loop(sd, dev, W, H)
+        if world == 1 and not args.no_integrate:
+            out["integrate"] = integrate_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, W, H, focal)
         print(json.dumps(out))
@@ -211,18 +228,22 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     r_visited_fwd = int(np.minimum(lens, tile_max_last + 1).sum())   # entries the forward has to look at
     p_visible = int((res["radii"] > 0).sum().item())
     tile_passes = (int(np.ceil(np.log2(max(2, gx * gy)))) + 1 + 7) // 8
-    alg_bytes = {                                                    # SURVEY.md 8(d) per-unit figures x units
+    pairs = int(fetch(res, "contrib_pairs").astype(np.int64).sum())   # contributing (pixel, list entry) pairs of this view
+    alg_bytes = {                                                    # SURVEY.md 8(d) per-unit figures x units, exactly as written there
         "preprocess_fwd": P * (236 + 119),
         "scan_tiles": 8 * P,
         "sort_gaussians_by_depth": 4 * 16 * P + 4 * P,               # 4 passes: 8 B read + 8 B written; one histogram read for all passes
         "emit_instances": 24 * P + 8 * R,
         "sort_instances_by_tile": tile_passes * (16 * R + 4 * R),     # per pass: 8 B read + 8 B written, + histogram read
         "tile_ranges": 8 * R + 8 * gx * gy,
-        "blend_forward": (72 + 32) * r_visited_fwd + 60 * N,            # records + footprint boxes read, contributor masks written, image state
-        "blend_backward": (72 + 32) * r_staged_bwd + 96 * N + 76 * p_visible,   # records + conics + masks read, pixel state/grads, accumulators
+        "blend_forward": 72 * r_visited_fwd + 60 * N,                # 8(d): 60 B state + 12 B colour per visited entry, 60 B per pixel
+        "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,   # 8(d): 72 B per staged entry, 60 + 36 B per pixel, accumulators once
         "preprocess_bwd": p_visible * (316 + 232),
         "backward_memsets": 4 * P * (3 + 3 + 1 + 3 + 6 + 48 + 3 + 4 + 10),
     }
+    # bytes this design moves on top of 8(d)'s list: the contributor masks (1 bit per pixel and visited entry = 32 B per entry),
+    # written by the forward, read by the backward, and the 32 B footprint conic per entry the forward's cull scan reads
+    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": 32 * r_staged_bwd}
     kernels = {}
     for name, rec in kernel_times.items():
         avg_ms = rec["total_ms"] / max(1, rec["calls"])
@@ -230,6 +251,8 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         if name in alg_bytes and avg_ms > 0:
             ent["alg_MB"] = round(alg_bytes[name] / 1e6, 2)
             ent["GBps"] = round(alg_bytes[name] / (avg_ms * 1e-3) / 1e9, 1)
+            if name in extra_bytes:
+                ent["design_extra_MB"] = round(extra_bytes[name] / 1e6, 2)
         kernels[name] = ent
     fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "blend_forward")
     fwd_ms = sum(kernels[k]["avg_ms"] for k in fwd_names if k in kernels)
@@ -238,23 +261,35 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     d = kernels[dom]
     achieved = d.get("GBps", 0.0)
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE): rocprofv3 cannot run
-    # inside this process, so the figure comes from the committed counter pass of the SAME workload (profiles/), or is null
-    traffic = None
-    valu_issue_frac = None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic_s1m.json")
-    if P == 1_000_000 and (W, H) == (1600, 1063) and os.path.exists(tfile):
-        pmc = json.load(open(tfile)).get(dom, {})
-        traffic = pmc.get("hbm_bytes_corrected")
-        valu_issue_frac = pmc.get("valu_issue_frac")
+    # inside this process, so the figure is READ FROM the committed counter pass of the same workload (profiles/), labelled with
+    # its source and with the hash of the kernel sources it was collected on; null if that hash is not the current one
+    traffic = valu_issue_frac = pmc_source = None
+    pmc_file = os.path.join(ROOT, "profiles", PMC_FILE)
+    if P == 1_000_000 and (W, H) == (1600, 1063) and os.path.exists(pmc_file):
+        pmc_all = json.load(open(pmc_file))
+        pmc_source = {"file": "profiles/" + PMC_FILE, "kernel_sha16": pmc_all.get("_kernel_sha16"), "current_kernel_sha16": kernel_sha16(),
+                      "collected_by": "rocprofv3 --pmc passes of tests/devtools/dev_pmc.py (separate FETCH_SIZE / WRITE_SIZE / SQ passes)"}
+        if pmc_all.get("_kernel_sha16") == kernel_sha16():
+            traffic = pmc_all.get(dom, {}).get("hbm_bytes_corrected")
+            valu_issue_frac = pmc_all.get(dom, {}).get("valu_issue_frac")
+    # what actually bounds the two blend kernels: vector-ALU work.  "Useful" flop per contributing pair = the arithmetic the
+    # reference's source spends on a contributing (pixel, Gaussian) pair (forward 85, backward 190; FMA = 2);
+    # peak = 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md)
+    valu = {}
+    for name, flop in (("blend_forward", FLOP_PER_PAIR_FWD), ("blend_backward", FLOP_PER_PAIR_BWD)):
+        if name in kernels and kernels[name]["avg_ms"] > 0:
+            tf = flop * pairs / (kernels[name]["avg_ms"] * 1e-3) / 1e12
+            valu[name] = {"bound": "valu", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                          "flop_per_pair": flop, "pairs": pairs, "avg_ms": kernels[name]["avg_ms"]}
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-            "avg_ms": d["avg_ms"], "alg_bytes": alg_bytes.get(dom),
-            # what actually bounds the blend kernels: VALU issue slots (committed PMC pass, profiles/): insts x 4 cycles / (SIMDs x cycles)
+            "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": pmc_source,
+            "avg_ms": d["avg_ms"], "alg_bytes": alg_bytes.get(dom), "design_extra_bytes": extra_bytes.get(dom),
             "valu_issue_frac": None if valu_issue_frac is None else round(valu_issue_frac, 3),
-            "note": "dominant kernel by time; the blend kernels are VALU/LDS-bound (SURVEY 8d), the figure is their HBM floor on "
-                    "algorithmic bytes; the HBM-bound stages are listed under 'kernels'",
+            "valu": valu,
+            "note": "dominant kernel by time on SURVEY 8(d)'s algorithmic bytes (its HBM floor); the two blend kernels are bound by "
+                    "vector-ALU issue, not by HBM -- their roofline is under 'valu'; the HBM-bound stages are listed under 'kernels'",
             "kernels": kernels,
-            "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd,
+            "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd, "contributing_pairs": pairs,
                          "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)}}
     return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": R, "roofline": roof}
 
@@ -370,6 +405,69 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
     return out
 
 
+def integrate_leg(dev, P=5_000_000, W=1600, H=1063):
+    """BASELINE config 5 shape -- the opacity-field level-set query of extract_mesh.py: 5M Gaussians (sigma_px 1.5), 9 query points per
+    Gaussian as GaussianModel.get_tetra_points builds them (45M points), one view at 1600x1063; the first call of a view (Gaussian
+    side + pixel pass + point pass) and a later call of the same view (per-view cache: point binning + point pass only -- the
+    pattern of the 8 bisection steps); then marching tetrahedra on a Freudenthal grid (CGAL Delaunay stand-in).  Per-kernel
+    durations from the library's HIP events; HBM figures on the algorithmic bytes of DESIGN.md section 3."""
+    import synthetic_scenes as S
+    import diff_gaussian_rasterization as DGR
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    sc = S.scene_frustum(P, W=W, H=H, seed=0, sigma_px=1.5)
+    pts = torch.from_numpy(S.tetra_points(sc)).to(dev)
+    sd = to_dev(sc, dev)
+    r = GaussianRasterizer(settings_from(sd))
+
+    def call():
+        with DGR.integrate_view_key(("bench", 0)):
+            return r.integrate(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"],
+                               scales=sd["scales"], rotations=sd["rotations"])
+    call()
+    torch.cuda.synchronize()
+    legs = {}
+    for name, clear in (("first_call_of_a_view", True), ("later_call_of_the_view", False)):
+        ts, reps = [], None
+        for _ in range(3):
+            if clear:
+                DGR.integrate_view_cache().clear()
+            B.profile_enable(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = call()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+            reps = B.profile_report()
+            B.profile_enable(False)
+        legs[name] = {"wall_ms": round(min(ts), 3), "kernels_ms": {k: round(v["total_ms"] / max(1, v["calls"]), 4) for k, v in reps.items()}}
+    n_in_view = int((out[1] != 1.0).sum().item())
+    DGR.integrate_view_cache().clear()
+    PN = int(pts.shape[0])
+    res = {"workload": "integrate: %d Gaussians, %d query points (9 per Gaussian), %dx%d, one view" % (P, PN, W, H),
+           "points_evaluated": n_in_view, "Mpoints_per_s_cached": round(PN / (legs["later_call_of_the_view"]["wall_ms"] * 1e-3) / 1e6, 1), **legs}
+    del pts, sd, out
+    # marching tetrahedra on a 6-tets-per-cube grid with a sphere-like field: 24.6M tets
+    import tetmesh
+    n = 160
+    verts, tets = S.freudenthal_tets(n, n, n)
+    v = torch.from_numpy(verts).to(dev)
+    t = torch.from_numpy(tets).to(dev)
+    c = (v / n - 0.5)
+    sdf = (c.norm(dim=1) - 0.35 + 0.03 * torch.sin(20 * c[:, 0]) * torch.cos(17 * c[:, 1]))[None]
+    scl = torch.ones((1, v.shape[0], 1), device=dev)
+    tetmesh.marching_tetrahedra(v[None], t, sdf, scl)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = tetmesh.marching_tetrahedra(v[None], t, sdf, scl)
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    res["marching_tetrahedra"] = {"tets": int(t.shape[0]), "vertices": int(v.shape[0]), "faces": int(m[2][0].shape[0]), "wall_ms": round(min(ts), 3)}
+    return res
+
+
 def cpu_baseline(args, W, H, focal):
     """Oracle (CPU restatement of the reference, OpenMP) on a bounded sample of the same workload."""
     import oracle_binding as ob
@@ -385,8 +483,8 @@ def cpu_baseline(args, W, H, focal):
     t2 = time.perf_counter()
     cores = int(ob.lib().gofref_num_threads())
     return {"value": round(1.0 / (t2 - t0), 4), "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": "oracle fwd+bwd on %d Gaussians (%.0f%% of the workload's count) at %dx%d, one iteration; fwd %.2fs bwd %.2fs"
-                      % (Pc, 100.0 * Pc / args.gaussians, W, H, t1 - t0, t2 - t1)}
+            "sample": "oracle (OpenMP CPU restatement of the reference) fwd+bwd on %d Gaussians (%.0f%% of the workload's count) at %dx%d, one "
+                      "iteration on the GPU box's host threads; fwd %.2fs bwd %.2fs" % (Pc, 100.0 * Pc / args.gaussians, W, H, t1 - t0, t2 - t1)}
 
 
 if __name__ == "__main__":

@@ -31,7 +31,23 @@ def sources():
 
 
 def headers():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "gof_hip.h")]
+    """Every header a translation unit may include: csrc/*.h and ALL of include/*.h (gof_train_hip.h / gof_knn_hip.h carry ABI structs)."""
+    inc = os.path.join(HERE, "..", "include")
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+
+
+def flags_stamp():
+    """The flag set is part of an object's identity: a stamp file in the object directory records it, a change rebuilds everything."""
+    import hashlib
+    stamp = os.path.join(OBJ, "flags.sha")
+    want = hashlib.sha256(" ".join([HIPCC] + FLAGS).encode()).hexdigest()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if have != want:
+        for f in os.listdir(OBJ):
+            if f.endswith(".o"):
+                os.remove(os.path.join(OBJ, f))
+        with open(stamp, "w") as fh:
+            fh.write(want)
 
 
 def needs(target, deps):
@@ -60,6 +76,7 @@ def build(force=False, verbose=False):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
+    flags_stamp()
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))

@@ -50,7 +50,8 @@ constexpr int FW_CHUNK = GOF_FW_CHUNK;
 
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] scanned wave-entries, [1] candidate
-// (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active
+// (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active,
+// [6] (GOF_CULL_AUDIT) pairs the exact path accepts that the cull scan had dropped
 __device__ unsigned long long g_fw_stats[8];
 #define STAT_ADD(i, v) atomicAdd(&g_fw_stats[i], (unsigned long long)(v))
 #else
@@ -85,6 +86,9 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     //   (n2, BB/2) = q1.zw rx + q2.xy ry + q2.zw;   q3 = {v9 = CC, w, r, g}, s_blue = b
     __shared__ f4 s_rec[4][TILE_PIX];
     __shared__ float s_blue[TILE_PIX];
+#ifdef GOF_CULL_AUDIT
+    __shared__ uint32_t s_cand[TILE_PIX / 32][TILE_PIX];
+#endif
     __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
     // footprint conic, SoA: s_cf[c][entry], c = {m00, 2 m01, m11, 2 m02, 2 m12, m22}; read as float4 = one coefficient of 4 entries
     __shared__ f4 s_cf[6][TILE_PIX / 4];
@@ -163,6 +167,12 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             const int valid = n - w * 32;                                    // entries of this word the list covers (>= 1)
             if (valid < 32) word &= (1u << valid) - 1u;                      // the tail of the LDS batch holds stale entries
             if (done) word = 0u;
+#ifdef GOF_CULL_AUDIT
+            // developer-only audit build (with GOF_STATS): the consumption below walks EVERY entry of the list, not only the scan's
+            // candidates, and counts the pairs the exact path accepts although the scan dropped them (stat [6], must stay 0)
+            s_cand[w][tid] = word;
+            word = done ? 0u : (valid < 32 ? (1u << valid) - 1u : 0xFFFFFFFFu);
+#endif
             s_mask[w][tid] = word;
             if ((tid & 63) == 0) STAT_ADD(0, min(32, valid));
             STAT_ADD(1, __popc(word));
@@ -197,6 +207,9 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
             pair_exact_cc(q3.x, q3.y, p);
             if (p.skip) continue;
             STAT_ADD(3, 1);
+#ifdef GOF_CULL_AUDIT
+            if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
+#endif
             const float alpha = p.alpha, t = p.t;
             const float test_T = T * (1 - alpha);
             if (test_T < 0.0001f) { done = true; continue; }

@@ -54,6 +54,17 @@ def _need_cuda_f32(t, what):
     return t.contiguous()
 
 
+def _same_device(*tensors):
+    """The device all operands live on (None entries skipped); a launch is enqueued on THAT device's current stream, so operands
+    spread over several GPUs are refused (the library has no hipSetDevice of its own)."""
+    ts = [t for t in tensors if t is not None]
+    dev = ts[0].device
+    for t in ts:
+        if t.device != dev:
+            raise RuntimeError("all operands must be on one ROCm device (got %s and %s)" % (dev, t.device))
+    return torch.cuda.device(dev)
+
+
 def window_taps(window_size=SSIM_WINDOW, sigma=1.5):
     """The 11 fp32 taps exactly as utils/loss_utils.py:22-24 builds them (python doubles -> fp32 tensor -> / fp32 sum)."""
     from math import exp
@@ -70,8 +81,9 @@ def ssim_forward(img1, img2, taps, want_grad):
     dmaps = torch.empty((3, planes, H, W), dtype=torch.float32, device=dev) if want_grad else None
     nb = lib.gof_ssim_scratch_bytes(planes, W, H)
     scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _check(lib.gof_ssim_forward(planes, W, H, img1.data_ptr(), img2.data_ptr(), taps, sums.data_ptr(),
-                                dmaps.data_ptr() if want_grad else None, scratch.data_ptr(), nb, _stream()))
+    with _same_device(img1, img2):
+        _check(lib.gof_ssim_forward(planes, W, H, img1.data_ptr(), img2.data_ptr(), taps, sums.data_ptr(),
+                                    dmaps.data_ptr() if want_grad else None, scratch.data_ptr(), nb, _stream()))
     return sums, dmaps
 
 
@@ -79,8 +91,9 @@ def ssim_backward(img1, img2, taps, dmaps, plane_scale):
     planes = dmaps.shape[1]
     H, W = int(img1.shape[-2]), int(img1.shape[-1])
     out = torch.empty_like(img1)
-    _check(lib.gof_ssim_backward(planes, W, H, img1.data_ptr(), img2.data_ptr(), taps, dmaps.data_ptr(),
-                                 plane_scale.data_ptr(), out.data_ptr(), _stream()))
+    with _same_device(img1, img2, dmaps, plane_scale):
+        _check(lib.gof_ssim_backward(planes, W, H, img1.data_ptr(), img2.data_ptr(), taps, dmaps.data_ptr(),
+                                     plane_scale.data_ptr(), out.data_ptr(), _stream()))
     return out
 
 
@@ -88,15 +101,17 @@ def depth_to_normal_forward(depth_hw, wvt, fx, fy):
     H, W = int(depth_hw.shape[0]), int(depth_hw.shape[1])
     normals = torch.empty((H, W, 3), dtype=torch.float32, device=depth_hw.device)
     points = torch.empty((H, W, 3), dtype=torch.float32, device=depth_hw.device)
-    _check(lib.gof_depth_to_normal(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, normals.data_ptr(), points.data_ptr(), _stream()))
+    with _same_device(depth_hw, wvt):
+        _check(lib.gof_depth_to_normal(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, normals.data_ptr(), points.data_ptr(), _stream()))
     return normals, points
 
 
 def depth_to_normal_backward(depth_hw, wvt, fx, fy, g_normals, g_points):
     H, W = int(depth_hw.shape[0]), int(depth_hw.shape[1])
     out = torch.empty((H, W), dtype=torch.float32, device=depth_hw.device)
-    _check(lib.gof_depth_to_normal_backward(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, g_normals.data_ptr(),
-                                            g_points.data_ptr() if g_points is not None else None, out.data_ptr(), _stream()))
+    with _same_device(depth_hw, wvt, g_normals, g_points):
+        _check(lib.gof_depth_to_normal_backward(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, g_normals.data_ptr(),
+                                                g_points.data_ptr() if g_points is not None else None, out.data_ptr(), _stream()))
     return out
 
 
@@ -105,13 +120,15 @@ def l1_forward(a, b):
     out = torch.empty(1, dtype=torch.float32, device=a.device)
     nb = lib.gof_l1_scratch_bytes(n)
     scratch = torch.empty(nb, dtype=torch.uint8, device=a.device)
-    _check(lib.gof_l1_forward(n, a.data_ptr(), b.data_ptr(), out.data_ptr(), scratch.data_ptr(), nb, _stream()))
+    with _same_device(a, b):
+        _check(lib.gof_l1_forward(n, a.data_ptr(), b.data_ptr(), out.data_ptr(), scratch.data_ptr(), nb, _stream()))
     return out.reshape(())
 
 
 def l1_backward(a, b, grad_out):
     out = torch.empty_like(a)
-    _check(lib.gof_l1_backward(a.numel(), a.data_ptr(), b.data_ptr(), grad_out.data_ptr(), out.data_ptr(), _stream()))
+    with _same_device(a, b, grad_out):
+        _check(lib.gof_l1_backward(a.numel(), a.data_ptr(), b.data_ptr(), grad_out.data_ptr(), out.data_ptr(), _stream()))
     return out
 
 
@@ -123,9 +140,10 @@ def train_loss(rendering, gt_image, taps, wvt, fx, fy, lambda_dssim, lambda_dept
     dL = torch.empty_like(rendering) if want_grad else None
     nb = lib.gof_train_loss_scratch_bytes(W, H)
     scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _check(lib.gof_train_loss(W, H, rendering.data_ptr(), gt_image.data_ptr(), taps, wvt.data_ptr(), fx, fy, float(lambda_dssim),
-                              float(lambda_depth_normal), float(lambda_distortion), terms.data_ptr(),
-                              dL.data_ptr() if want_grad else None, scratch.data_ptr(), nb, _stream()))
+    with _same_device(rendering, gt_image, wvt):
+        _check(lib.gof_train_loss(W, H, rendering.data_ptr(), gt_image.data_ptr(), taps, wvt.data_ptr(), fx, fy, float(lambda_dssim),
+                                  float(lambda_depth_normal), float(lambda_distortion), terms.data_ptr(),
+                                  dL.data_ptr() if want_grad else None, scratch.data_ptr(), nb, _stream()))
     return terms, dL
 
 
@@ -138,4 +156,5 @@ def adam_step(entries, beta1, beta2, eps):
             arr[k].param, arr[k].grad, arr[k].exp_avg, arr[k].exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
             arr[k].n = p.numel()
             arr[k].step_size, arr[k].bias_correction2_sqrt = step_size, bc2s
-        _check(lib.gof_adam_step(len(chunk), arr, beta1, beta2, eps, _stream()))
+        with _same_device(*[t for e in chunk for t in e[:4]]):
+            _check(lib.gof_adam_step(len(chunk), arr, beta1, beta2, eps, _stream()))

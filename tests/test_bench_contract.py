@@ -1,5 +1,6 @@
-"""CPU-only: the committed bench line of the round (profiles/r01_bench_s1m_v*.json, written by bench.py on the MI355X) carries
-every field of the driver's contract, and bench.py's argument defaults are the contract's."""
+"""CPU-only: the committed bench line of the round (profiles/rNN_bench_s1m_v*.json, written by bench.py on the MI355X) carries
+every field of the driver's contract, bench.py's argument defaults are the contract's, `--gpus N` really starts N ranks, and the
+committed PMC counter pass the bench line quotes was collected on the kernels as they are now."""
 import glob
 import json
 import os
@@ -9,8 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _latest():
-    files = glob.glob(os.path.join(ROOT, "profiles", "r01_bench_s1m_v*.json"))
-    return max(files, key=lambda f: int(re.search(r"_v(\d+)\.json$", f).group(1)))
+    files = glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_bench_s1m_v*.json"))
+    return max(files, key=lambda f: (int(re.search(r"r(\d+)_bench", f).group(1)), int(re.search(r"_v(\d+)\.json$", f).group(1))))
 
 
 def test_committed_bench_line_has_the_contract_fields():
@@ -28,6 +29,14 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["kernel"] == "blend_backward" and r["traffic"] is None or r["traffic"] > 0
+    if "r02" in os.path.basename(_latest()):              # round 2: the blend kernels' VALU roofline + where the PMC figures come from
+        for k in ("blend_forward", "blend_backward"):
+            v = r["valu"][k]
+            assert v["bound"] == "valu" and v["peak"] == 157.3 and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3
+            assert abs(v["achieved"] - v["flop_per_pair"] * v["pairs"] / (v["avg_ms"] * 1e-3) / 1e12) < 0.02 * v["achieved"]
+        assert r["traffic_source"]["file"].startswith("profiles/") and r["traffic_source"]["kernel_sha16"]
+        assert d["steps"] >= 100
+        assert "integrate" in d and d["integrate"]["later_call_of_the_view"]["wall_ms"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -39,5 +48,47 @@ def test_bench_defaults_are_single_gpu_and_quick():
     assert re.search(r'"--gpus", type=int, default=1\b', src)
     steps = int(re.search(r'"--steps", type=int, default=(\d+)', src).group(1))
     warm = int(re.search(r'"--warmup", type=int, default=(\d+)', src).group(1))
-    assert 1 <= warm < steps <= 100
+    assert 1 <= warm < steps and steps >= 100
     assert 'default=1_000_000' in src and 'default=1600' in src and 'default=1063' in src     # BASELINE.json's S1M configuration
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gof_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_gpus_n_without_a_launcher_spawns_n_ranks(monkeypatch):
+    """`python bench.py --gpus 8` (RANK unset) must not silently run one rank: it re-runs itself under torch.distributed.run."""
+    import subprocess
+    import sys
+    b = _bench_module()
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7"])
+    assert b.spawn_ranks(8) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "7"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_a_world_size_that_contradicts_gpus_is_refused():
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but the launcher started 1 rank" in (r.stderr + r.stdout)
+
+
+def test_the_committed_pmc_pass_was_collected_on_the_current_blend_kernels():
+    """bench.py quotes HBM traffic / VALU issue figures from profiles/<PMC_FILE> (rocprofv3 cannot run in-process); the file records
+    the hash of csrc/blend_*.hip + gof_common.h it was collected on.  A kernel edit without a fresh counter pass fails here."""
+    b = _bench_module()
+    f = os.path.join(ROOT, "profiles", b.PMC_FILE)
+    if not os.path.exists(f):
+        import pytest
+        pytest.skip("no round-2 PMC pass committed yet")
+    assert json.load(open(f))["_kernel_sha16"] == b.kernel_sha16()

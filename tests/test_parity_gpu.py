@@ -722,3 +722,27 @@ def test_full_size_properties_s1m():
     # idempotence: a second run gives the identical image
     res2 = product_forward_raw(to_dev(sc))
     assert torch.equal(res["color"], res2["color"])
+
+
+def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
+    """The forward's footprint-conic scan is a prefilter with an error allowance (csrc/preprocess.hip: footprint_bbox); bit-exactness
+    of the image already implies that it drops no CONTRIBUTING pair, this audit counts it directly and also covers pairs behind a
+    pixel's saturation point: an instrumented build of the same kernel (lib/libgof_hip_audit.so, built by __graft_entry__.build())
+    walks every list entry and counts the pairs the exact path accepts that the scan had not marked -- 0 on the full-size S1M
+    configuration (kernel_size 0 and 0.1), the cull stress scene, far sub-pixel splats and the rest of the scene table."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gaussian-opacity-fields_amd", "lib", "libgof_hip_audit.so")
+    assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
+    names = ["s1m", "s1m_ks01", "stress_box", "far_subpixel", "long_lists", "lego10k", "ragged", "mid100k", "small_ks01"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert [x["scene"] for x in rows] == names
+    for x in rows:
+        assert x["dropped_by_the_scan"] == 0 and x["accepted_pairs"] > 0, x
+    assert rows[0]["accepted_pairs"] > 100_000_000            # S1M: ~1.2e8 contributing pairs were examined
