@@ -64,7 +64,7 @@ __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* g
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
                                  const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
-                                 float* out_alpha_integrated, float* out_color_integrated, uint32_t gx, uint32_t ntiles);
+                                 float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, uint32_t gx, uint32_t ntiles);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
@@ -624,7 +624,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, im.point_ranges, b.vals, pb.vals, rec_ptr, zfront_ptr, zstride, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
-                       base_color, out_color, out_alpha_integrated, out_color_integrated, d.gx, d.ntiles);
+                       base_color, out_color, out_alpha_integrated, out_color_integrated, im.n_contrib, d.gx, d.ntiles);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }

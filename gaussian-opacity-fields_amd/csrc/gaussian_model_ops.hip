@@ -17,6 +17,9 @@
 #include "gof_common.h"
 
 namespace gof {
+size_t scan_tmp_words(size_t n);                 // radix.hip
+hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                           const uint32_t** total_dev_out, hipStream_t stream);
 
 constexpr int F3_CHUNK = 128;
 
@@ -191,6 +194,74 @@ act_rotation_bwd(int64_t P, const float4* __restrict__ rr, const float4* __restr
     }
 }
 
+
+// ---- densification (scene/gaussian_model.py:631-707): role of every Gaussian, ordered index lists, one-pass row gather ----------
+// role: 0 = stays, 1 = cloned (stays + one new Gaussian), 2 = split (leaves + two new Gaussians).  The selection is the
+// reference's: gradient condition `norm(grads) >= max_grad  or  norm(grads_abs) >= Q` (densify_and_clone :660-662; densify_and_split
+// :636-643 applies the same thresholds to the same values), clone where max(get_scaling) <= percent_dense * extent, split where it
+// is larger.  grads = xyz_gradient_accum / denom with NaN -> 0 (:686-690).  q_abs is a DEVICE scalar (the torch.quantile value).
+__global__ void __launch_bounds__(256)
+densify_roles_kernel(int64_t P, const float* __restrict__ accum, const float* __restrict__ accum_abs, const float* __restrict__ denom,
+                     const float* __restrict__ scale_max, float max_grad, const float* __restrict__ q_abs, float size_threshold,
+                     uint8_t* __restrict__ role, uint32_t* __restrict__ f_keep, uint32_t* __restrict__ f_clone, uint32_t* __restrict__ f_split)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float g = accum[i] / denom[i], ga = accum_abs[i] / denom[i];
+    if (g != g) g = 0.0f;
+    if (ga != ga) ga = 0.0f;
+    const bool sel = (sqrtf(g * g) >= max_grad) || (sqrtf(ga * ga) >= q_abs[0]);
+    const bool small = scale_max[i] <= size_threshold;
+    const uint8_t r = sel ? (small ? 1 : 2) : 0;
+    role[i] = r;
+    f_keep[i] = r != 2; f_clone[i] = r == 1; f_split[i] = r == 2;
+}
+// ordered index lists from the exclusive scans of the three flag arrays (in place: flags in, ranks in the same arrays)
+__global__ void __launch_bounds__(256)
+densify_lists_kernel(int64_t P, const uint8_t* __restrict__ role, const uint32_t* __restrict__ r_keep, const uint32_t* __restrict__ r_clone,
+                     const uint32_t* __restrict__ r_split, int32_t* __restrict__ keep_idx, int32_t* __restrict__ clone_idx, int32_t* __restrict__ split_idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint8_t r = role[i];
+    if (r != 2) keep_idx[r_keep[i]] = (int32_t)i;
+    if (r == 1) clone_idx[r_clone[i]] = (int32_t)i;
+    if (r == 2) split_idx[r_split[i]] = (int32_t)i;
+}
+// out[rank(i)] = src ? src[i] : i for the rows with keep[i] != 0 (rank = exclusive scan of keep)
+__global__ void __launch_bounds__(256)
+compact_rows_kernel(int64_t n, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ rank, const int32_t* __restrict__ src, int32_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    out[rank[i]] = src ? src[i] : (int32_t)i;
+}
+__global__ void __launch_bounds__(256)
+bytes_to_flags_kernel(int64_t n, const uint8_t* __restrict__ b, uint32_t* __restrict__ f)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) f[i] = b[i] != 0;
+}
+// out[r, :] = src[row[r], :] if row[r] >= 0, else extra[-row[r] - 1, :] (zeros when extra == nullptr).  One thread per float4 (or float).
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
+template <> __device__ __forceinline__ float4 zero_of<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <typename T>
+__global__ void __launch_bounds__(256)
+rows_gather_kernel(int64_t total, int32_t per_row, const int32_t* __restrict__ row, const T* __restrict__ src, const T* __restrict__ extra, T* __restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= total) return;
+    const int64_t r = k / per_row;
+    const int32_t c = (int32_t)(k - r * per_row);
+    const int32_t s = row[r];
+    T v;
+    if (s >= 0) v = src[(int64_t)s * per_row + c];
+    else if (extra) v = extra[(int64_t)(-s - 1) * per_row + c];
+    else v = zero_of<T>();
+    out[k] = v;
+}
+
 } // namespace gof
 
 using namespace gof;
@@ -228,6 +299,89 @@ int gof_compute_3d_filter(int64_t P, const float* xyz, int32_t num_cams, const f
         GOF_HIP_CHECK(hipStreamSynchronize(stream));
         *any_valid_host = (int32_t)flag;
     }
+    return GOF_OK;
+}
+
+
+size_t gof_densify_ws_bytes(int64_t n)
+{
+    const size_t m = (size_t)(n < 1 ? 1 : n);
+    return 256 + 3 * ((m * 4 + 255) & ~(size_t)255) + 3 * ((scan_tmp_words(m) * 4 + 255) & ~(size_t)255) + 256;
+}
+
+int gof_densify_select(int64_t P, const float* accum, const float* accum_abs, const float* denom, const float* scale_max, float max_grad,
+                       const float* q_abs_dev, float size_threshold, uint8_t* role, int32_t* keep_idx, int32_t* clone_idx, int32_t* split_idx,
+                       void* ws, size_t ws_bytes, int64_t* counts_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (counts_host) counts_host[0] = counts_host[1] = counts_host[2] = 0;
+    if (P < 0) { set_error("bad number of points"); return GOF_E_INVALID; }
+    if (P == 0) return GOF_OK;
+    if (P >= (int64_t)1 << 31) { set_error("more than 2^31 points"); return GOF_E_INVALID; }
+    if (!accum || !accum_abs || !denom || !scale_max || !q_abs_dev || !role || !keep_idx || !clone_idx || !split_idx || !ws || !counts_host) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    if (ws_bytes < gof_densify_ws_bytes(P)) { set_error("densify workspace too small"); return GOF_E_WORKSPACE; }
+    char* base = reinterpret_cast<char*>((reinterpret_cast<size_t>(ws) + 255) & ~(size_t)255);
+    const size_t fl = ((size_t)P * 4 + 255) & ~(size_t)255, st = (scan_tmp_words((size_t)P) * 4 + 255) & ~(size_t)255;
+    uint32_t* f[3]; uint32_t* t[3];
+    for (int k = 0; k < 3; k++) { f[k] = reinterpret_cast<uint32_t*>(base + k * fl); t[k] = reinterpret_cast<uint32_t*>(base + 3 * fl + k * st); }
+    const unsigned blocks = (unsigned)((P + 255) / 256);
+    GOF_PROFILE("densify_select", stream);
+    hipLaunchKernelGGL(densify_roles_kernel, dim3(blocks), dim3(256), 0, stream, P, accum, accum_abs, denom, scale_max, max_grad, q_abs_dev, size_threshold,
+                       role, f[0], f[1], f[2]);
+    const uint32_t* tot[3];
+    for (int k = 0; k < 3; k++) GOF_HIP_CHECK(device_scan_u32(f[k], nullptr, f[k], (size_t)P, false, t[k], &tot[k], stream));
+    hipLaunchKernelGGL(densify_lists_kernel, dim3(blocks), dim3(256), 0, stream, P, role, f[0], f[1], f[2], keep_idx, clone_idx, split_idx);
+    GOF_LAUNCH_CHECK(stream, 0);
+    uint32_t h[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3; k++) GOF_HIP_CHECK(hipMemcpyAsync(&h[k], tot[k], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int k = 0; k < 3; k++) counts_host[k] = h[k];
+    return GOF_OK;
+}
+
+int gof_compact_rows(int64_t n, const uint8_t* keep, const int32_t* src_rows, int32_t* out_rows, void* ws, size_t ws_bytes, int64_t* count_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (count_host) *count_host = 0;
+    if (n < 0 || n >= (int64_t)1 << 31) { set_error("bad row count"); return GOF_E_INVALID; }
+    if (n == 0) return GOF_OK;
+    if (!keep || !out_rows || !ws || !count_host) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    if (ws_bytes < gof_densify_ws_bytes(n)) { set_error("compaction workspace too small"); return GOF_E_WORKSPACE; }
+    char* base = reinterpret_cast<char*>((reinterpret_cast<size_t>(ws) + 255) & ~(size_t)255);
+    const size_t fl = ((size_t)n * 4 + 255) & ~(size_t)255;
+    uint32_t* flags = reinterpret_cast<uint32_t*>(base);
+    uint32_t* tmp = reinterpret_cast<uint32_t*>(base + 3 * fl);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    GOF_PROFILE("compact_rows", stream);
+    hipLaunchKernelGGL(bytes_to_flags_kernel, dim3(blocks), dim3(256), 0, stream, n, keep, flags);
+    const uint32_t* tot = nullptr;
+    GOF_HIP_CHECK(device_scan_u32(flags, nullptr, flags, (size_t)n, false, tmp, &tot, stream));
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(blocks), dim3(256), 0, stream, n, keep, flags, src_rows, out_rows);
+    GOF_LAUNCH_CHECK(stream, 0);
+    uint32_t h = 0;
+    GOF_HIP_CHECK(hipMemcpyAsync(&h, tot, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    *count_host = h;
+    return GOF_OK;
+}
+
+int gof_rows_gather(int64_t n_rows, int32_t floats_per_row, const int32_t* rows, const float* src, const float* extra, float* out, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_rows < 0 || floats_per_row <= 0) { set_error("bad sizes"); return GOF_E_INVALID; }
+    if (n_rows == 0) return GOF_OK;
+    if (!rows || !src || !out) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
+    GOF_PROFILE("rows_gather", stream);
+    const bool v4 = (floats_per_row % 4 == 0) && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(extra)) % 16 == 0);
+    if (v4) {
+        const int64_t total = n_rows * (floats_per_row / 4);
+        hipLaunchKernelGGL(rows_gather_kernel<float4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total, floats_per_row / 4, rows,
+                           reinterpret_cast<const float4*>(src), reinterpret_cast<const float4*>(extra), reinterpret_cast<float4*>(out));
+    } else {
+        const int64_t total = n_rows * floats_per_row;
+        hipLaunchKernelGGL(rows_gather_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total, floats_per_row, rows, src, extra, out);
+    }
+    GOF_LAUNCH_CHECK(stream, 0);
     return GOF_OK;
 }
 

@@ -93,7 +93,14 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
     bool done = !inside;
 
     for (int b = 0; b < nbatches; b++, toDo -= TILE_PIX) {
-        __syncthreads();   // previous batch finished with s_rec
+        // A sub-ray whose transmittance T satisfies T * (1 - 1/255) < 1e-4 (in fp32, as the test below evaluates it) is finished
+        // for good: an entry is only used with alpha >= 1/255, (1 - alpha) and the product are monotone in alpha, so
+        // T * (1 - alpha) < 1e-4 for every later entry -- the reference's loop keeps running there (forward.cu:951-956, the
+        // `continue` leaves T untouched, so T never actually falls below 1e-4) but can never use another entry.  A pixel whose
+        // five sub-rays are all finished stops here (`done`), a wave whose pixels have all stopped
+        // skips its scan, and the tile stops staging once all 256 have: bit-identical results, and on scenes that saturate the
+        // bulk of a long tile list is never touched (integrate_points bounds its walk by the tile's last contributor likewise).
+        if (__syncthreads_and(done)) break;      // (also the barrier: the previous batch is finished with s_rec)
         const uint32_t k = range.x + (uint32_t)b * TILE_PIX + tid;
         if (k < range.y) {
             const uint32_t id = gaussian_list[k];
@@ -105,6 +112,11 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
             s_con[1][tid] = fconic[2 * (size_t)id + 1];
         }
         __syncthreads();
+        if (__ballot(!done) == 0ull) {             // the whole wave has stopped: it only helped staging; "no contributors" for this batch
+            const int nz = ((toDo < TILE_PIX ? toDo : TILE_PIX) + 31) >> 5;
+            for (int w = 0; w < nz; w++) cm_tile[((size_t)b * 8 + w) * TILE_PIX + tid] = 0u;
+            continue;
+        }
 
         // ---- phase A1: cull scan (wave-uniform over entries): footprint box, then the footprint conic bounded over the
         // pixel's 5 sub-rays; survivors are recorded per pixel as candidate bits in s_used ----
@@ -203,6 +215,8 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                     }
                     n_local += 1;
                     if (n_local >= (uint32_t)MAX_NUM_CONTRIBUTORS * 4) done = true;
+                    // nothing can be used any more (see the head of the batch loop): the largest T against the smallest usable alpha
+                    if (fmaxf(fmaxf(fmaxf(cT[0], cT[1]), fmaxf(cT[2], cT[3])), cT[4]) * (1 - 1.0f / 255.0f) < 0.0001f) done = true;
                 }
             }
             s_used[w][tid] = word;
@@ -244,7 +258,7 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                  const SplatRec* __restrict__ rec, const float* __restrict__ zfront, int zstride, const uint32_t* __restrict__ cmask, int W, int H,
                  float focal_x, float focal_y, const float2* __restrict__ pt_xy, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
                  float* __restrict__ pt_acc, const float* __restrict__ base_color, float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
-                 float* __restrict__ out_color_integrated, uint32_t gx, uint32_t ntiles)
+                 float* __restrict__ out_color_integrated, const uint32_t* __restrict__ n_contrib, uint32_t gx, uint32_t ntiles)
 {
     const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -267,7 +281,14 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
         if (inside) out_color[8 * HW + pix_id] = 0.0f;
         return;
     }
-    const int toDo0 = (int)(range.y - range.x);
+    // only list positions up to the tile's last contributor (n_contrib, written by integrate_pixels) carry mask bits -- and only
+    // the batches up to there were processed by the pixel pass
+    __shared__ uint32_t s_max_last;
+    if (tid == 0) s_max_last = 0;
+    __syncthreads();
+    atomicMax(&s_max_last, inside ? n_contrib[pix_id] : 0u);
+    __syncthreads();
+    const int toDo0 = (int)min(range.y - range.x, s_max_last);
     const int rounds = (toDo0 + TILE_PIX - 1) / TILE_PIX;
     const int nbatches = rounds > 0 ? rounds : 1;      // a tile without Gaussians still writes alpha = 0 for its points
 

@@ -15,7 +15,8 @@ What it does, in this order (nothing in the reference checkout is edited):
   4. rebinds the per-iteration training epilogue to its HIP implementation (train_epilogue/, include/gof_train_hip.h):
      utils.loss_utils.ssim (train.py:20), utils.depth_utils.depth_to_normal / depths_to_points (train.py:38) and the
      optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups) and
-     GaussianModel.compute_3D_filter (scene/gaussian_model.py:262-311, one launch over points x cameras).
+     GaussianModel.compute_3D_filter (scene/gaussian_model.py:262-311, one launch over points x cameras) and
+     GaussianModel.densify_and_prune (:685-707: device index lists + one row gather per tensor; GOF_TORCH_DENSIFY=1 keeps the reference's).
      GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations;
   5. wraps gaussian_renderer.integrate (imported by name at extract_mesh.py:5) so that the Gaussian side of the opacity-field
      query (binning + pixel pass) runs once per view for the ~10 point sets extract_mesh.py queries against the unchanged model
@@ -64,6 +65,13 @@ def rebind_train_epilogue():
     GaussianModel.training_setup = training_setup
     GaussianModel.compute_3D_filter = T.compute_3D_filter      # train.py:118,261,269: after every densification
     GaussianModel.add_densification_stats = T.add_densification_stats   # train.py:256: every iteration until densify_until_iter
+    # train.py:260: clone / split / prune as ordered device index lists + one row gather per tensor (train_epilogue/densify.py)
+    if os.environ.get("GOF_TORCH_DENSIFY") != "1":
+        current = GaussianModel.densify_and_prune
+        if hasattr(current, "inner"):          # the data-parallel launcher's wrapper (statistics all-reduce first): replace what it calls
+            current.inner = T.densify_and_prune
+        else:
+            GaussianModel.densify_and_prune = T.densify_and_prune
     # the three derived tensors render() reads every iteration (gaussian_renderer/__init__.py:60,70-71)
     GaussianModel.get_scaling_with_3D_filter = property(T.activations.get_scaling_with_3D_filter)
     GaussianModel.get_opacity_with_3D_filter = property(T.activations.get_opacity_with_3D_filter)

@@ -143,12 +143,13 @@ def main():
     # Densification statistics are accumulated per rank (each rank sees other views) and zeroed by every densification
     # (densification_postfix, gaussian_model.py:609-629).  Reducing the running totals ONCE, right before they are consumed,
     # gives every rank the statistics of all views since the last densification -> identical densify / prune decisions.
-    _densify = GaussianModel.densify_and_prune
-
     def densify_and_prune(self, *a, **k):
         all_reduce_densification_stats(self.xyz_gradient_accum, self.xyz_gradient_accum_abs, self.denom,
                                        self.max_radii2D, getattr(self, "xyz_gradient_accum_abs_max", None))
-        return _densify(self, *a, **k)
+        return densify_and_prune.inner(self, *a, **k)
+    # `inner` is what actually densifies: the reference's method now, the device implementation once run_reference_script.py has
+    # rebound the training epilogue (it looks for this attribute instead of overwriting the wrapper)
+    densify_and_prune.inner = GaussianModel.densify_and_prune
     GaussianModel.densify_and_prune = densify_and_prune
 
     if rank != 0:      # only rank 0 writes

@@ -7,3 +7,4 @@ from .depth_utils import depth_to_normal, depths_to_points  # noqa: F401
 from .optim import FusedAdam                             # noqa: F401
 from .filter_3d import compute_3D_filter, filter_3d, camera_table, add_densification_stats   # noqa: F401
 from . import activations                                # noqa: F401,E402
+from .densify import densify_and_prune                  # noqa: F401,E402

@@ -123,6 +123,29 @@ int gof_add_densification_stats(int64_t num_points, const float* viewspace_grad,
                                 float* xyz_gradient_accum, float* xyz_gradient_accum_abs, float* xyz_gradient_accum_abs_max,
                                 float* denom, void* stream);
 
+/* ---- densification on the device (scene/gaussian_model.py:631-707, GaussianModel.densify_and_prune) ------
+ * The reference clones / splits / prunes with boolean-mask indexing: every `x[mask]` is a nonzero + gather with a host sync, and
+ * the six parameter tensors and their two Adam moments are re-concatenated and re-indexed four times per densification (clone
+ * postfix, split postfix, removal of the split originals, final prune).  Here the decisions become ordered INDEX LISTS on the
+ * device and every tensor is rebuilt ONCE by a row gather; two 12-byte read-backs (list lengths, final row count) remain.
+ *   gof_densify_select : role of every Gaussian (0 stays, 1 cloned, 2 split) from the accumulated gradients, with the reference's
+ *                        thresholds (`norm(grads) >= max_grad or norm(grads_abs) >= Q`, clone if max(get_scaling) <= size_threshold,
+ *                        else split; grads = accum / denom with NaN -> 0), and the ordered lists keep_idx (role != 2), clone_idx,
+ *                        split_idx (each sized for num_points by the caller); counts_host[3] = their lengths.  q_abs_dev is the
+ *                        torch.quantile value as a DEVICE scalar.  SYNCHRONISES the stream (the caller allocates from the counts).
+ *   gof_compact_rows   : out_rows = (src_rows ? src_rows[i] : i) for the rows with keep[i] != 0, in order; *count_host = how many.
+ *                        SYNCHRONISES the stream.
+ *   gof_rows_gather    : out[r, :] = src[rows[r], :] if rows[r] >= 0 else extra[-rows[r] - 1, :] (zeros if extra is NULL):
+ *                        parameters take their new rows from `extra`, Adam moments get zeros there.
+ * ws: gof_densify_ws_bytes(n) bytes for n rows. */
+size_t gof_densify_ws_bytes(int64_t n);
+int gof_densify_select(int64_t num_points, const float* xyz_gradient_accum, const float* xyz_gradient_accum_abs, const float* denom,
+                       const float* scale_max, float max_grad, const float* q_abs_dev, float size_threshold, uint8_t* role,
+                       int32_t* keep_idx, int32_t* clone_idx, int32_t* split_idx, void* ws, size_t ws_bytes, int64_t* counts_host, void* stream);
+int gof_compact_rows(int64_t n, const uint8_t* keep, const int32_t* src_rows, int32_t* out_rows, void* ws, size_t ws_bytes,
+                     int64_t* count_host, void* stream);
+int gof_rows_gather(int64_t n_rows, int32_t floats_per_row, const int32_t* rows, const float* src, const float* extra, float* out, void* stream);
+
 /* ---- parameter activations of the render path (scene/gaussian_model.py:157-166, 183-194) -------------------------------------
  * render() reads three derived tensors per iteration (gaussian_renderer/__init__.py:60,70-71); in the reference each is a chain
  * of 3-10 torch elementwise kernels plus their autograd (~50 launches per iteration).  One forward and one backward launch each:

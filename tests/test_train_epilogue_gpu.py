@@ -677,3 +677,25 @@ def test_end_to_end_training_iterations_reduce_the_loss(variant):
         assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0]) and np.abs(a - b).max() <= 0.02 * a[0], (a[:3], b[:3], np.abs(a - b).max())
     # the screen-space gradient carrier received the densification signal: x, y signed, z = sum of absolute values (>= 0)
     assert means2D.grad is not None and (radii > 0).any() and (means2D.grad[:, 2] >= 0).all() and means2D.grad[:, 2].max() > 0
+
+
+def test_densify_and_prune_on_the_device_equals_the_references_own_method():
+    """train_epilogue.densify_and_prune (ordered device index lists + one row gather per tensor) against the reference's
+    GaussianModel.densify_and_prune executed on this GPU (staged copy, oracle/_ref/refpy): the same Gaussians in the same order --
+    every parameter, both Adam moments (torch Adam and FusedAdam states), the reset statistics and the returned triple; new
+    positions included (same torch statements on the same selections, same generator consumption)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(os.path.join(root, "oracle", "_ref", "refpy", "scene", "gaussian_model.py")), "oracle/_ref/refpy is missing: run __graft_entry__.build()"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_densify_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert len(rows) == 5
+    for x in rows:
+        assert x["n_ref"] == x["n_ours"] and x["ret_ref"] == x["ret_ours"], x
+        assert x["ret_ref"][0] > 0 and x["ret_ref"][1] > 0 and x["ret_ref"][2] > 0, x      # clones, splits and prunes all occurred
+        for k, v in x["diff"].items():
+            assert v == 0.0, (k, v, x)
