@@ -7,10 +7,10 @@
 //  * The reference issues 17 global fp32 atomicAdd per contributing (pixel, splat) pair
 //    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave (an 8x8 pixel quadrant) look at the SAME splat
 //    at the same time, and the 17 partial gradients are summed IN REGISTERS over the whole wave:
-//      1. per 16-lane row a TRANSPOSED (butterfly) reduction of 16 of the values -- the two quad exchange steps halve the
-//         number of live values, two row rotations finish (row_sum16_transposed) -- plus a plain 4-step DPP sum of the 17th;
-//      2. across the four rows the butterfly continues with two ds_bpermute exchanges (4 -> 2 -> 1 live values), so that
-//         lane (row r, l & 3) ends up with the wave total of value 4r + (l & 3);
+//      1. a TRANSPOSED reduction of 16 of the values: every level halves the number of live values per lane -- the half-wave and
+//         row levels with v_permlane32_swap / v_permlane16_swap (gfx950; no selects), the two quad levels with DPP and selects,
+//         two row rotations finish; the 17th value by a plain DPP row sum and two ds_bpermute exchanges;
+//      2. lane l ends with the wave total of value 8 b1 + 4 b0 + 2 p + h (lane bits 0, 1, row parity, wave half);
 //      3. ONE plain LDS store (16 active lanes) + one for the 17th value put the totals into the wave's own slab
 //         s_slab[wave][17][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
 //         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
@@ -80,30 +80,6 @@ __device__ __forceinline__ float dpp_get(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-// Transposed ("butterfly") row reduction of 16 values: each exchange step halves the number of live values instead of summing
-// every value at every step.  After the two quad steps lane (b1 b0) holds, for m = 0..3, the quad sum of value 4m + 2 b1 + b0;
-// two row rotations complete the sum over the row's four quads.  44 VALU instead of 64, and the 16 results sit in 4 lanes
-// (4 each) instead of 16 values in one lane: 4 LDS adds instead of 16.
-__device__ __forceinline__ void row_sum16_transposed(const float* g, bool b0, bool b1, float w4[4])
-{
-    float u[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const float keep = b0 ? g[2 * m + 1] : g[2 * m];
-        const float send = b0 ? g[2 * m] : g[2 * m + 1];
-        u[m] = keep + dpp_get<0xB1>(send);          // quad_perm [1,0,3,2]
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const float keep = b1 ? u[2 * m + 1] : u[2 * m];
-        const float send = b1 ? u[2 * m] : u[2 * m + 1];
-        float w = keep + dpp_get<0x4E>(send);       // quad_perm [2,3,0,1]
-        w = w + dpp_get<0x124>(w);                  // row_ror:4
-        w = w + dpp_get<0x128>(w);                  // row_ror:8
-        w4[m] = w;
-    }
-}
-
 // OR over the 16-lane row; every lane of the row gets the result
 __device__ __forceinline__ uint32_t row_or(uint32_t v)
 {
@@ -238,6 +214,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
         // The wave walks the union of its pixels' contributors back to front (wave-uniform entry index: scalar bit walk over
         // the OR of the 64 mask words, LDS reads of the record are broadcasts).
         const uint32_t wave = tid >> 6;
+        const uint32_t slab_row = 8u * ((lane >> 1) & 1u) + 4u * (lane & 1u) + 2u * ((lane >> 4) & 1u) + (lane >> 5);   // value this lane's total belongs to
         for (int w = ((n + 31) >> 5) - 1; w >= 0; w--) {
             const uint32_t word = s_cm[w][tid];
             uint32_t todo = wave_or(word);
@@ -357,23 +334,40 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     g[16] = dL_dmin_value;
                     }
                 }
-                // wave total of the 17 values: in-row butterfly, then the butterfly continues across the rows (4 -> 2 -> 1 live values)
-                float w4[4];
-                row_sum16_transposed(g, (lane & 1u) != 0u, (lane & 2u) != 0u, w4);
-                float g16 = row_sum(g[16]);
-                {
-                    const bool r0 = (lane & 16u) != 0u, r1 = (lane & 32u) != 0u;
-                    const float k0 = r0 ? w4[1] : w4[0], s0 = r0 ? w4[0] : w4[1];
-                    const float k1 = r0 ? w4[3] : w4[2], s1 = r0 ? w4[2] : w4[3];
-                    const float u0 = k0 + lane_xor(s0, lane, 16u);           // rows (0,1), (2,3): value m = (r & 1)      of w4[0..1]
-                    const float u1 = k1 + lane_xor(s1, lane, 16u);           //                    value m = 2 + (r & 1)  of w4[2..3]
-                    const float k = r1 ? u1 : u0, sn = r1 ? u0 : u1;
-                    const float tot = k + lane_xor(sn, lane, 32u);           // row r holds the wave total of value 4 * m(r) + (lane & 3), m(r) = 2 (r >> 1) + (r & 1) = r
-                    g16 = g16 + lane_xor(g16, lane, 16u);
-                    g16 = g16 + lane_xor(g16, lane, 32u);
-                    if ((lane & 12u) == 0u) s_slab[wave][4u * (lane >> 4) + (lane & 3u)][j] = tot;
-                    if (lane == 63u) s_slab[wave][16][j] = g16;
+                // wave total of the 17 values.  16 of them by a transposed reduction whose first two levels use gfx950's lane-group
+                // swaps (no selects): v_permlane32_swap exchanges the upper half of one register with the lower half of another, so
+                // x + y afterwards holds value A summed over the halves in lanes 0-31 and value B in lanes 32-63; v_permlane16_swap
+                // does the same for odd / even rows.  16 -> 8 -> 4 live values; two DPP quad levels with selects 4 -> 2 -> 1; two row
+                // rotations finish.  Lane l ends with the wave total of value 8 b1 + 4 b0 + 2 p + h (b0, b1 = lane bits 0, 1;
+                // p = row parity; h = wave half).
+                float u[8], v4[4];
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g[2 * m]), __float_as_uint(g[2 * m + 1]), false, false);
+                    u[m] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
                 }
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * m]), __float_as_uint(u[2 * m + 1]), false, false);
+                    v4[m] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+                float tot;
+                {
+                    const bool b0 = (lane & 1u) != 0u, b1 = (lane & 2u) != 0u;
+                    const float k0 = b0 ? v4[1] : v4[0], s0 = b0 ? v4[0] : v4[1];
+                    const float k1 = b0 ? v4[3] : v4[2], s1 = b0 ? v4[2] : v4[3];
+                    const float w0 = k0 + dpp_get<0xB1>(s0);          // quad_perm [1,0,3,2]
+                    const float w1 = k1 + dpp_get<0xB1>(s1);
+                    const float k = b1 ? w1 : w0, sn = b1 ? w0 : w1;
+                    tot = k + dpp_get<0x4E>(sn);                      // quad_perm [2,3,0,1]
+                    tot = tot + dpp_get<0x124>(tot);                  // row_ror:4
+                    tot = tot + dpp_get<0x128>(tot);                  // row_ror:8
+                }
+                float g16 = row_sum(g[16]);
+                g16 = g16 + lane_xor(g16, lane, 16u);
+                g16 = g16 + lane_xor(g16, lane, 32u);
+                if ((lane & 12u) == 0u) s_slab[wave][slab_row][j] = tot;
+                if (lane == 63u) s_slab[wave][16][j] = g16;
             }
             if (lane == 0) s_vis[wave][w] = visited;
         }

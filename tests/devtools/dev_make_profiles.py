@@ -1,13 +1,16 @@
 """Developer script: turn the rocprofv3 outputs merged under gpurun_out/ into the committed summaries in profiles/.
-usage: python tests/devtools/dev_make_profiles.py <tag e.g. v4> <prof dir> <pmc FETCH dir> <pmc WRITE dir> [bench json] [pmc VALU dir]
-The optional VALU pass (--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE) adds, per kernel, the VALU issue
-utilisation = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
-import csv, json, os, re, sys, shutil
+usage: python tests/devtools/dev_make_profiles.py <round e.g. r02> <tag e.g. v2> <kernel-trace stats dir> <pmc root dir> [bench json]
+The pmc root holds one sub-directory per counter pass (tests/devtools/dev_r2_profiles.sh): fetch (FETCH_SIZE), write (WRITE_SIZE),
+sq1 (SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_*), sq2 (SQ_WAIT_* SQ_INSTS_* SQ_THREAD_CYCLES_VALU), sq3 (LDS + GRBM_GUI_ACTIVE),
+sq4 (SQ_INSTS_VALU_* by type).  Writes profiles/<round>_bench_s1m_kernel_stats_<tag>.{csv,md}, profiles/<round>_pmc_traffic_s1m.json
+(keyed by kernel; "_kernel_sha16" = hash of the blend kernel sources the passes ran on, bench.py refuses a stale file) and copies
+the bench line."""
+import csv, glob, json, os, re, sys, shutil
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-tag, prof, pf, pw = sys.argv[1:5]
+sys.path.insert(0, ROOT)
+rnd, tag, prof, pmc_root = sys.argv[1:5]
 bench = sys.argv[5] if len(sys.argv) > 5 else None
-pv = sys.argv[6] if len(sys.argv) > 6 else None
 
 
 def short(name):
@@ -16,9 +19,14 @@ def short(name):
     return {"__amd_rocclr_fillBufferAligned": "hipMemsetAsync (fillBufferAligned)", "__amd_rocclr_copyBuffer": "hipMemcpyAsync (copyBuffer)"}.get(n, n)
 
 
-stats = list(csv.DictReader(open([os.path.join(prof, f) for f in os.listdir(prof) if f.endswith("kernel_stats.csv")][0])))
-shutil.copy([os.path.join(prof, f) for f in os.listdir(prof) if f.endswith("kernel_stats.csv")][0],
-            os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.csv" % tag))
+def find(d, suffix):
+    fs = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    return fs[0] if fs else None
+
+
+stats_file = find(prof, "kernel_stats.csv")
+stats = list(csv.DictReader(open(stats_file)))
+shutil.copy(stats_file, os.path.join(ROOT, "profiles", "%s_bench_s1m_kernel_stats_%s.csv" % (rnd, tag)))
 agg = defaultdict(lambda: [0, 0.0])
 for r in stats:
     k = short(r["Name"])
@@ -28,57 +36,84 @@ for r in stats:
 tot = sum(v[1] for v in agg.values())
 
 
-def pmc(d, counter):
-    f = [os.path.join(d, x) for x in os.listdir(d) if x.endswith("counter_collection.csv")][0]
-    acc = defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+def pmc(sub):
+    f = find(os.path.join(pmc_root, sub), "counter_collection.csv")
+    out = defaultdict(lambda: defaultdict(list))
+    if f:
+        for r in csv.DictReader(open(f)):
+            out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in out.items()}
 
 
-fetch, write = pmc(pf, "FETCH_SIZE"), pmc(pw, "WRITE_SIZE")
-traffic = {}
-for k in sorted(set(fetch) | set(write)):
+passes = {s: pmc(s) for s in ("fetch", "write", "sq1", "sq2", "sq3", "sq4")}
+kernels = sorted(set().union(*[set(p) for p in passes.values()]))
+import bench as bench_mod
+data = {"_kernel_sha16": bench_mod.kernel_sha16(),
+        "_note": "per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md); "
+                 "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves / SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs"}
+for k in kernels:
     if k.startswith("hipMem") or k.startswith("torch") or k.startswith("at"):
         continue
-    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-    traffic[k] = {"fetch_KiB_raw": f, "write_KiB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024}
-valu = {}
-if pv:
-    insts, salu, ldsi, gui = pmc(pv, "SQ_INSTS_VALU"), pmc(pv, "SQ_INSTS_SALU"), pmc(pv, "SQ_INSTS_LDS"), pmc(pv, "GRBM_GUI_ACTIVE")
-    for k in traffic:
-        if k in insts and gui.get(k):
-            cycles = gui[k] / 8.0                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-            traffic[k]["valu_insts"] = insts[k]
-            traffic[k]["salu_insts"] = salu.get(k, 0.0)
-            traffic[k]["lds_insts"] = ldsi.get(k, 0.0)
-            traffic[k]["gpu_cycles"] = cycles
-            traffic[k]["valu_issue_frac"] = insts[k] * 4.0 / (1024.0 * cycles)
-            valu[k] = traffic[k]["valu_issue_frac"]
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_s1m.json"), "w"), indent=1)
-with open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % tag), "w") as o:
-    o.write("# rocprofv3 summaries, round 1, kernels of commit-state '%s'\n\n" % tag)
-    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline`\n"
-            "(S1M: 1M Gaussians, 1600x1063, R = 8 837 593; 12 fwd+bwd iterations + 1 stage-statistics forward)\n\n")
+    e = {}
+    f, w = passes["fetch"].get(k, {}).get("FETCH_SIZE"), passes["write"].get(k, {}).get("WRITE_SIZE")
+    if f is not None or w is not None:
+        e.update(fetch_KiB_raw=f or 0.0, write_KiB=w or 0.0, hbm_bytes_corrected=2 * (f or 0.0) * 1024 + (w or 0.0) * 1024)
+    c = {}
+    for s in ("sq1", "sq2", "sq3", "sq4"):
+        c.update(passes[s].get(k, {}))
+    if c:
+        e["counters"] = c
+        gui = c.get("GRBM_GUI_ACTIVE")
+        if gui and c.get("SQ_ACTIVE_INST_VALU"):
+            cycles = gui / 8.0
+            e["gpu_cycles"] = cycles
+            e["valu_pipe_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles)          # quad-cycles -> cycles, 1024 SIMDs
+            e["valu_issue_frac"] = e["valu_pipe_busy_frac"]
+        if c.get("SQ_INSTS_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+            e["cycles_per_valu_inst"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
+        if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+            e["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        if c.get("SQ_WAVE_CYCLES"):
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                if c.get(n) is not None:
+                    e[n.lower() + "_frac_of_wave_cycles"] = c[n] / c["SQ_WAVE_CYCLES"]
+    if e:
+        data[k] = e
+json.dump(data, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_s1m.json" % rnd), "w"), indent=1)
+md = os.path.join(ROOT, "profiles", "%s_bench_s1m_kernel_stats_%s.md" % (rnd, tag))
+with open(md, "w") as o:
+    o.write("# rocprofv3 summaries, round %s, kernels of commit-state '%s' (blend kernel sources sha16 %s)\n\n" % (rnd[1:], tag, data["_kernel_sha16"]))
+    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop`\n"
+            "(S1M: 1M Gaussians, 1600x1063, R = 8 837 593)\n\n")
     o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         o.write("| %s | %d | %.3f | %.1f | %.2f |\n" % (k, c, t / 1e6, t / c / 1e3, 100 * t / tot))
-    o.write("\n## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, tests/devtools/dev_pmc.py)\n\n"
-            "FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; per the MI355X guide, on gfx950 FETCH_SIZE counts wide coalesced\n"
-            "reads at 1/2 (64 B per 128-B request), so the read column is given raw and doubled; WRITE_SIZE is uncalibrated.\n"
-            "The 64 MB record table and the tile lists stay resident in the 256 MiB Infinity Cache, whose hits the counter includes.\n\n")
+    o.write("\n## HBM traffic per launch (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over tests/devtools/dev_pmc.py)\n\n"
+            "FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X guide), so the read\n"
+            "column is given raw and doubled; the 64 MB record table and the tile lists stay resident in the 256 MiB Infinity Cache.\n\n")
     o.write("| kernel | FETCH_SIZE KiB (raw) | read MB (x2 corrected) | WRITE_SIZE KiB | write MB |\n|---|---|---|---|---|\n")
-    for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
+    for k, v in sorted(((k, v) for k, v in data.items() if isinstance(v, dict) and "hbm_bytes_corrected" in v), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
         o.write("| %s | %.0f | %.1f | %.0f | %.1f |\n" % (k, v["fetch_KiB_raw"], 2 * v["fetch_KiB_raw"] * 1024 / 1e6, v["write_KiB"], v["write_KiB"] * 1024 / 1e6))
-    if valu:
-        o.write("\n## VALU issue utilisation (separate `--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE` pass)\n\n"
-                "wave-level VALU instructions x 4 cycles (a wave64 instruction occupies a 16-lane SIMD for 4 cycles; fp64 and transcendental\n"
-                "instructions take longer, so the figure is a lower bound of the VALU busy time) / (1024 SIMDs x kernel cycles).\n\n"
-                "| kernel | VALU insts / launch | SALU | LDS | kernel cycles | VALU issue fraction |\n|---|---|---|---|---|---|\n")
-        for k, f in sorted(valu.items(), key=lambda kv: -traffic[kv[0]]["valu_insts"]):
-            t = traffic[k]
-            o.write("| %s | %.3e | %.2e | %.2e | %.3e | %.2f |\n" % (k, t["valu_insts"], t["salu_insts"], t["lds_insts"], t["gpu_cycles"], f))
+    o.write("\n## Vector-ALU counters of the kernels (separate SQ passes)\n\n"
+            "VALU pipe busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x kernel cycles); cycles per VALU instruction = pipe time / SQ_INSTS_VALU;\n"
+            "lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wave-cycle split: parked at s_waitcnt / barrier (WAIT_ANY), issue stall\n"
+            "(WAIT_INST_ANY), issuing (ACTIVE_INST_ANY).\n\n"
+            "| kernel | VALU insts | VALU pipe busy | cycles / VALU inst | lane utilisation | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | LDS bank conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|---|\n")
+    for k, v in sorted(((k, v) for k, v in data.items() if isinstance(v, dict) and "valu_pipe_busy_frac" in v), key=lambda kv: -kv[1]["counters"].get("SQ_INSTS_VALU", 0)):
+        c = v["counters"]
+        o.write("| %s | %.3e | %.2f | %.2f | %s | %s | %s | %s | %s |\n" % (
+            k, c.get("SQ_INSTS_VALU", 0), v["valu_pipe_busy_frac"], v.get("cycles_per_valu_inst", float("nan")),
+            "%.2f" % v["valu_lane_utilisation"] if "valu_lane_utilisation" in v else "-",
+            *["%.2f" % v[n] if n in v else "-" for n in ("sq_wait_any_frac_of_wave_cycles", "sq_wait_inst_any_frac_of_wave_cycles", "sq_active_inst_any_frac_of_wave_cycles")],
+            "%.2f" % (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else "-"))
+    o.write("\n## VALU instruction mix of the blend kernels (SQ_INSTS_VALU_* pass)\n\n| kernel | " + " | ".join(
+        n.replace("SQ_INSTS_VALU_", "") for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                                                 "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) + " |\n|---|" + "---|" * 8 + "\n")
+    for k in ("blend_forward", "blend_backward", "integrate_pixels", "integrate_points"):
+        c = data.get(k, {}).get("counters", {})
+        if c.get("SQ_INSTS_VALU_ADD_F32") is not None:
+            o.write("| %s | " % k + " | ".join("%.3e" % c.get(n, 0) for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                                                                                "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) + " |\n")
 if bench:
-    shutil.copy(bench, os.path.join(ROOT, "profiles", "r01_bench_s1m_%s.json" % tag))
-print(open(os.path.join(ROOT, "profiles", "r01_bench_s1m_kernel_stats_%s.md" % tag)).read())
+    shutil.copy(bench, os.path.join(ROOT, "profiles", "%s_bench_s1m_%s.json" % (rnd, tag)))
+print(open(md).read())
