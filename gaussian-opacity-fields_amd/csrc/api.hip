@@ -5,6 +5,7 @@
 // buffer management (reference rasterize_points.cu:28-122).  No torch types, no global state,
 // every launch on the caller's stream.
 #include "gof_common.h"
+#include "gof_status.h"
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +42,7 @@ size_t scan_tmp_words(size_t n);
 hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
                            const uint32_t** total_dev_out, hipStream_t stream);
 size_t rs_tmp_words(size_t n);
+const uint32_t* radix_sort_error_flag(const uint32_t* tmp, size_t n, int end_bit);
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 int radix_passes(int end_bit);
@@ -66,7 +68,8 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
                                  float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, uint32_t gx, uint32_t ntiles);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
-__global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts);
+__global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
+                             const uint32_t* sort_error);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
@@ -261,7 +264,7 @@ using namespace gof;
 extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
-int gof_abi_version(void) { return 3; }
+int gof_abi_version(void) { return 4; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
@@ -292,7 +295,8 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
     { GOF_PROFILE("scan_tiles", stream);
     // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
     // scanned in place
-    hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, g.dkey_b, g.dval_b, g.order_off);
+    hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, g.dkey_b, g.dval_b, g.order_off,
+                       radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32));
     GOF_HIP_CHECK(device_scan_u32(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
                                   total_dev_out, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
@@ -323,6 +327,11 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
         GOF_HIP_CHECK(hipMemcpyAsync(&host_words[1], g.flags, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
     *num_rendered_host = host_words[0];
+    if (host_words[0] >= GOF_SORT_FAILED_COUNT) {
+        *num_rendered_host = 0;
+        set_error("depth sort: a single-kernel radix pass timed out waiting for a predecessor block (GPU heavily oversubscribed?)");
+        return GOF_E_DEVICE;
+    }
     if (a->prefiltered && host_words[1]) {
         set_error("Point is filtered although prefiltered is set. This shouldn't happen!");   // auxiliary.h:193-197
         return GOF_E_PREFILTER;
@@ -371,6 +380,10 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
                        im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
     GOF_LAUNCH_CHECK(stream, 0);
     GOF_HIP_CHECK(hipEventSynchronize(ev));
+    if (*num_rendered_pinned_host >= GOF_SORT_FAILED_COUNT) {
+        set_error("depth sort: a single-kernel radix pass timed out waiting for a predecessor block (GPU heavily oversubscribed?)");
+        return GOF_E_DEVICE;
+    }
     if (*num_rendered_pinned_host > capacity) {
         set_error("instance count %u exceeds the capacity %u of the binning workspace", *num_rendered_pinned_host, capacity);
         return GOF_E_CAPACITY;

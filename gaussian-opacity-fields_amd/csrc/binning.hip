@@ -16,6 +16,7 @@
 // stable sort, because both sorts are stable and step 3 preserves the order of step 1.
 // Scan and sort are the hand-written kernels of radix.hip.
 #include "gof_common.h"
+#include "gof_status.h"
 
 namespace gof {
 
@@ -37,10 +38,17 @@ uint32_t higher_msb(uint32_t n)
 // both scan passes and radii + the record's pixel position again in the emission cost three 64-byte sectors per Gaussian.)
 __global__ void __launch_bounds__(256)
 gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, uint32_t* __restrict__ minxy_sorted,
-             uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ counts)
+             uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ counts, const uint32_t* __restrict__ sort_error)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // the depth sort's bounded look-back poll expired (radix.hip: OS_SPIN_LIMIT): `order` is not a sorted permutation.  Make the
+    // instance count the host reads back impossible (GOF_SORT_FAILED_COUNT) so that the call fails instead of rendering garbage.
+    if (sort_error && *sort_error) {
+        minxy_sorted[i] = 0u; wh_sorted[i] = 0u;
+        counts[i] = (i == 0u) ? GOF_SORT_FAILED_COUNT : 0u;
+        return;
+    }
     const uint2 r = rect[order[i]];
     minxy_sorted[i] = r.x;
     wh_sorted[i] = r.y;

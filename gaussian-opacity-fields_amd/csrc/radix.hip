@@ -489,4 +489,13 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
 }
 int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
 
+// Device word that is non-zero after radix_sort_pairs_u32(.., n, end_bit, tmp, ..) if a single-kernel pass gave up waiting for a
+// predecessor (bounded look-back poll); nullptr when that sort runs as histogram / scan / scatter launches, which cannot time out.
+const uint32_t* radix_sort_error_flag(const uint32_t* tmp, size_t n, int end_bit)
+{
+    const int npass = (end_bit + 7) / 8;
+    if (n == 0 || npass <= 0 || rs_units(n) > OS_MAX_UNITS || npass > OS_MAX_PASSES) return nullptr;
+    return tmp + OS_MAX_PASSES * RS_DIGITS + 8;
+}
+
 } // namespace gof

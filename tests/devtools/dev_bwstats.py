@@ -18,7 +18,5 @@ torch.cuda.synchronize()
 B.lib.gof_debug_bw_stats(out, 1)
 s = list(out)
 nwaves = 6700 * 4
-print("staged entries %d (per tile %.1f); wave iterations %d (per wave %.1f); active (row, iteration) pairs %d (per wave %.1f = %.2f of 4 rows)"
-      % (s[4], s[4] / 6700, s[0], s[0] / nwaves, s[1], s[1] / nwaves, s[1] / max(1, 4.0 * s[0])))
-print("contributing pairs %d (per active row-iteration %.2f of 16 lanes; lane utilisation of the loop %.3f); word fetches per wave %.1f"
-      % (s[2], s[2] / max(1, s[1]), s[2] / max(1, 64.0 * s[0]), s[3] / nwaves))
+print("staged entries %d (per tile %.1f); wave iterations of the entry loop %d (per wave %.1f)" % (s[4], s[4] / 6700, s[0], s[0] / nwaves))
+print("contributing (pixel, entry) pairs %d; lane utilisation of the gradient block %.3f" % (s[2], s[2] / max(1, 64.0 * s[0])))

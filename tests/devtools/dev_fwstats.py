@@ -14,5 +14,5 @@ s = list(out)
 npix = sd["W"] * sd["H"]; nwaves = 6700 * 4
 print("scanned wave-entries %d (per wave %.1f)" % (s[0], s[0] / nwaves))
 print("candidates %d (per pixel %.1f), exact-pass %d (per pixel %.1f), contributing %d (per pixel %.1f)" % (s[1], s[1] / npix, s[3], s[3] / npix, s[4], s[4] / npix))
-print("box violations (must be 0):", s[6], " fp32-cull survivors", s[7], "(per pixel %.1f)" % (s[7] / npix))
+print("(cull audit build only) pairs accepted by the exact path that the scan had dropped (must be 0):", s[6])
 print("phase-2 wave iterations %d (per wave %.1f); lane-iterations active %d -> lane utilisation %.2f" % (s[2], s[2] / nwaves, s[5], s[5] / (64.0 * s[2])))
