@@ -94,8 +94,9 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
                (float)(I.Sx * Rt.m[2][0]), (float)(I.Sy * Rt.m[2][1]), (float)(I.Sz * Rt.m[2][2]));
 }
 
-// Conservative PIXEL bounding box of the region where this splat can reach alpha >= 1/255, used by the
-// blend kernels to skip (pixel, splat) pairs without touching the per-pair arithmetic.
+// Conservative footprint of the region where this splat can reach alpha >= 1/255 -- as a PIXEL bounding box (the opacity-field
+// query's wave-level prefilter) and as a CONIC in ray space (the cull scans of blend_forward and integrate_pixels) -- used to skip
+// (pixel, splat) pairs without touching the per-pair arithmetic.
 //
 // alpha = w * exp(-min_value / 2) >= 1/255  <=>  min_value <= m0 = 2 ln(255 w); min_value(ray) is the
 // minimum of the Mahalanobis distance along the ray, so the candidate rays are those that hit the
@@ -105,12 +106,21 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
 // camera plane, otherwise the box is left unbounded).  Everything is evaluated in fp64 from the
 // well-conditioned view-space covariance (no inversion).
 //
-// The blend evaluates min_value from fp32-rounded coefficients with fp32 arithmetic; its absolute error
-// is bounded by ~ c * eps * cond(Sigma') * lambda_max * |mu|^2 (forward error of r^T Sigma' r and b.r with
-// |b| <= lambda_max |mu|, r^T Sigma' r >= lambda_min |r|^2; c ~ 30 covers coefficient rounding too).  The level is
-// therefore raised to k = m0 + Delta with Delta = 3e-5 * cond * lambda_max * |mu|^2 + 0.05, which keeps the box
-// conservative with respect to the arithmetic the blend actually performs (for sub-pixel, far-away
-// splats the box grows accordingly); for cond > 1e4 the box is left unbounded.
+// The blend evaluates min_value = CC - BB^2 / (4 AA) from fp32-rounded coefficients: the prelude (normal = Sigma' r, AA = r.normal,
+// BB = 2 b.r) in fp32, the rest in fp64.  Forward error, eps = 2^-24: every stored Sigma'_ij is off by <= 4 eps lambda_max (product
+// chain of preprocess), so AA by <= 12 eps lambda_max |r|^2 from the coefficients + <= 10.4 eps lambda_max |r|^2 from its own 7
+// roundings (|| |Sigma'| ||_2 <= sqrt(3) lambda_max); BB by <= 24 eps lambda_max |mu| |r| (b = Sigma' mu, 5 roundings, doubled) + <= 10
+// eps lambda_max |mu| |r| from the fp32 rounding of the transformed mean inside b; CC by <= 11 eps lambda_max |mu|^2.  With
+// d(min_value)/dBB = t, d/dAA = t^2 and t |r| ~ |mu| at the ray's closest approach:  |delta min_value| <~ (22.4 + 34 + 11) eps
+// lambda_max |mu|^2 = 4.0e-6 lambda_max |mu|^2.  The level is therefore raised to k = m0 + Delta with
+//     Delta = GOF_BOX_C * lambda_max * |mu|^2 + 0.05,   GOF_BOX_C = 6e-6
+// (1.5x that bound; the constant term covers the fp32 rounding of `power`, the <= 1 ulp exp and the threshold compare with a wide
+// margin), which keeps box and conic conservative with respect to the arithmetic the blend actually performs (for sub-pixel,
+// far-away splats they grow accordingly).  For cond(Sigma') > 1e4, a non-orthonormal frame, or an ellipsoid that reaches the
+// camera plane, no statement is made (unbounded box, all-zero conic = always a candidate).  Measured: an instrumented build
+// (-DGOF_CULL_AUDIT) counts the pairs the exact path accepts outside the conic -- 0 on S1M and the whole scene table
+// (tests/test_parity_gpu.py::test_the_cull_scan_drops_no_pair_the_exact_path_accepts); with the constant lowered to 2e-7 / 0 the
+// same count was 13 / 2438 of 1.24e8 accepted pairs at S1M (round-1 measurement), none at 1e-6.
 // Also emits the footprint CONIC in ray space (fc[0..1]): a ray r = (rx, ry, 1) meets the level-set ellipsoid iff
 // g(r) = r^T M r <= 0 with M = (C - k) Sigma' - b b^T, b = Sigma' mu, C = mu^T Sigma' mu (min over t of the quadratic
 // along the ray is C - (b.r)^2 / (r^T Sigma' r)).  M is evaluated in fp64 from the same well-conditioned factors as the

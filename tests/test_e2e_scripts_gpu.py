@@ -11,6 +11,8 @@ launch/run_train_dp.py exactly as INTEGRATION.md tells a user to start them.
     `oneupSHdegree` at 1000 and the late 3D-filter refresh, saves the model; the test PSNR must rise by > 6 dB and end above 24 dB.
   * the same run with GOF_TORCH_EPILOGUE=1 (the reference's own torch loss / optimizer / filter code instead of the HIP training
     epilogue): same PSNR after the first 100 iterations (no densification yet) within 0.3 dB, same final PSNR within 1.5 dB.
+  * render.py on the trained model (forward-only use): 4 test renderings whose PSNR against the written ground truths matches what
+    train.py reported.
   * extract_mesh.py on the trained model (Delaunay by the scipy stand-in, opacity-field queries, HIP marching tetrahedra, the 8-step
     bisection): writes a non-empty mesh; with the per-view integrate cache disabled the mesh is byte-identical.
   * 2-rank data-parallel training (run_train_dp.py, both ranks on this GPU, gloo): both ranks finish, the replicas stay
@@ -131,6 +133,26 @@ def test_hip_epilogue_and_the_references_torch_epilogue_train_alike(scene, train
     assert abs(a[ITERS] - b[ITERS]) < 1.5, (a, b)
     ta, tb = _psnr(out_hip, "train"), _psnr(out_t, "train")
     assert abs(ta[ITERS] - tb[ITERS]) < 1.5, (ta, tb)
+
+
+def test_render_py_runs_unchanged(trained):
+    """render.py (render.py:24-36: the forward-only use of the path) on the trained model: writes its renderings and ground truths;
+    what it wrote agrees with the ground truth to the PSNR train.py reported (8-bit PNGs: a little less)."""
+    from PIL import Image
+    model, out_train = trained
+    cmd = [sys.executable, os.path.join(PKG, "launch", "run_reference_script.py"), os.path.join(REFPY, "render.py"), "-m", model,
+           "--iteration", str(ITERS), "--skip_train", "--quiet"]
+    _run(cmd, _env())
+    base = os.path.join(model, "test", "ours_%d" % ITERS)
+    preds = sorted(os.listdir(os.path.join(base, "test_preds_-1")))
+    assert len(preds) == 4
+    psnr = []
+    for f in preds:
+        a = np.asarray(Image.open(os.path.join(base, "test_preds_-1", f)).convert("RGB"), np.float64) / 255.0
+        b = np.asarray(Image.open(os.path.join(base, "gt_-1", f)).convert("RGB"), np.float64) / 255.0
+        assert a.shape == b.shape == (120, 160, 3)
+        psnr.append(-10.0 * np.log10(np.mean((a - b) ** 2) + 1e-12))
+    assert np.mean(psnr) > _psnr(out_train)[ITERS] - 3.0 and np.mean(psnr) > 24.0, (psnr, _psnr(out_train))
 
 
 def _mesh_path(model):

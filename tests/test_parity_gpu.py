@@ -675,6 +675,28 @@ def test_integrate_full_size_properties_config5():
     cache.clear()
 
 
+def test_integrate_config5_gaussian_count_against_oracle():
+    """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 44M instances, tile lists of ~6600 entries) with a 5M-point subsample
+    of its 45M query points, against the oracle on the GPU box's host cores: every output bit-identical."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = S.scene_frustum(5_000_000, seed=0, sigma_px=1.5)
+    pts = np.ascontiguousarray(S.tetra_points(sc)[::9], dtype=np.float32)
+    assert pts.shape[0] == 5_000_000
+    o = ob.OracleScene(sc)
+    oc, oal, ocol, orad = o.integrate(pts)
+    sd = to_dev(sc)
+    r = GaussianRasterizer(settings_from(sd))
+    color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
+                                            opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), orad) and o.num_rendered() > 40_000_000
+    c = color.cpu().numpy()
+    assert np.array_equal(bits(c), bits(oc)), [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)]
+    a = alpha.cpu().numpy()
+    assert np.array_equal(bits(a), bits(oal)), (int((bits(a) != bits(oal)).sum()), np.abs(a - oal).max())
+    assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
+
+
 def test_full_size_s1m_against_oracle():
     """BASELINE config 2 at FULL size (1M Gaussians, 1600x1063) against the oracle on the GPU box's host cores:
     forward bit-exact (normals 2e-6), blend gradients within 1e-4."""
