@@ -21,7 +21,7 @@ for p in (os.path.join(ROOT, "gaussian-opacity-fields_amd"), os.path.join(ROOT, 
 FOVX = 0.6911112070083618            # camera_angle_x of the NeRF-synthetic scenes
 
 
-def ground_truth(seed=0, n=3000):
+def ground_truth(seed=0, n=3000, scale=0.035):
     """A few anisotropic blobs of small Gaussians inside the [-1.3, 1.3]^3 box the reader's random initialisation assumes."""
     rng = np.random.default_rng(seed)
     centres = np.array([[0.0, 0.0, 0.0], [0.7, 0.2, -0.3], [-0.6, -0.4, 0.4], [0.1, 0.6, 0.6]])
@@ -33,7 +33,7 @@ def ground_truth(seed=0, n=3000):
     shell = rng.uniform(0.85, 1.0, (n, 1))                       # points near the surface of each ellipsoid
     means = centres[which] + d * shell * radii[which]
     colors = np.clip(base[which] + 0.25 * d * np.array([1.0, -1.0, 0.5]) + rng.normal(0, 0.03, (n, 3)), 0.02, 0.98)
-    scales = np.exp(rng.normal(math.log(0.035), 0.25, (n, 3)))
+    scales = np.exp(rng.normal(math.log(scale), 0.25, (n, 3)))
     q = rng.normal(size=(n, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     return dict(means3D=means.astype(np.float32), colors=colors.astype(np.float32), scales=scales.astype(np.float32),
@@ -70,12 +70,12 @@ def render_view(gt, R_c2w, centre, W, H, bg, device="cuda:0"):
     return color[:3].clamp(0, 1).permute(1, 2, 0).cpu().numpy()
 
 
-def make_scene(out_dir, n_train=24, n_test=4, W=160, H=120, seed=0, n_init=6000, white_background=False):
+def make_scene(out_dir, n_train=24, n_test=4, W=160, H=120, seed=0, n_init=6000, white_background=False, n_gt=3000, gt_scale=0.035):
     from PIL import Image
     from plyfile import PlyData, PlyElement
     os.makedirs(os.path.join(out_dir, "train"), exist_ok=True)
     os.makedirs(os.path.join(out_dir, "test"), exist_ok=True)
-    gt = ground_truth(seed)
+    gt = ground_truth(seed, n_gt, gt_scale)
     rng = np.random.default_rng(seed + 1)
     bg = (1.0, 1.0, 1.0) if white_background else (0.0, 0.0, 0.0)
     for split, n in (("train", n_train), ("test", n_test)):
@@ -108,6 +108,9 @@ if __name__ == "__main__":
     ap.add_argument("out")
     ap.add_argument("--views", type=int, default=24)
     ap.add_argument("--size", type=int, nargs=2, default=[160, 120])
+    ap.add_argument("--gt", type=int, default=3000, help="ground-truth Gaussians the images are rendered from")
+    ap.add_argument("--gt-scale", type=float, default=0.035)
+    ap.add_argument("--init", type=int, default=6000, help="points of the initial cloud (points3d.ply)")
     a = ap.parse_args()
-    make_scene(a.out, n_train=a.views, W=a.size[0], H=a.size[1])
+    make_scene(a.out, n_train=a.views, W=a.size[0], H=a.size[1], n_gt=a.gt, gt_scale=a.gt_scale, n_init=a.init)
     print("wrote", a.out)

@@ -676,7 +676,7 @@ def test_integrate_full_size_properties_config5():
 
 
 def test_integrate_config5_gaussian_count_against_oracle():
-    """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 44M instances, tile lists of ~6600 entries) with a 5M-point subsample
+    """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 18M instances, tile lists of ~2700 entries) with a 5M-point subsample
     of its 45M query points, against the oracle on the GPU box's host cores: every output bit-identical."""
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = S.scene_frustum(5_000_000, seed=0, sigma_px=1.5)
@@ -689,7 +689,7 @@ def test_integrate_config5_gaussian_count_against_oracle():
     color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
                                             opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
     torch.cuda.synchronize()
-    assert np.array_equal(radii.cpu().numpy(), orad) and o.num_rendered() > 40_000_000
+    assert np.array_equal(radii.cpu().numpy(), orad) and o.num_rendered() > 15_000_000
     c = color.cpu().numpy()
     assert np.array_equal(bits(c), bits(oc)), [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)]
     a = alpha.cpu().numpy()
