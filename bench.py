@@ -239,11 +239,12 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         "blend_forward": 72 * r_visited_fwd + 60 * N,                # 8(d): 60 B state + 12 B colour per visited entry, 60 B per pixel
         "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,   # 8(d): 72 B per staged entry, 60 + 36 B per pixel, accumulators once
         "preprocess_bwd": p_visible * (316 + 232),
-        "backward_memsets": 4 * P * (3 + 3 + 1 + 3 + 6 + 48 + 3 + 4 + 10),
+        "gather_tile_partials": 68 * r_staged_bwd + R + 8 * P + 68 * P,   # partial records + validity bytes + counts/offsets read, 17 floats per Gaussian written
+        "backward_memsets": 4 * P * 6 + R,                                 # dL_dcov3D (dead output) + the validity bytes
     }
     # bytes this design moves on top of 8(d)'s list: the contributor masks (1 bit per pixel and visited entry = 32 B per entry),
     # written by the forward, read by the backward, and the 32 B footprint conic per entry the forward's cull scan reads
-    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": 32 * r_staged_bwd}
+    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": (32 + 69) * r_staged_bwd}   # masks read; partial record + validity byte written
     kernels = {}
     for name, rec in kernel_times.items():
         avg_ms = rec["total_ms"] / max(1, rec["calls"])
@@ -256,7 +257,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         kernels[name] = ent
     fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "blend_forward")
     fwd_ms = sum(kernels[k]["avg_ms"] for k in fwd_names if k in kernels)
-    bwd_ms = sum(kernels[k]["avg_ms"] for k in ("backward_memsets", "blend_backward", "preprocess_bwd") if k in kernels)
+    bwd_ms = sum(kernels[k]["avg_ms"] for k in ("backward_memsets", "blend_backward", "gather_tile_partials", "preprocess_bwd") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["calls"])
     d = kernels[dom]
     achieved = d.get("GBps", 0.0)

@@ -58,8 +58,10 @@ __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, c
                               float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
-                               const uint32_t* n_contrib, const float* dL_dpixels, float* dL_dmean2D, float* dL_dopacity,
-                               float* dL_dcolors, float* dL_dv2g, uint32_t gx, uint32_t ntiles);
+                               const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
+                               float4* part16, float* part17, uint8_t* part_valid, uint32_t gx, uint32_t ntiles);
+__global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
+                                     const uint8_t* part_valid, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors, float* dL_dv2g);
 __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
                                  uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
@@ -264,7 +266,7 @@ using namespace gof;
 extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
-int gof_abi_version(void) { return 4; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib
+int gof_abi_version(void) { return 5; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
@@ -421,7 +423,24 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     return GOF_OK;
 }
 
-size_t gof_backward_scratch_bytes(int32_t P) { (void)P; return 0; }
+// backward scratch: first instance of every Gaussian in GAUSSIAN-ID order ([P] u32: exclusive scan of tiles_touched -- the partial
+// records of consecutive Gaussians are consecutive in memory, so the gather streams), scan scratch, then per tile instance (R of
+// them) a validity byte, the 17th partial gradient [R] f32 and the 64-byte record of the other 16 [R][16] f32
+struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint8_t* valid; float* part17; float4* part16; };
+static size_t bwd_scratch_layout(int32_t P, uint32_t R, void* base, BwdScratch* o)
+{
+    char* p = static_cast<char*>(base);
+    const size_t p0 = reinterpret_cast<size_t>(p);
+    BwdScratch t;
+    carve(p, t.inst_off, (size_t)(P < 1 ? 1 : P));
+    carve(p, t.scan_tmp, scan_tmp_words((size_t)(P < 1 ? 1 : P)));
+    carve(p, t.valid, (size_t)R + 1);
+    carve(p, t.part17, (size_t)R + 1);
+    carve(p, t.part16, 4 * ((size_t)R + 1));
+    if (o) *o = t;
+    return reinterpret_cast<size_t>(p) - p0;
+}
+size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered) { return bwd_scratch_layout(P, num_rendered, nullptr, nullptr) + ALIGN; }
 
 // stages: 1 = zero-fill + blend_backward (K8), 2 = preprocess_bwd (K9), 3 = both
 static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes,
@@ -430,11 +449,13 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
                  float* dL_dsh_rest, float* dL_dscales, float* dL_drotations, float* dL_dview2gaussian, void* scratch, size_t scratch_bytes,
                  void* stream_)
 {
-    (void)scratch; (void)scratch_bytes;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
+    if (!scratch || scratch_bytes < gof_backward_scratch_bytes(a->P, R)) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
+    BwdScratch ws;
+    bwd_scratch_layout(a->P, R, aligned_base(scratch), &ws);
     if (!dL_dout || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_dview2gaussian ||
         (a->M > 0 && a->shs && !dL_dsh) || !radii) { set_error("a gradient / radii pointer is NULL"); return GOF_E_INVALID; }
     const bool split_sh = a->shs_rest != nullptr;
@@ -459,7 +480,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
       struct Range { char* p; size_t n; } r[6];
       int nr = 0;
       auto add = [&](void* ptr, size_t floats) { if (ptr && floats) { r[nr].p = static_cast<char*>(ptr); r[nr].n = floats * sizeof(float); nr++; } };
-      add(dL_dmeans2D, 3 * P); add(dL_dcolors, 3 * P); add(dL_dopacity, P); add(dL_dcov3D, 6 * P); add(dL_dview2gaussian, 10 * P);
+      add(dL_dcov3D, 6 * P);           // dL_dmeans2D / dL_dcolors / dL_dopacity / dL_dview2gaussian are written completely by gather_tile_partials
       if (dL_dsh && a->M > 0 && !k9_tiled) add(dL_dsh, 3 * P * (size_t)a->M);
       std::sort(r, r + nr, [](const Range& x, const Range& y) { return x.p < y.p; });
       for (int i = 0; i < nr; ) {
@@ -467,15 +488,22 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
           while (j < nr && r[j].p == p0 + n) { n += r[j].n; j++; }
           GOF_HIP_CHECK(hipMemsetAsync(p0, 0, n, stream));
           i = j;
-      } }
+      }
+      if (R > 0) GOF_HIP_CHECK(hipMemsetAsync(ws.valid, 0, (size_t)R, stream)); }
 
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);
+        GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian, d.gx, d.ntiles);
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
+    { GOF_PROFILE("gather_tile_partials", stream);
+      // R == 0: tiles_touched is 0 everywhere, the kernel writes zeros
+      hipLaunchKernelGGL(gather_tile_partials, dim3((unsigned)(((size_t)a->P * 4 + 255) / 256)), dim3(256), 0, stream, a->P, ws.inst_off, g.tiles_touched, ws.part16, ws.part17,
+                         ws.valid, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian);
+      GOF_LAUNCH_CHECK(stream, a->debug); }
     }
     if (!(stages & 2)) return GOF_OK;
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };

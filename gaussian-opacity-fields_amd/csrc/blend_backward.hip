@@ -15,8 +15,12 @@
 //         s_slab[wave][17][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
 //         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
 //         entry and wave kept the LDS busy ~70 % of the time);
-//      4. after the batch, thread j adds the slabs of the waves that visited entry j and issues ONE global atomic per
-//         component: <= 17 atomics per (tile, splat) instead of up to 17 x 256, 64 lanes wide.
+//      4. after the batch, thread j adds the slabs of the waves that visited entry j (in wave order) and STORES the 17 sums as
+//         the partial gradient of that (tile, Gaussian) instance -- plain stores into a record indexed by an instance number e
+//         in which the instances of one Gaussian, and of consecutive Gaussians, are consecutive -- plus a validity byte.  No
+//         global atomic at all: gather_tile_partials (below) then adds the records of every Gaussian in ascending e.  The reference's 17
+//         atomicAdd per contributing pair (and round 1's 45 M memory-side float atomics per frame, 795 MB of "writes" for
+//         67 MB of accumulators) are gone, and the gradients are bit-reproducible from run to run.
 //  * Entries behind the last contributor of EVERY pixel of the tile are never staged: the
 //    traversal starts at max-over-tile(last_contributor) (the reference stages the full list and
 //    skips per pixel, backward.cu:763-765).
@@ -37,7 +41,6 @@
 // the depth gradient goes only to contributor == max_contributor-1 (backward.cu:880-882);
 // dL_dmean2D.z accumulates |.| (backward.cu:908-909).
 #include "gof_common.h"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace gof {
 
@@ -105,8 +108,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-               const float* __restrict__ dL_dpixels, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
-               float* __restrict__ dL_dcolors, float* __restrict__ dL_dv2g, uint32_t gx, uint32_t ntiles)
+               const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
+               float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx, uint32_t ntiles)
 {
     const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -132,7 +135,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     //   q0 = {v0, v1 | v1, v3}, q1 = {v2, v4 | v2, v6}, q2 = {v4, v7 | v5, v8}   (prelude, as in blend_forward)
     //   q3 = {CC, w | r, g}, q4 = {b, - | mean2D.x, mean2D.y}, q5 = {conic.x, conic.z | conic.y, conic.y}
     __shared__ f4 s_rec[6][BATCH];
-    __shared__ uint32_t s_id[BATCH];
+    __shared__ uint32_t s_inst[BATCH];                 // instance index of the staged (tile, Gaussian) pair
     __shared__ float s_slab[4][NGRAD][BATCH];          // per wave: the wave totals of the entries it visited in this batch
     __shared__ uint32_t s_vis[4][BATCH / 32];           // per wave: which entries those are
     __shared__ uint32_t s_cm[BATCH / 32][TILE_PIX];
@@ -201,7 +204,10 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                 s_rec[3][tid] = f4{ c.y, c.z, c.w, d.x };
                 s_rec[4][tid] = f4{ d.y, 0.f, d.z, d.w };
                 s_rec[5][tid] = f4{ co.x, co.z, co.y, co.y };
-                s_id[tid] = id;
+                // index of this (tile, Gaussian) instance: instances are numbered Gaussian by Gaussian (in id order), within a Gaussian
+                // row by row over its tile rectangle: e = first(id) + (ty - miny) * w + (tx - minx)
+                const uint2 rc = rect[id];
+                s_inst[tid] = inst_off[id] + (ty - (rc.x >> 16)) * (rc.y & 0xFFFFu) + (tx - (rc.x & 0xFFFFu));
             }
             const int nw = (n + 31) >> 5;
 #pragma unroll
@@ -372,28 +378,117 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
             if (lane == 0) s_vis[wave][w] = visited;
         }
         __syncthreads();
-        // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, then one global atomic
-        // per component, 64 lanes wide
+        // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, stored as the partial
+        // gradient record of this (tile, Gaussian) instance
         if ((int)tid < n) {
             const uint32_t qw = tid >> 5, qb = 1u << (tid & 31u);
             const bool v0 = (s_vis[0][qw] & qb) != 0u, v1 = (s_vis[1][qw] & qb) != 0u, v2 = (s_vis[2][qw] & qb) != 0u, v3 = (s_vis[3][qw] & qb) != 0u;
             if (v0 | v1 | v2 | v3) {
-                const size_t id = s_id[tid];
-                float* const dst[4] = { dL_dcolors + id * 3, dL_dmean2D + id * 3, dL_dopacity + id, dL_dv2g + id * 10 };
-                constexpr int first[5] = { 0, 3, 6, 7, 17 };
+                const size_t e = s_inst[tid];
+                auto total = [&](int k) {
+                    float x = v0 ? s_slab[0][k][tid] : 0.f;
+                    x += v1 ? s_slab[1][k][tid] : 0.f;
+                    x += v2 ? s_slab[2][k][tid] : 0.f;
+                    x += v3 ? s_slab[3][k][tid] : 0.f;
+                    return x;
+                };
+                float4* dst = part16 + e * 4;
 #pragma unroll
-                for (int grp = 0; grp < 4; grp++) {
-#pragma unroll
-                    for (int k = first[grp]; k < first[grp + 1]; k++) {
-                        float a = v0 ? s_slab[0][k][tid] : 0.f;
-                        a += v1 ? s_slab[1][k][tid] : 0.f;
-                        a += v2 ? s_slab[2][k][tid] : 0.f;
-                        a += v3 ? s_slab[3][k][tid] : 0.f;
-                        unsafeAtomicAdd(dst[grp] + (k - first[grp]), a);
-                    }
-                }
+                for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
+                part17[e] = total(16);
+                part_valid[e] = 1;
             }
         }
+    }
+}
+
+// Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):
+// writes dL_dcolors [P,3], dL_dmean2D [P,3], dL_dopacity [P], dL_dview2gaussian [P,10] completely (zeros for Gaussians no pixel
+// blended), so none of them needs a memset.  A QUAD of lanes per Gaussian; instances are numbered in Gaussian-id order, so
+// validity bytes, records, counts, offsets and outputs are all visited in ascending address order: lane q of the quad owns values
+// 4q .. 4q+3 of the record, so a record is ONE 64-byte line read by four adjacent lanes (a thread per Gaussian issued four fully
+// address-divergent 16-byte loads per record and a divergent byte load per instance: 0.245 ms, bound by the address units, not by
+// bytes); the validity bytes are read by the quad together (lane q takes instances k0 + q and k0 + 4 + q) and handed round by DPP.
+// (Adding 0.0f for an absent record leaves every bit of the sum unchanged, so the result is that of the plain ordered loop.)
+__global__ void __launch_bounds__(256)
+gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_t* __restrict__ tiles_touched,
+                     const float4* __restrict__ part16, const float* __restrict__ part17, const uint8_t* __restrict__ part_valid,
+                     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dv2g)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2;
+    const uint32_t q = (uint32_t)t & 3u;
+    const bool live = i < P;                              // (no early return: the wave-wide section below wants all 64 lanes)
+    const uint32_t g = (uint32_t)i;
+    const uint32_t n = live ? tiles_touched[g] : 0u;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc17 = 0.f;
+    constexpr uint32_t BIG = 64;          // Gaussians covering more tiles than this are summed by the whole wave (a near, huge splat can
+                                          // cover thousands of tiles: left to its own quad it alone determined the kernel's duration)
+    const size_t e0 = n ? inst_off[g] : 0;
+    // 8 instances per trip: both validity loads first, then all (up to 8) record loads back to back, then the adds in instance order
+#define GOF_GATHER_TRIP(E0, N, K0)                                                                                   \
+    {                                                                                                                  \
+        const uint32_t ka = (K0) + q, kb = (K0) + 4u + q;                                                              \
+        const int va = (ka < (N)) ? (int)part_valid[(E0) + ka] : 0;                                                    \
+        const int vb = (kb < (N)) ? (int)part_valid[(E0) + kb] : 0;                                                    \
+        float4 r[8];                                                                                                   \
+        float r17[8];                                                                                                  \
+        GOF_GATHER_LOAD(E0, K0, 0, va, 0x00) GOF_GATHER_LOAD(E0, K0, 1, va, 0x55) GOF_GATHER_LOAD(E0, K0, 2, va, 0xAA) GOF_GATHER_LOAD(E0, K0, 3, va, 0xFF) \
+        GOF_GATHER_LOAD(E0, K0, 4, vb, 0x00) GOF_GATHER_LOAD(E0, K0, 5, vb, 0x55) GOF_GATHER_LOAD(E0, K0, 6, vb, 0xAA) GOF_GATHER_LOAD(E0, K0, 7, vb, 0xFF) \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc.x += r[j].x; acc.y += r[j].y; acc.z += r[j].z; acc.w += r[j].w; acc17 += r17[j]; }            \
+    }
+#define GOF_GATHER_LOAD(E0, K0, J, V, CTRL)                                                                          \
+        {                                                                                                              \
+            const bool ok = __builtin_amdgcn_update_dpp(0, V, CTRL, 0xf, 0xf, false) != 0;   /* quad_perm [j,j,j,j] */   \
+            const size_t e = (E0) + (K0) + J;                                                                          \
+            r[J] = ok ? part16[e * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+            r17[J] = (ok && q == 0u) ? part17[e] : 0.f;                                                                \
+        }
+    if (n && n <= BIG)
+        for (uint32_t k0 = 0; k0 < n; k0 += 8) GOF_GATHER_TRIP(e0, n, k0)
+    // the big ones, one after the other, by all 16 quads of the wave: quad c takes trips c, c + 16, ...; the 16 partial sums are
+    // added in a fixed tree (row rotations, then across the rows), i.e. still bit-reproducible
+    uint64_t big = __ballot(n > BIG && q == 0u);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (big) {
+        const int owner = __builtin_ctzll(big);                      // lane 4 * (owner quad)
+        big &= big - 1ull;
+        const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)n, owner);
+        const size_t be0 = ((size_t)(uint32_t)__builtin_amdgcn_readlane((int)(e0 >> 32), owner) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e0, owner);
+        float4 keep = acc; float keep17 = acc17;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f); acc17 = 0.f;
+        for (uint32_t k0 = 8u * (lane >> 2); k0 < bn; k0 += 8u * 16u) GOF_GATHER_TRIP(be0, bn, k0)
+        float v5[5] = { acc.x, acc.y, acc.z, acc.w, acc17 };
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            float x = v5[c];
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4  (quads of the row)
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
+            x += __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane ^ 16u) << 2), __float_as_int(x)));
+            x += __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), __float_as_int(x)));
+            v5[c] = x;
+        }
+        const bool mine = (int)(lane & ~3u) == owner;
+        acc = mine ? make_float4(v5[0], v5[1], v5[2], v5[3]) : keep;
+        acc17 = mine ? v5[4] : keep17;
+    }
+#undef GOF_GATHER_LOAD
+#undef GOF_GATHER_TRIP
+    // record layout (blend_backward's flush): [colour 0-2, mean2D 0 | mean2D 1-2, opacity, v2g 0 | v2g 1-4 | v2g 5-8], 17th = v2g 9
+    if (!live) return;
+    const size_t o = (size_t)g;
+    if (q == 0u) {
+        dL_dcolors[o * 3 + 0] = acc.x; dL_dcolors[o * 3 + 1] = acc.y; dL_dcolors[o * 3 + 2] = acc.z;
+        dL_dmean2D[o * 3 + 0] = acc.w;
+        dL_dv2g[o * 10 + 9] = acc17;
+    } else if (q == 1u) {
+        dL_dmean2D[o * 3 + 1] = acc.x; dL_dmean2D[o * 3 + 2] = acc.y;
+        dL_dopacity[o] = acc.z;
+        dL_dv2g[o * 10 + 0] = acc.w;
+    } else {
+        float* d = dL_dv2g + o * 10 + (q == 2u ? 1 : 5);
+        d[0] = acc.x; d[1] = acc.y; d[2] = acc.z; d[3] = acc.w;
     }
 }
 

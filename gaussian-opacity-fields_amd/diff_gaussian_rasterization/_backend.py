@@ -43,7 +43,7 @@ def _load():
     lib.gof_last_error.restype = C.c_char_p
     lib.gof_abi_version.restype = C.c_int
     for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]),
-                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32]), ("gof_mtets_tet_ws_bytes", [i64]),
+                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32, u32]), ("gof_mtets_tet_ws_bytes", [i64]),
                        ("gof_mtets_edge_ws_bytes", [i64])):
         f = getattr(lib, name)
         f.restype = sz
@@ -279,7 +279,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):
-            nscratch = lib.gof_backward_scratch_bytes(P)
+            nscratch = lib.gof_backward_scratch_bytes(P, int(R))
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),

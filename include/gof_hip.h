@@ -130,8 +130,10 @@ int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
                       int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, void* stream);
 
 /* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
-/* Scratch the backward needs besides the outputs (accumulators); may be 0. */
-size_t gof_backward_scratch_bytes(int32_t P);
+/* Scratch the backward needs besides the outputs: per tile instance (num_rendered of them) the 68-byte partial gradient record the
+ * per-pixel backward stores and the per-Gaussian gather adds up (no atomics), plus P offsets.  num_rendered = the
+ * value the backward is called with. */
+size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered);
 /* dL_dout is [9,H,W].  All gradient outputs are fully written by the call (the library
  * zero-fills them itself; the reference binding allocates them with torch::zeros,
  * rasterize_points.cu:161-170).  dL_dcov3D [P,6] is all zero in the reference (its producer
@@ -153,11 +155,11 @@ int gof_backward(const GofRasterArgs* args,
                  float* dL_dscales,         /* [P,3]  */
                  float* dL_drotations,      /* [P,4]  */
                  float* dL_dview2gaussian,  /* [P,10] */
-                 void* scratch, size_t scratch_bytes,  /* gof_backward_scratch_bytes(P); NULL if 0 */
+                 void* scratch, size_t scratch_bytes,  /* gof_backward_scratch_bytes(P, num_rendered) */
                  void* stream);
 
-/* The two stages of gof_backward as separate calls with the SAME argument list: gof_backward_blend zero-fills the accumulators
- * and runs the per-pixel backward (afterwards dL_dmeans2D, dL_dcolors, dL_dopacity and dL_dview2gaussian are final),
+/* The two stages of gof_backward as separate calls with the SAME argument list: gof_backward_blend runs the per-pixel backward
+ * and the per-Gaussian gather of its partial sums (afterwards dL_dmeans2D, dL_dcolors, dL_dopacity and dL_dview2gaussian are final),
  * gof_backward_preprocess turns them into the parameter gradients.  A data-parallel trainer starts the exchange of the colour
  * gradient between the two (dp/reducer.py); gof_backward = one after the other. */
 #define GOF_BACKWARD_ARGS                                                                                                          \

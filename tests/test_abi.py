@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported():
 def test_size_queries_are_host_only_and_monotone():
     from diff_gaussian_rasterization import _backend as B
     L = B.lib
-    assert L.gof_abi_version() >= 4
+    assert L.gof_abi_version() >= 5
     assert L.gof_geom_bytes(0) > 0
     assert L.gof_geom_bytes(1000) < L.gof_geom_bytes(100000)
     assert L.gof_geom_bytes(1_000_000) >= 1_000_000 * (64 + 16 + 4 + 4 + 4 + 1)
