@@ -6,16 +6,17 @@
 // MI355X design:
 //  * The reference issues 17 global fp32 atomicAdd per contributing (pixel, splat) pair
 //    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave (an 8x8 pixel quadrant) look at the SAME splat
-//    at the same time, and the 17 partial gradients are summed IN REGISTERS over the whole wave:
-//      1. a TRANSPOSED reduction of 16 of the values: every level halves the number of live values per lane -- the half-wave and
+//    at the same time, and the partial gradients are summed IN REGISTERS over the whole wave (16 of the 17: the last one,
+//    dL_dview2gaussian[9] = -0.5 w G dL_dalpha, is -0.5 w times the opacity gradient with w a constant of the Gaussian):
+//      1. a TRANSPOSED reduction of the 16 values: every level halves the number of live values per lane -- the half-wave and
 //         row levels with v_permlane32_swap / v_permlane16_swap (gfx950; no selects), the two quad levels with DPP and selects,
-//         two row rotations finish; the 17th value by a plain DPP row sum and two ds_bpermute exchanges;
+//         two row rotations finish;
 //      2. lane l ends with the wave total of value 8 b1 + 4 b0 + 2 p + h (lane bits 0, 1, row parity, wave half);
-//      3. ONE plain LDS store (16 active lanes) + one for the 17th value put the totals into the wave's own slab
-//         s_slab[wave][17][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
+//      3. ONE plain LDS store (16 active lanes) puts the totals into the wave's own slab
+//         s_slab[wave][16][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
 //         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
 //         entry and wave kept the LDS busy ~70 % of the time);
-//      4. after the batch, thread j adds the slabs of the waves that visited entry j (in wave order) and STORES the 17 sums as
+//      4. after the batch, thread j adds the slabs of the waves that visited entry j (in wave order) and STORES the 16 sums (and the 17th value derived from the opacity sum) as
 //         the partial gradient of that (tile, Gaussian) instance -- plain stores into a record indexed by an instance number e
 //         in which the instances of one Gaussian, and of consecutive Gaussians, are consecutive -- plus a validity byte.  No
 //         global atomic at all: gather_tile_partials (below) then adds the records of every Gaussian in ascending e.  The reference's 17
@@ -44,9 +45,9 @@
 
 namespace gof {
 
-constexpr int NGRAD = 17;   // colour 3, mean2D 3, opacity 1, view2gaussian 10
-// tile-list entries staged per batch.  64 keeps the LDS footprint (records 6 KB, masks 2 KB, four per-wave slabs 17 KB) at
-// 26 KB, so that occupancy is bounded by registers (5 waves/SIMD), not by LDS.
+constexpr int NGRAD = 16;   // colour 3, mean2D 3, opacity 1, view2gaussian 0..8 -- reduced per (wave, entry); view2gaussian 9 follows from the opacity total
+// tile-list entries staged per batch.  64 keeps the LDS footprint (records 6 KB, masks 2 KB, four per-wave slabs 16 KB) at
+// 25 KB, so that occupancy is bounded by registers (5 waves/SIMD), not by LDS.
 #ifndef GOF_BW_BATCH
 #define GOF_BW_BATCH 64
 #endif
@@ -337,10 +338,11 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     g[13] = g1314.x;
                     g[14] = g1314.y;
                     g[15] = dL_dB2;
-                    g[16] = dL_dmin_value;
+                    // dL_dv2g[9] = dL_dmin_value = -0.5 wgt (G dL_dalpha) = -0.5 wgt g[6] with wgt a constant of the Gaussian: its total is
+                    // formed from the total of g[6] at the flush, not reduced here
                     }
                 }
-                // wave total of the 17 values.  16 of them by a transposed reduction whose first two levels use gfx950's lane-group
+                // wave total of the 16 values by a transposed reduction whose first two levels use gfx950's lane-group
                 // swaps (no selects): v_permlane32_swap exchanges the upper half of one register with the lower half of another, so
                 // x + y afterwards holds value A summed over the halves in lanes 0-31 and value B in lanes 32-63; v_permlane16_swap
                 // does the same for odd / even rows.  16 -> 8 -> 4 live values; two DPP quad levels with selects 4 -> 2 -> 1; two row
@@ -369,11 +371,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                     tot = tot + dpp_get<0x124>(tot);                  // row_ror:4
                     tot = tot + dpp_get<0x128>(tot);                  // row_ror:8
                 }
-                float g16 = row_sum(g[16]);
-                g16 = g16 + lane_xor(g16, lane, 16u);
-                g16 = g16 + lane_xor(g16, lane, 32u);
                 if ((lane & 12u) == 0u) s_slab[wave][slab_row][j] = tot;
-                if (lane == 63u) s_slab[wave][16][j] = g16;
             }
             if (lane == 0) s_vis[wave][w] = visited;
         }
@@ -395,7 +393,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                 float4* dst = part16 + e * 4;
 #pragma unroll
                 for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
-                part17[e] = total(16);
+                part17[e] = -0.5f * s_rec[3][tid].y * total(6);      // dL_dv2g[9], see the gradient block
                 part_valid[e] = 1;
             }
         }

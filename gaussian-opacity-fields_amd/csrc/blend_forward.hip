@@ -44,7 +44,8 @@ namespace gof {
 // scan/consume granularity inside a staged batch: smaller = finer early exit once a wave saturates,
 // larger = better lane compaction in phase 2
 #ifndef GOF_FW_CHUNK
-#define GOF_FW_CHUNK 64      // measured A/B at S1M: 64 -> 1.066 ms, 128 -> 1.08 ms, 256 -> 1.14 ms
+#define GOF_FW_CHUNK 256     // measured A/B at S1M with the packed conic scan: 32 -> 0.932 ms, 64 -> 0.898, 128 -> 0.891, 256 -> 0.887 (the scan is cheap now:
+                             // scanning past a pixel's saturation costs less than the lane compaction of a longer candidate run gains)
 #endif
 constexpr int FW_CHUNK = GOF_FW_CHUNK;
 
@@ -58,7 +59,10 @@ __device__ unsigned long long g_fw_stats[8];
 #define STAT_ADD(i, v)
 #endif
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
+#ifndef GOF_FW_WAVES
+#define GOF_FW_WAVES 4       // LDS bounds the occupancy at 5 workgroups per CU; asking for 4 leaves the allocator more room (88 VGPR, measured -1 %)
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
 blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
               const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,

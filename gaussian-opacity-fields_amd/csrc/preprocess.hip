@@ -211,6 +211,9 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     return make_float4((float)fmax(-1e9, ceil(px0)), (float)fmin(1e9, floor(px1)), (float)fmax(-1e9, ceil(py0)), (float)fmin(1e9, floor(py1)));
 }
 
+#ifdef GOF_PRE_WAVES
+__attribute__((amdgpu_waves_per_eu(GOF_PRE_WAVES, 8)))
+#endif
 __global__ void __launch_bounds__(256)
 preprocess_fwd(int P, int D, int M,
                const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
