@@ -443,6 +443,29 @@ def integrate_leg(dev, P=5_000_000, W=1600, H=1063):
             B.profile_enable(False)
         legs[name] = {"wall_ms": round(min(ts), 3), "kernels_ms": {k: round(v["total_ms"] / max(1, v["calls"]), 4) for k, v in reps.items()}}
     n_in_view = int((out[1] != 1.0).sum().item())
+    # one step of extract_mesh.py's view loop (:24-29) for a cached view: the call + the reduction over views, as the script composes it
+    # (ones / zeros outputs, torch.where, torch.min) and with the reduction fused into the point pass (integrate_min_into)
+    PNv = int(pts.shape[0])
+    fa = torch.ones(PNv, device=dev); fc = torch.ones(PNv, 3, device=dev)
+    def step_torch():
+        nonlocal fa, fc
+        o = call()
+        fc = torch.where((o[1] < fa).reshape(-1, 1), o[2], fc)
+        fa = torch.min(fa, o[1])
+    def step_fused():
+        with DGR.integrate_min_into(fa, fc):
+            call()
+    for name, fn in (("script_composition", step_torch), ("fused_into_the_point_pass", step_fused)):
+        ts = []
+        for _ in range(3):
+            fa.fill_(1.0); fc.fill_(1.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        legs.setdefault("view_loop_step_cached_view_with_colour", {})[name + "_wall_ms"] = round(min(ts), 3)
+    del fa, fc
     DGR.integrate_view_cache().clear()
     PN = int(pts.shape[0])
     res = {"workload": "integrate: %d Gaussians, %d query points (9 per Gaussian), %dx%d, one view" % (P, PN, W, H),

@@ -68,7 +68,7 @@ __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* g
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
                                  const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
-                                 float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, uint32_t gx, uint32_t ntiles);
+                                 float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, int acc_min, uint32_t gx, uint32_t ntiles);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
                              const uint32_t* sort_error);
@@ -266,7 +266,7 @@ using namespace gof;
 extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
-int gof_abi_version(void) { return 5; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib
+int gof_abi_version(void) { return 6; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
@@ -618,7 +618,7 @@ int gof_integrate_pack_geom(const GofRasterArgs* a, const void* geom_ws, size_t 
     return GOF_OK;
 }
 
-static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI, bool packed,
+static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI, bool packed, bool acc_min,
                          const void* geom_ws, size_t geom_bytes, const void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
                          void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
                          const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
@@ -627,7 +627,8 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     int rc = validate(a);
     if (rc) return rc;
     if (a->P == 0 || PN <= 0) return GOF_OK;     // rasterize_points.cu:301
-    if (!base_color || !out_color || !out_alpha_integrated || !out_color_integrated) { set_error("an output pointer is NULL"); return GOF_E_INVALID; }
+    // the accumulating variants may leave out the image and the colour
+    if (!base_color || !out_alpha_integrated || (!acc_min && (!out_color || !out_color_integrated))) { set_error("an output pointer is NULL"); return GOF_E_INVALID; }
     if (geom_bytes < (packed ? gof_integrate_packed_geom_bytes(a->P) : gof_geom_bytes(a->P)) || image_bytes < gof_image_bytes(a->W, a->H) ||
         binning_bytes < gof_binning_bytes(R, a->W, a->H) ||
         point_bytes < gof_point_bytes(PN) || point_binning_bytes < gof_point_binning_bytes(NI, a->W, a->H)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
@@ -665,7 +666,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, im.point_ranges, b.vals, pb.vals, rec_ptr, zfront_ptr, zstride, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
-                       base_color, out_color, out_alpha_integrated, out_color_integrated, im.n_contrib, d.gx, d.ntiles);
+                       base_color, out_color, out_alpha_integrated, out_color_integrated, im.n_contrib, acc_min ? 1 : 0, d.gx, d.ntiles);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -675,7 +676,7 @@ int gof_integrate_points(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_
                          void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
                          const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
 {
-    return integrate_points_impl(a, R, PN, NI, false, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
+    return integrate_points_impl(a, R, PN, NI, false, false, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
                                  point_binning_ws, point_binning_bytes, base_color, out_color, out_alpha_integrated, out_color_integrated, stream_);
 }
 int gof_integrate_points_packed(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI,
@@ -683,8 +684,17 @@ int gof_integrate_points_packed(const GofRasterArgs* a, uint32_t R, int32_t PN, 
                          void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
                          const float* base_color, float* out_color, float* out_alpha_integrated, float* out_color_integrated, void* stream_)
 {
-    return integrate_points_impl(a, R, PN, NI, true, packed_geom, packed_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
+    return integrate_points_impl(a, R, PN, NI, true, false, packed_geom, packed_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws, point_bytes,
                                  point_binning_ws, point_binning_bytes, base_color, out_color, out_alpha_integrated, out_color_integrated, stream_);
+}
+
+int gof_integrate_points_min(const GofRasterArgs* a, uint32_t R, int32_t PN, uint32_t NI, int32_t packed,
+                             const void* geom_ws, size_t geom_bytes, const void* binning_ws, size_t binning_bytes, void* image_ws, size_t image_bytes,
+                             void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                             const float* base_color, float* out_color, float* alpha_min_inout, float* color_min_inout, void* stream_)
+{
+    return integrate_points_impl(a, R, PN, NI, packed != 0, true, geom_ws, geom_bytes, binning_ws, binning_bytes, image_ws, image_bytes, point_ws,
+                                 point_bytes, point_binning_ws, point_binning_bytes, base_color, out_color, alpha_min_inout, color_min_inout, stream_);
 }
 
 int gof_integrate_run(const GofRasterArgs* a, uint32_t R, const int32_t* radii, int32_t PN, uint32_t NI,

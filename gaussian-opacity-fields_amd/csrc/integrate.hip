@@ -258,7 +258,7 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                  const SplatRec* __restrict__ rec, const float* __restrict__ zfront, int zstride, const uint32_t* __restrict__ cmask, int W, int H,
                  float focal_x, float focal_y, const float2* __restrict__ pt_xy, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
                  float* __restrict__ pt_acc, const float* __restrict__ base_color, float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
-                 float* __restrict__ out_color_integrated, const uint32_t* __restrict__ n_contrib, uint32_t gx, uint32_t ntiles)
+                 float* __restrict__ out_color_integrated, const uint32_t* __restrict__ n_contrib, int acc_min, uint32_t gx, uint32_t ntiles)
 {
     const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
@@ -273,12 +273,13 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
 
     const uint2 range = gaussian_ranges[tile];
     const uint2 prange = point_ranges[tile];
-    if (base_color != out_color && inside) {
+    // out_color == nullptr (accumulating calls of a mesh-extraction driver): no image is produced
+    if (out_color && base_color != out_color && inside) {
 #pragma unroll
         for (int c = 0; c < 8; c++) out_color[c * HW + pix_id] = base_color[c * HW + pix_id];
     }
     if (prange.y <= prange.x) {                        // no query point in this tile: channel 8 = 0
-        if (inside) out_color[8 * HW + pix_id] = 0.0f;
+        if (out_color && inside) out_color[8 * HW + pix_id] = 0.0f;
         return;
     }
     // only list positions up to the tile's last contributor (n_contrib, written by integrate_pixels) carry mask bits -- and only
@@ -363,16 +364,29 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             if (!last_batch) { pt_T[pi] = T; pt_acc[pi] = acc; }
             else {
                 const uint32_t pid = point_list[pi];
-                out_alpha_integrated[pid] = acc;
-                const uint32_t ppx = (uint32_t)xy.x, ppy = (uint32_t)xy.y;
-                const size_t ppix = (size_t)W * ppy + ppx;
-                out_color_integrated[3 * (size_t)pid + 0] = base_color[0 * HW + ppix];
-                out_color_integrated[3 * (size_t)pid + 1] = base_color[1 * HW + ppix];
-                out_color_integrated[3 * (size_t)pid + 2] = base_color[2 * HW + ppix];
+                // acc_min: the caller's buffers hold the running minimum over the views queried so far and the colour of the view that
+                // attained it -- extract_mesh.py:26-29 (final_color = where(alpha < final_alpha, color, final_color); final_alpha =
+                // min(final_alpha, alpha)) fused into the store; a point outside this view keeps its values (its alpha here is 1).
+                // torch.min propagates NaN, `<` does not select it: alpha becomes NaN, the colour stays.
+                bool take = true, take_color = true;
+                if (acc_min) {
+                    const float old = out_alpha_integrated[pid];
+                    take_color = acc < old;
+                    take = take_color || (acc != acc);
+                }
+                if (take) out_alpha_integrated[pid] = acc;
+                if (take_color && out_color_integrated) {
+                    const uint32_t ppx = (uint32_t)xy.x, ppy = (uint32_t)xy.y;
+                    const size_t ppix = (size_t)W * ppy + ppx;
+                    out_color_integrated[3 * (size_t)pid + 0] = base_color[0 * HW + ppix];
+                    out_color_integrated[3 * (size_t)pid + 1] = base_color[1 * HW + ppix];
+                    out_color_integrated[3 * (size_t)pid + 2] = base_color[2 * HW + ppix];
+                }
             }
         }
     }
     __syncthreads();
+    if (!out_color) return;                             // channel 8 is the only thing left to compute
 
     // number of outer-loop iterations the reference's block would run: max over pixels of
     // max(1, ceil(points_in_pixel / 256))

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _backend as _C
-from ._backend import integrate_view_key, integrate_view_cache, IntegrateViewCache   # noqa: F401  (mesh-extraction driver fusion, NEW)
+from ._backend import integrate_view_key, integrate_view_cache, IntegrateViewCache, integrate_min_into   # noqa: F401  (mesh-extraction driver fusion, NEW)
 
 
 class GaussianRasterizationSettings(NamedTuple):

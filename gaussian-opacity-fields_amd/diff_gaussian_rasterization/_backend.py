@@ -60,6 +60,7 @@ def _load():
     lib.gof_integrate_view.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.gof_integrate_points.argtypes = [A, u32, i32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     lib.gof_integrate_points_packed.argtypes = lib.gof_integrate_points.argtypes
+    lib.gof_integrate_points_min.argtypes = [A, u32, i32, u32, i32, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     lib.gof_integrate_pack_geom.argtypes = [A, vp, sz, vp, sz, vp]
     lib.gof_integrate_packed_geom_bytes.restype = sz
     lib.gof_integrate_packed_geom_bytes.argtypes = [i32]
@@ -77,7 +78,7 @@ def _load():
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
     for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
-                 "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_integrate_points_packed", "gof_integrate_pack_geom", "gof_mark_visible", "gof_mtets_classify", "gof_mtets_count", "gof_mtets_emit"):
+                 "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_integrate_points_packed", "gof_integrate_points_min", "gof_integrate_pack_geom", "gof_mark_visible", "gof_mtets_classify", "gof_mtets_count", "gof_mtets_emit"):
         getattr(lib, name).restype = C.c_int
     return lib
 
@@ -429,6 +430,30 @@ def integrate_view_cache():
     return _view_cache
 
 
+_integrate_acc = threading.local()
+
+
+class integrate_min_into:
+    """Context manager: `with integrate_min_into(alpha_min, color=None): rasterizer.integrate(points, ...)` -- the call min-combines its
+    alpha_integrated into `alpha_min` [N] (float32, filled with 1 before the first view) in the kernel's final store and, where it
+    lowers the minimum, writes the view's colour into `color` [N, 3]: the reduction over views of reference extract_mesh.py:17-34
+    (`final_color = where(alpha < final_alpha, color, final_color); final_alpha = min(final_alpha, alpha)`) without the per-view
+    `ones` / `zeros` fills and the separate min / where passes.  The call returns the two buffers as alpha_integrated /
+    color_integrated and the view's base image as its colour output (gof_integrate_points_min)."""
+
+    def __init__(self, alpha_min, color=None):
+        self.value = (alpha_min, color)
+
+    def __enter__(self):
+        self.prev = getattr(_integrate_acc, "value", None)
+        _integrate_acc.value = self.value
+        return self
+
+    def __exit__(self, *exc):
+        _integrate_acc.value = self.prev
+        return False
+
+
 def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity, scales, rotations, scale_modifier,
                                   cov3D_precomp, view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                   kernel_size, subpixel_offset, image_height, image_width, sh, degree, campos,
@@ -445,10 +470,21 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
     PN = int(points3D.size(0))
     pts = _dev_f32(points3D, dev, "points3D")
     f = dict(dtype=torch.float32, device=dev)
+    acc = getattr(_integrate_acc, "value", None)
+    if acc is not None:
+        acc_alpha, acc_color = acc
+        if acc_alpha.dtype != torch.float32 or acc_alpha.device != dev or not acc_alpha.is_contiguous() or acc_alpha.numel() != PN:
+            raise RuntimeError("integrate_min_into: alpha buffer must be a contiguous float32 tensor of %d elements on %s" % (PN, dev))
+        if acc_color is not None and (acc_color.dtype != torch.float32 or acc_color.device != dev or not acc_color.is_contiguous()
+                                      or tuple(acc_color.shape) != (PN, 3)):
+            raise RuntimeError("integrate_min_into: colour buffer must be a contiguous float32 [%d, 3] tensor on %s" % (PN, dev))
     with torch.cuda.device(dev):
         out_color = torch.zeros((OUTPUT_CHANNELS, v.H, v.W), **f)
-        out_alpha = torch.ones((PN,), **f)            # rasterize_points.cu:277
-        out_color_pts = torch.zeros((PN, 3), **f)     # rasterize_points.cu:278
+        if acc is None:
+            out_alpha = torch.ones((PN,), **f)            # rasterize_points.cu:277
+            out_color_pts = torch.zeros((PN, 3), **f)     # rasterize_points.cu:278
+        else:
+            out_alpha, out_color_pts = acc                # nothing to fill: the running buffers are updated in place
         radii = torch.zeros(v.P, dtype=torch.int32, device=dev)
         empty = v.bytes_tensor(0)
         if v.P == 0 or PN == 0:
@@ -478,6 +514,14 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
         ni = C.c_uint32(0)
         _check(lib.gof_integrate_prepare_points(v.ref(), PN, _ptr(pts), _ptr(pws), pws.numel(), C.byref(ni), _stream()))
         pbin = v.bytes_tensor(lib.gof_point_binning_bytes(int(ni.value), v.W, v.H))
+        if acc is not None:
+            # min-accumulating call (integrate_min_into): the running minimum / arg-min colour buffers of the driver are the outputs
+            acc_alpha, acc_color = acc
+            _check(lib.gof_integrate_points_min(v.ref(), rendered, PN, int(ni.value), 1 if points_fn is lib.gof_integrate_points_packed else 0,
+                                                _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+                                                _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), None,
+                                                _ptr(acc_alpha), None if acc_color is None else _ptr(acc_color), _stream()))
+            return rendered, base, acc_alpha, acc_color, radii, geom, binning, img
         _check(points_fn(v.ref(), rendered, PN, int(ni.value), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                         _ptr(img), img.numel(), _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), _ptr(out_color),
                                         _ptr(out_alpha), _ptr(out_color_pts), _stream()))

@@ -233,6 +233,19 @@ int gof_integrate_points_packed(const GofRasterArgs* args, uint32_t num_rendered
                                 const float* base_color, float* out_color,
                                 float* out_alpha_integrated, float* out_color_integrated, void* stream);
 
+/* gof_integrate_points / _packed (packed != 0) with the reduction over views of extract_mesh.py:17-34 (evaluage_alpha) fused into
+ * the store: alpha_min_inout [PN] holds the running minimum of alpha_integrated over the views queried so far (the caller fills it
+ * with 1 before the first view) and color_min_inout [PN,3] (NULL: not wanted) the colour of the view that attained it:
+ *     color = where(alpha < alpha_min, color_view, color);  alpha_min = min(alpha_min, alpha)      (NaN propagates as in torch.min)
+ * A point outside this view is left untouched (its alpha_integrated would be 1).  out_color (the [9,H,W] image + channel 8) may be
+ * NULL: a mesh-extraction driver does not read it. */
+int gof_integrate_points_min(const GofRasterArgs* args, uint32_t num_rendered, int32_t PN, uint32_t num_integrated, int32_t packed,
+                             const void* geom_ws_or_packed, size_t geom_bytes, const void* binning_ws, size_t binning_bytes,
+                             void* image_ws, size_t image_bytes,
+                             void* point_ws, size_t point_bytes, void* point_binning_ws, size_t point_binning_bytes,
+                             const float* base_color, float* out_color,
+                             float* alpha_min_inout, float* color_min_inout, void* stream);
+
 /* ---- mark_visible (replaces _C.mark_visible, rasterize_points.cu:213-232) -------------- */
 int gof_mark_visible(int32_t P, const float* means3D,
                      const float* viewmatrix, const float* projmatrix,

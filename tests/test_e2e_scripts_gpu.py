@@ -14,7 +14,8 @@ launch/run_train_dp.py exactly as INTEGRATION.md tells a user to start them.
   * render.py on the trained model (forward-only use): 4 test renderings whose PSNR against the written ground truths matches what
     train.py reported.
   * extract_mesh.py on the trained model (Delaunay by the scipy stand-in, opacity-field queries, HIP marching tetrahedra, the 8-step
-    bisection): writes a non-empty mesh; with the per-view integrate cache disabled the mesh is byte-identical.
+    bisection): writes a non-empty mesh; with the per-view integrate cache disabled and the script's own view loop in place of the
+    launcher's fused one (mesh_extraction.evaluate_alpha) the mesh is byte-identical.
   * 2-rank data-parallel training (run_train_dp.py, both ranks on this GPU, gloo): both ranks finish, the replicas stay
     bit-identical throughout (parameters, reduced gradients, 3D filter: checked every 25 steps), both ranks report the same test
     PSNR, rank 0 saves a finite model, and the final PSNR is within 2.5 dB of the single-process run.
@@ -170,10 +171,11 @@ def test_extract_mesh_py_runs_unchanged(trained):
     hdr = first[:first.index(b"end_header")].decode()
     nv, nf = int(re.search(r"element vertex (\d+)", hdr).group(1)), int(re.search(r"element face (\d+)", hdr).group(1))
     assert nv > 500 and nf > 500, hdr
-    # second run: the Delaunay cells are re-used from cells.pt (extract_mesh.py:45-47); no per-view cache of the Gaussian side
-    out2 = _run(cmd, _env(GOF_INTEGRATE_CACHE_GB="0"), timeout=1500)
+    # second run: the Delaunay cells are re-used from cells.pt (extract_mesh.py:45-47); no per-view cache of the Gaussian side, and the
+    # script's OWN evaluage_alpha (per-view outputs + torch.min / torch.where) instead of the view loop with the fused reduction
+    out2 = _run(cmd, _env(GOF_INTEGRATE_CACHE_GB="0", GOF_TORCH_VIEW_REDUCE="1"), timeout=1500)
     assert "load existing cells" in out2
-    assert open(mesh, "rb").read() == first, "mesh differs between cached and uncached opacity-field queries"
+    assert open(mesh, "rb").read() == first, "mesh differs between (cached, fused view reduction) and (uncached, the script's own view loop)"
     # the surface of the fitted blobs lies inside the scene box
     body = np.frombuffer(first[first.index(b"end_header") + len(b"end_header\n"):][:nv * 12], dtype="<f4").reshape(nv, 3)
     assert np.isfinite(body).all() and np.percentile(np.abs(body), 90) < 2.0
