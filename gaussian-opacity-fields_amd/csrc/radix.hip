@@ -163,16 +163,19 @@ hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* ou
 // radix sort
 // ---------------------------------------------------------------------------------------------------
 // mask of the lanes (among `valid`) whose 8-bit digit equals this lane's digit
+// Per bit: s = the bit spread over a word (v_bfe_i32), its ballot, and peers &= ~(ballot ^ s) as ONE three-input boolean
+// instruction per half (v_bitop3_b32, gfx950; truth table a & ~(b ^ c) = 0x90): 4-5 VALU per bit where select + xor + and took 8.
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid)
 {
-    uint64_t peers = valid;
+    uint32_t lo = (uint32_t)valid, hi = (uint32_t)(valid >> 32);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);      // 0 or 0xFFFFFFFF
+        const uint64_t bal = __ballot(s != 0u);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, s, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), s, 0x90);
     }
-    return peers;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // ---- block kernels: 256 threads, RS_BLOCK items; wave w owns the contiguous quarter [w*RS_BLOCK/4, ...) ----
