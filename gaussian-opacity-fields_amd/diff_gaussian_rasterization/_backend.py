@@ -502,13 +502,14 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
                 # keep only what the point pass reads of the geometry workspace (records + front depths: 68 of ~220 B per Gaussian)
                 packed = v.bytes_tensor(lib.gof_integrate_packed_geom_bytes(v.P))
                 _check(lib.gof_integrate_pack_geom(v.ref(), _ptr(geom), geom.numel(), _ptr(packed), packed.numel(), _stream()))
-                if _view_cache.put(key, (packed, img, binning, radii, rendered, base, v.P, v.W, v.H)):
+                if _view_cache.put(key, (packed, img, binning, radii, rendered, base, v.P, v.W, v.H)) and acc is None:
                     out_color = torch.empty_like(base)     # the cached base image must stay untouched by channel 8
         else:
             geom, img, binning, radii, rendered, base, cP, cW, cH = entry
             if (cP, cW, cH) != (v.P, v.W, v.H):
                 raise RuntimeError("integrate view cache: key %r was announced for a different problem size" % (key,))
-            out_color = torch.empty_like(base)
+            if acc is None:
+                out_color = torch.empty_like(base)
             points_fn = lib.gof_integrate_points_packed
         pws = v.bytes_tensor(lib.gof_point_bytes(PN))
         ni = C.c_uint32(0)
@@ -521,7 +522,8 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
                                                 _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
                                                 _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), None,
                                                 _ptr(acc_alpha), None if acc_color is None else _ptr(acc_color), _stream()))
-            return rendered, base, acc_alpha, acc_color, radii, geom, binning, img
+            # the image handed back must not alias the cached base image of the view (a caller may write into it)
+            return rendered, (base.clone() if key is not None else base), acc_alpha, acc_color, radii, geom, binning, img
         _check(points_fn(v.ref(), rendered, PN, int(ni.value), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                         _ptr(img), img.numel(), _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), _ptr(out_color),
                                         _ptr(out_alpha), _ptr(out_color_pts), _stream()))
