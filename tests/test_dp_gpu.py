@@ -100,3 +100,77 @@ def test_two_ranks_dense_and_compressed_gradient_exchange_agree():
         p.join(300)
         assert p.exitcode == 0
     assert all(ret.get(r, (False, "no result"))[0] for r in range(world)), dict(ret)
+
+
+def _worker_rccl(port, ret):
+    """One rank, backend "nccl" (= RCCL): world size 1 makes every collective an identity, so the exchange must hand back the local
+    gradients bit for bit -- while the calls themselves (all_gather_into_tensor of the packed colour gradient, the in-place
+    all-reduce of the shared gradient bucket, the packed fallback) go through RCCL on the GPU exactly as they do at N > 1."""
+    for p in (os.path.join(ROOT, "gaussian-opacity-fields_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import synthetic_scenes as S
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    from dp import GradientAllReducer
+    sd = to_dev(S.scene_lego_like(P=20000, W=200, H=150, seed=8))
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    red = GradientAllReducer(list(params.values()), sh_params=[params["shs"]])
+    color, _ = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                                     opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+    color.backward(torch.randn(color.shape, generator=torch.Generator().manual_seed(3)).to(color.device))
+    local = {k: params[k].grad.clone() for k in names}
+    msg = []
+    assert dist.get_backend() == "nccl"
+    # compressed form: all-gather of 12 B per Gaussian over RCCL + local expansion, all-reduce of the rest in place
+    pending = red._sh_begin(1)
+    if pending is None:
+        msg.append("the compressed SH exchange was not applicable")
+    else:
+        rest = [params[k] for k in names if k != "shs"]
+        finish = red._dense_begin(rest, 1)
+        red._sh_finish(pending, 1)
+        finish()
+        torch.cuda.synchronize()
+        for k in names:
+            if not torch.equal(params[k].grad, local[k]):
+                msg.append("compressed: %s changed (max diff %.3e)" % (k, (params[k].grad - local[k]).abs().max().item()))
+    # dense form over everything: the rasterizer's one allocation reduced in place
+    bucket = red._shared_bucket([params[k].grad for k in names])
+    if bucket is None:
+        msg.append("the gradients of one backward are not one bucket")
+    red._dense_begin([params[k] for k in names], 1)()
+    torch.cuda.synchronize()
+    for k in names:
+        if not torch.equal(params[k].grad, local[k]):
+            msg.append("dense: %s changed" % k)
+    # packed fallback (gradients that are separate allocations), averaged: still the identity at one rank
+    for k in names:
+        params[k].grad = local[k].clone()
+    red_avg = GradientAllReducer(list(params.values()), average=True, track=False)
+    red_avg._dense_begin([params[k] for k in names], 1)()
+    torch.cuda.synchronize()
+    for k in names:
+        if not torch.equal(params[k].grad, local[k]):
+            msg.append("fallback: %s changed" % k)
+    B.set_sh_grad_ready_callback(None)
+    B.track_sh_grad_source(False)
+    ret[0] = (not msg, "; ".join(msg))
+    dist.destroy_process_group()
+
+
+def test_the_exchange_runs_over_rccl_on_one_rank_and_is_the_identity():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_worker_rccl, args=(port, ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert ret.get(0, (False, "no result"))[0], dict(ret)
