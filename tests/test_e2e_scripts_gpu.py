@@ -201,3 +201,21 @@ def test_two_rank_data_parallel_training_on_one_gpu(scene, trained, tmp_path_fac
     v = _load_ply(os.path.join(model, "point_cloud", "iteration_%d" % ITERS, "point_cloud.ply"))["vertex"]
     for nme in ("x", "opacity", "scale_0", "f_dc_0"):
         assert np.isfinite(v[nme]).all(), nme
+
+
+def test_data_parallel_launcher_over_rccl_with_one_rank(scene, tmp_path_factory):
+    """The launcher as it starts on a multi-GPU node -- backend "nccl" (= RCCL), its own HIP_VISIBLE_DEVICES mask, the replica check
+    gathering over RCCL -- with the one rank this box can hold: 260 iterations across two densifications must run and learn."""
+    model = str(tmp_path_factory.mktemp("model_dp1_rccl"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    args = ["--iterations", "260", "--densify_from_iter", "100", "--densification_interval", "100", "--opacity_reset_interval", "300",
+            "--densify_until_iter", "900", "--test_iterations", "1", "260", "--save_iterations", "260", "--eval"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(PKG, "launch", "run_train_dp.py"), os.path.join(REFPY, "train.py"), "-s", scene, "-m", model] + args
+    out = _run(cmd, _env(GOF_DP_CHECK_EVERY="50"), timeout=900)
+    assert out.count("Training complete.") == 1
+    ps = _psnr(out)
+    assert ps[260] > ps[1] + 3.0, ps
+    assert os.path.exists(os.path.join(model, "point_cloud", "iteration_260", "point_cloud.ply"))
