@@ -69,7 +69,8 @@ def _rand_sh(rng, P, deg_max=3):
 
 
 def scene_frustum(P, W=1600, H=1063, focal=1200.0, seed=0, sh_degree=3, sigma_px=3.0,
-                  zmin=1.0, zmax=20.0, bg=(0.0, 0.0, 0.0), kernel_size=0.0):
+                  zmin=1.0, zmax=20.0, bg=(0.0, 0.0, 0.0), kernel_size=0.0, pose_seed=None):
+    """pose_seed: None = the SURVEY recipe (camera at the origin, viewmatrix = I); an int = the same cloud under pose_scene()."""
     rng = np.random.default_rng(seed)
     tanx = (W / 2) / focal
     tany = (H / 2) / focal
@@ -92,7 +93,47 @@ def scene_frustum(P, W=1600, H=1063, focal=1200.0, seed=0, sh_degree=3, sigma_px
     scene.update(means3D=means, scales=scales, rotations=rot, opacities=opac, shs=sh,
                  sh_degree=int(sh_degree), bg=np.asarray(bg, dtype=np.float32), kernel_size=float(kernel_size),
                  scale_modifier=1.0, subpixel_offset=np.zeros((H, W, 2), dtype=np.float32))
-    return scene
+    return scene if pose_seed is None else pose_scene(scene, pose_seed)
+
+
+def _quat_to_rot(q):
+    r, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                     [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                     [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+
+
+def _quat_mul(a, b):
+    """Hamilton product a (x) b, (r, x, y, z) order as the reference's rotations; a: (4,), b: (P, 4)."""
+    ar, ax, ay, az = a
+    br, bx, by, bz = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    return np.stack([ar * br - ax * bx - ay * by - az * bz,
+                     ar * bx + ax * br + ay * bz - az * by,
+                     ar * by - ax * bz + ay * br + az * bx,
+                     ar * bz + ax * by - ay * bx + az * br], 1)
+
+
+def pose_scene(scene, seed, spread=3.0):
+    """Re-pose a scene built in the camera frame (viewmatrix = I, campos = 0: scene_frustum and what tests derive from it) under a
+    random rigid motion: camera-to-world rotation R (uniform, from a random unit quaternion), camera centre c ~ N(0, spread^2).
+    Means go to world = R x + c, every Gaussian's quaternion is composed with R's (so the splats keep their place and shape in
+    the image up to fp32 rounding), and viewmatrix / projmatrix / campos are the matching world-to-view camera in the reference's
+    conventions (scene/cameras.py:50-58) -- the configuration every real training step renders: a posed camera looking at
+    rotated anisotropic Gaussians.  Returns a new dict; the input is not modified."""
+    rng = np.random.default_rng(7000 + seed)
+    qc = rng.normal(0, 1, 4)
+    qc /= np.linalg.norm(qc)
+    R = _quat_to_rot(qc)                                    # camera-to-world
+    c = rng.normal(0.0, spread, 3)
+    out = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
+    out["means3D"] = (scene["means3D"].astype(np.float64) @ R.T + c).astype(np.float32)
+    q = _quat_mul(qc, scene["rotations"].astype(np.float64))
+    nrm = np.linalg.norm(scene["rotations"].astype(np.float64), axis=1, keepdims=True)       # keeps un-normalised inputs un-normalised
+    qn = np.linalg.norm(q, axis=1, keepdims=True)
+    out["rotations"] = (q / np.where(qn > 0, qn, 1.0) * nrm).astype(np.float32)
+    fovx, fovy = 2 * math.atan(scene["tanfovx"]), 2 * math.atan(scene["tanfovy"])
+    out.update(camera(scene["W"], scene["H"], fovx, fovy, R=R, T=-R.T @ c))
+    return out
 
 
 def scene_lego_like(P=10_000, W=400, H=400, seed=0, sh_degree=3, bg=(1.0, 1.0, 1.0), kernel_size=0.0):

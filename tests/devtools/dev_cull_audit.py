@@ -20,6 +20,8 @@ def scenes():
     table = dict(SCENES)
     table["s1m"] = lambda: S.scene_frustum(1_000_000, seed=0)
     table["s1m_ks01"] = lambda: S.scene_frustum(1_000_000, seed=0, kernel_size=0.1)
+    table["s1m_posed"] = lambda: S.scene_frustum(1_000_000, seed=0, pose_seed=0)
+    table["far_subpixel_posed"] = lambda: S.scene_frustum(300_000, W=800, H=528, focal=600.0, seed=7, sigma_px=0.4, zmin=5.0, zmax=80.0, pose_seed=9)
     table["far_subpixel"] = lambda: S.scene_frustum(300_000, W=800, H=528, focal=600.0, seed=7, sigma_px=0.4, zmin=5.0, zmax=80.0)
     return table
 

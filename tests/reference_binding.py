@@ -1,7 +1,9 @@
 """ctypes binding of oracle/_ref/libgof_cudaref*.so (TEST INFRASTRUCTURE): the REFERENCE CUDA
 rasterizer compiled for gfx950 by oracle/build_ref.sh.  Device memory via torch."""
+import contextlib
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -18,6 +20,24 @@ def available(variant=""):
 _ELEM = {"depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "view2gaussian": np.float32, "conic_opacity": np.float32,
          "rgb": np.float32, "clamped": np.uint8, "tiles_touched": np.uint32, "point_offsets": np.uint32, "point_list": np.uint32,
          "point_list_keys": np.uint64, "ranges": np.uint32, "final_T": np.float32, "n_contrib": np.uint32}
+
+
+@contextlib.contextmanager
+def _stdout_to_devnull():
+    """The reference's integrateCUDA printf()s "ERROR: Maximal contributors are met..." once per saturated pixel
+    (forward.cu:988): tens of thousands of lines that push pytest's summary out of the recorded tail.  Device printf goes to
+    fd 1 when the stream is synchronised, so fd 1 points at /dev/null from the launch to the synchronise."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    null = os.open(os.devnull, os.O_WRONLY)
+    try:
+        os.dup2(null, 1)
+        yield
+        torch.cuda.synchronize()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(null)
 
 
 class Reference:
@@ -102,5 +122,6 @@ class Reference:
         radii = torch.zeros(self.P, dtype=torch.int32, device=dev)
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         torch.cuda.synchronize()
-        self.R = self.L.cudaref_integrate(self.h, C.byref(self.args), PN, p(pts), p(out), p(alpha), p(col), p(radii))
+        with _stdout_to_devnull():
+            self.R = self.L.cudaref_integrate(self.h, C.byref(self.args), PN, p(pts), p(out), p(alpha), p(col), p(radii))
         return out.cpu().numpy(), alpha.cpu().numpy(), col.cpu().numpy(), radii.cpu().numpy()

@@ -68,7 +68,19 @@ SCENES = {
     "long_lists": lambda: S.scene_frustum(3000, W=32, H=32, focal=24.0, seed=4, sigma_px=6.0),
     "mid100k": lambda: S.scene_frustum(100_000, W=800, H=528, focal=600.0, seed=5),
     "stress_box": lambda: stress_scene(),
+    # round 3: the configuration every real train.py step renders -- a POSED camera (random SE(3), synthetic_scenes.pose_scene)
+    # looking at rotated anisotropic Gaussians: a transposition / frame slip in view2gaussian (forward.cu:168-279), its backward
+    # (backward.cu:381-587), the view-dependent SH colour or the fp64 footprint conic is invisible with viewmatrix = I
+    "posed_tiny": lambda: S.scene_frustum(7, W=64, H=48, focal=50.0, seed=1, pose_seed=1),
+    "posed_small_ks01": lambda: S.scene_frustum(1000, W=64, H=48, focal=50.0, seed=3, kernel_size=0.1, pose_seed=2),
+    "posed_ragged": lambda: S.scene_frustum(20_000, W=333, H=211, focal=240.0, seed=4, bg=(0.3, 0.6, 0.9), pose_seed=3),
+    "posed_long_lists": lambda: S.scene_frustum(3000, W=32, H=32, focal=24.0, seed=4, sigma_px=6.0, pose_seed=4),
+    "posed_mid100k": lambda: S.scene_frustum(100_000, W=800, H=528, focal=600.0, seed=5, pose_seed=5),
+    "posed_stress_box": lambda: S.pose_scene(stress_scene(), 6),
+    "posed_mod2": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=9, sigma_px=1.5, pose_seed=7), "scale_modifier": 2.0},
+    "posed_mod05_ks01": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=10, sigma_px=5.0, kernel_size=0.1, pose_seed=8), "scale_modifier": 0.5},
 }
+POSED = [k for k in SCENES if k.startswith("posed_")]
 
 
 def stress_scene():
@@ -117,10 +129,15 @@ def _fuzz_scene(seed):
     sc["opacities"] = rng.choice([rng.uniform(0.0, 1.0, (P, 1)), rng.uniform(0.002, 0.01, (P, 1)), rng.uniform(0.9, 1.2, (P, 1))]).astype(np.float32)
     sc["means3D"][rng.random(P) < 0.05, 2] *= -1.0                                                     # some behind the camera
     sc["sh_degree"] = int(rng.integers(0, 4))
+    # round 3: three of four seeds under a random rigid pose (camera and Gaussian frames no longer coincide), and scale_modifier
+    # != 1 on half of them (cov3D uses mod * scale, view2gaussian the raw scale: forward.cu:138, 255-256)
+    sc["scale_modifier"] = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
+    if seed % 4 != 0:
+        sc = S.pose_scene(sc, seed, spread=float(rng.uniform(0.0, 10.0)))
     return sc
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_forward_and_integrate_fuzz_bit_exact(seed):
     """Randomised small scenes (image size, focal length, splat size from sub-pixel to tile-covering, anisotropy up to ~1:100,
     opacity regimes, depth range, kernel size, SH degree): image, state and the opacity-field query bit-identical to the oracle --
@@ -143,7 +160,7 @@ def test_forward_and_integrate_fuzz_bit_exact(seed):
     assert np.array_equal(bits(colp.cpu().numpy()), bits(icol))
 
 
-@pytest.mark.parametrize("seed", range(100, 116))
+@pytest.mark.parametrize("seed", range(100, 132))
 def test_backward_fuzz_within_tolerance(seed):
     """The same randomised scenes through the backward blend: every gradient the blend produces within 1e-4 of the oracle's
     (relative to the largest entry) -- the fp32 hi+lo min_value, v_exp_f32 and FMA-contracted gradient arithmetic over sub-pixel
@@ -157,6 +174,12 @@ def test_backward_fuzz_within_tolerance(seed):
         ref = go[k]; got = gp[k].reshape(ref.shape)
         assert np.isfinite(got).all(), k
         assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-30), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    # the per-Gaussian stage (view2gaussian backward through R_view * R_q, SH backward with the world-space view direction) on
+    # bit-identical inputs: the product's own dL_dview2gaussian / dL_dcolors through the oracle's K9
+    iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
+    for k in ("means3D", "sh", "scales", "rotations"):
+        ref = iso[k]; got = gp[k].reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-20), (k, np.abs(got - ref).max(), np.abs(ref).max())
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
@@ -182,6 +205,73 @@ def test_forward_precomputed_inputs():
     # precomputed inputs reproduce the computed path exactly for visible Gaussians
     assert np.array_equal(bits(oc2), bits(oc)) or np.abs(oc2 - oc).max() == 0.0
     assert vis.any()
+
+
+@pytest.mark.parametrize("mod", [1.0, 0.5, 2.0])
+@pytest.mark.parametrize("which", ["colors", "view2gaussian", "colors+view2gaussian"])
+def test_backward_with_precomputed_inputs(which, mod):
+    """pipe.convert_SHs_python / pipe.compute_view2gaussian_python (arguments/__init__.py:73-76, gaussian_renderer/__init__.py:67-96):
+    the caller hands in colours and / or the 10 view2gaussian floats, and autograd routes dL_dcolors / dL_dview2gaussian back to
+    them (DGR __init__.py:152-165).  Posed camera, rotated anisotropic Gaussians, scale_modifier 0.5 / 1 / 2 (the precomputed
+    view2gaussian is built from the RAW scale whatever the modifier, as gaussian_model.py:202-260 does).  Checked against the oracle:
+    forward bit-exact; the returned dL_dcolors / dL_dview2gaussian / dL_dmeans2D / dL_dopacity within 1e-4; the per-Gaussian stage
+    -- which the reference still runs on scales / rotations with the precomputed view2gaussian (backward.cu:621) and, without SHs,
+    without the colour term in dL_dmeans3D (:624) -- within 1e-5 on identical inputs; dL_dsh absent / zero without SHs."""
+    base = S.scene_frustum(3000, W=160, H=112, focal=120.0, seed=12, kernel_size=0.1, pose_seed=11)
+    base["scale_modifier"] = mod
+    ob0 = ob.OracleScene(base)
+    ob0.forward()
+    rgb = ob0.fetch("rgb").reshape(-1, 3).copy()
+    rgb *= np.random.default_rng(3).uniform(0.5, 1.5, rgb.shape).astype(np.float32)          # not what the SHs would give
+    v2g = ob0.fetch("view2gaussian").reshape(-1, 10).copy()
+    over = {}
+    if "colors" in which:
+        over["colors_precomp"] = torch.from_numpy(rgb).cuda()
+    if "view2gaussian" in which:
+        over["view2gaussian_precomp"] = torch.from_numpy(v2g).cuda()
+    o, oc, orad, res = _forward_pair(base, **over)
+    assert np.array_equal(res["radii"].cpu().numpy(), orad) and res["R"] == o.num_rendered()
+    assert_image_matches(res["color"].cpu().numpy(), oc)
+    dL = np.random.default_rng(4).normal(size=oc.shape).astype(np.float32)
+    go = o.backward(dL)
+    gp = _product_backward(res, dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian"):
+        ref = go[k]; got = gp[k].reshape(ref.shape)
+        assert np.abs(ref).max() > 0
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
+    for k in ("means3D", "scales", "rotations") + (() if "colors" in which else ("sh",)):
+        ref = iso[k]; got = gp[k].reshape(ref.shape)
+        assert np.abs(ref).max() > 0
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    if "colors" in which:
+        assert gp["sh"].size == 0 or not gp["sh"].any()
+    assert not gp["cov3D"].any()
+
+
+def test_backward_with_precomputed_inputs_through_autograd():
+    """The same through the autograd surface (DGR __init__.py:106-165): gradients arrive at colors_precomp and
+    view2gaussian_precomp leaves, not at shs."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = S.scene_frustum(2000, W=128, H=96, focal=100.0, seed=13, pose_seed=12)
+    o0 = ob.OracleScene(sc)
+    o0.forward()
+    rgb = o0.fetch("rgb").reshape(-1, 3).copy(); v2g = o0.fetch("view2gaussian").reshape(-1, 10).copy()
+    sd = to_dev(sc)
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+    col = torch.from_numpy(rgb).cuda().requires_grad_(True); vg = torch.from_numpy(v2g).cuda().requires_grad_(True)
+    means2D = torch.zeros_like(leaf["means3D"], requires_grad=True)
+    color, radii = GaussianRasterizer(settings_from(sd))(means3D=leaf["means3D"], means2D=means2D, colors_precomp=col, opacities=leaf["opacities"],
+                                                         scales=leaf["scales"], rotations=leaf["rotations"], view2gaussian_precomp=vg)
+    dL = torch.randn(color.shape, generator=torch.Generator().manual_seed(6))
+    color.backward(dL.cuda())
+    o = ob.OracleScene(sc, colors_precomp=rgb, view2gaussian_precomp=v2g)
+    oc, orad = o.forward()
+    go = o.backward(dL.numpy())
+    assert_image_matches(color.detach().cpu().numpy(), oc)
+    for name, t in (("colors", col.grad), ("view2gaussian", vg.grad), ("means2D", means2D.grad), ("opacity", leaf["opacities"].grad)):
+        ref = go[name]; got = t.cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
 
 
 def test_empty_and_culled():
@@ -214,7 +304,7 @@ def _product_backward(res, dL):
     return {n: g.cpu().numpy() for n, g in zip(names, grads)}
 
 
-@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k"])
+@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k"] + POSED)
 def test_backward_blend_gradients(name):
     sc = SCENES[name]()
     o, oc, orad, res = _forward_pair(sc)
@@ -306,7 +396,7 @@ def test_integrate_matches_oracle():
     assert (a[-2:] == 1.0).all()          # points outside the image keep the initial 1.0 (rasterize_points.cu:277)
 
 
-@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k"])
+@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k"] + POSED)
 def test_integrate_bit_exact_on_scene(name):
     """The opacity-field query on the forward's scene table (incl. the cull stress scene: sub-pixel far splats, needles,
     splats containing the camera plane, opacities around 1/255): every output bit-identical to the oracle.  Query points =
@@ -716,6 +806,34 @@ def test_full_size_s1m_against_oracle():
         assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
 
 
+def test_full_size_s1m_posed_against_oracle():
+    """BASELINE config 2 at full size under a random rigid pose (pose_scene: the same 1M-Gaussian cloud seen by a posed camera --
+    what a real training step renders): sorted list, contributor counts, transmittances and image bit-exact, blend gradients
+    within 1e-4, the per-Gaussian backward within 1e-5 on identical inputs."""
+    sc = S.scene_frustum(1_000_000, seed=0, pose_seed=0)
+    assert np.abs(sc["viewmatrix"][:3, :3] - np.eye(3)).max() > 0.3 and np.abs(sc["campos"]).max() > 0.5
+    o, oc, orad, res = _forward_pair(sc)
+    assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad) and res["R"] > 8_000_000
+    assert _same(fetch(res, "point_list"), o.fetch("point_list"))
+    assert _same(fetch(res, "n_contrib"), o.fetch("n_contrib"))
+    P = len(orad); vis = orad > 0
+    for arr in K1_ARRAYS:
+        a = fetch(res, arr); b = o.fetch(arr)
+        assert _same(a.reshape(P, -1)[vis], b.reshape(P, -1)[vis]), arr
+    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["color"].cpu().numpy(), oc)
+    dL = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
+    go = o.backward(dL)
+    gp = _product_backward(res, dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian"):
+        ref = go[k]; got = gp[k].reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
+    for k in ("means3D", "sh", "scales", "rotations"):
+        ref = iso[k]; got = gp[k].reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
 def test_full_size_properties_s1m():
     """BASELINE config 2 at full size: size-independent properties instead of an oracle run."""
     sc = S.scene_frustum(1_000_000, seed=0)
@@ -760,9 +878,10 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "gaussian-opacity-fields_amd", "lib", "libgof_hip_audit.so")
     assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
-    names = ["s1m", "s1m_ks01", "stress_box", "far_subpixel", "long_lists", "lego10k", "ragged", "mid100k", "small_ks01"]
+    names = ["s1m", "s1m_ks01", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
+             "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01"]
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib),
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
     assert [x["scene"] for x in rows] == names
