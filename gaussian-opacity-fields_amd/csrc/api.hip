@@ -50,7 +50,8 @@ __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* ord
                                uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity);
 __global__ void point_keys(int PN, const float2* points2D, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
-__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev);
+__global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev, const uint32_t* sort_error,
+                            uint32_t* async_status);
 __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* gids, const float* depths, uint64_t* keys);
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
@@ -84,6 +85,37 @@ void set_error(const char* fmt, ...)
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_error = buf;
+}
+
+// ---- asynchronous device status ----------------------------------------------------------------------
+// One host-mapped word per process (pinned, visible to every device): a kernel that detects a failure nobody reads back in the
+// same call -- the tile sort's bounded look-back poll on lists of <= 2M instances, which has no host read-back behind it -- writes
+// it through the mapping, and the NEXT forward / backward / integrate call returns GOF_E_DEVICE (the convention of asynchronous
+// errors in the reference's runtime: they surface at a later call).  Written only on failure, so it costs nothing otherwise.
+namespace {
+std::mutex g_status_mutex;
+volatile uint32_t* g_status_host = nullptr;
+}
+static uint32_t* async_status_word()
+{
+    std::lock_guard<std::mutex> lk(g_status_mutex);
+    if (!g_status_host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        std::memset(p, 0, 64);
+        g_status_host = static_cast<volatile uint32_t*>(p);
+    }
+    return const_cast<uint32_t*>(g_status_host);       // unified addressing: the host pointer of mapped pinned memory is valid on the device
+}
+static int take_async_status()
+{
+    std::lock_guard<std::mutex> lk(g_status_mutex);
+    if (g_status_host && *g_status_host) {
+        *g_status_host = 0;
+        set_error("an EARLIER call's tile sort timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
+        return GOF_E_DEVICE;
+    }
+    return GOF_OK;
 }
 
 // ---- profiling ---------------------------------------------------------------------------------------
@@ -253,7 +285,8 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
-        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev);
+        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev,
+                           radix_sort_error_flag(b.sort_tmp, (size_t)R, tile_bits), async_status_word());
         GOF_LAUNCH_CHECK(stream, dbg);
     }
     return GOF_OK;
@@ -310,6 +343,7 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
+    if (!rc) rc = take_async_status();
     if (rc) return rc;
     if (!num_rendered_host) { set_error("num_rendered_host is NULL"); return GOF_E_INVALID; }
     *num_rendered_host = 0;
@@ -351,6 +385,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
+    if (!rc) rc = take_async_status();
     if (rc) return rc;
     if (!num_rendered_pinned_host || !out_color) { set_error("num_rendered_pinned_host / out_color is NULL"); return GOF_E_INVALID; }
     if (a->P == 0 || a->prefiltered || a->debug) { set_error("gof_forward_fused: empty / prefiltered / debug calls use gof_forward_prepare + gof_forward_render"); return GOF_E_INVALID; }
@@ -451,6 +486,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
+    if (!rc && (stages & 1)) rc = take_async_status();
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
     if (!scratch || scratch_bytes < gof_backward_scratch_bytes(a->P, R)) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
@@ -658,7 +694,8 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.point_ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (NI > 0) {
-        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr);
+        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr,
+                           radix_sort_error_flag(pb.sort_tmp, (size_t)NI, (int)higher_msb(d.ntiles) + 8), async_status_word());
         GOF_LAUNCH_CHECK(stream, a->debug);
         hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.points2D, w.depths, pb.pt_xy, pb.pt_depth);
         GOF_LAUNCH_CHECK(stream, a->debug);

@@ -44,9 +44,11 @@ gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restr
     if (i >= n) return;
     // the depth sort's bounded look-back poll expired (radix.hip: OS_SPIN_LIMIT): `order` is not a sorted permutation.  Make the
     // instance count the host reads back impossible (GOF_SORT_FAILED_COUNT) so that the call fails instead of rendering garbage.
+    // The sentinel sits in the LAST count: every exclusive offset stays 0 and every rectangle empty, so emit_instances writes
+    // nothing, and the launches already queued behind the scan see device_item_count() == 0 (gof_status.h).
     if (sort_error && *sort_error) {
         minxy_sorted[i] = 0u; wh_sorted[i] = 0u;
-        counts[i] = (i == 0u) ? GOF_SORT_FAILED_COUNT : 0u;
+        counts[i] = (i == n - 1u) ? GOF_SORT_FAILED_COUNT : 0u;
         return;
     }
     const uint2 r = rect[order[i]];
@@ -136,12 +138,20 @@ gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const
     pt_depth[i] = depths[id];
 }
 
-// replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before
+// replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before.
+// sort_error (nullable): the tile sort's time-out flag when it ran as single-kernel passes (<= 2M instances): the list is then not
+// sorted, so the ranges stay empty (the frame renders as background instead of from a mis-sorted list) and the failure is raised in
+// the host-mapped status word, which the next library call reports (api.hip: take_async_status).
 __global__ void __launch_bounds__(256)
-tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges, int shift, const uint32_t* __restrict__ n_dev)
+tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ ranges, int shift, const uint32_t* __restrict__ n_dev,
+            const uint32_t* __restrict__ sort_error, uint32_t* __restrict__ async_status)
 {
-    if (n_dev) L = min(L, *n_dev);
+    L = device_item_count(L, n_dev);
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (sort_error && *sort_error) {
+        if (idx == 0 && async_status) *async_status = 1u;
+        return;
+    }
     if (idx >= L) return;
     const uint32_t currtile = tiles[idx] >> shift;
     if (idx == 0) ranges[currtile].x = 0;

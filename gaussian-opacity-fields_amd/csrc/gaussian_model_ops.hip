@@ -210,9 +210,13 @@ densify_roles_kernel(int64_t P, const float* __restrict__ accum, const float* __
     float g = accum[i] / denom[i], ga = accum_abs[i] / denom[i];
     if (g != g) g = 0.0f;
     if (ga != ga) ga = 0.0f;
-    const bool sel = (sqrtf(g * g) >= max_grad) || (sqrtf(ga * ga) >= q_abs[0]);
+    // the clone test takes torch.norm over the size-1 last dimension = |g| (:660-661), the split test the raw value (:636-640);
+    // fabsf is exact where sqrtf(g * g) underflowed for |g| < ~1e-19 (matters for a tiny or zero threshold)
+    const float q = q_abs[0];
+    const bool sel_clone = (fabsf(g) >= max_grad) || (fabsf(ga) >= q);
+    const bool sel_split = (g >= max_grad) || (ga >= q);
     const bool small = scale_max[i] <= size_threshold;
-    const uint8_t r = sel ? (small ? 1 : 2) : 0;
+    const uint8_t r = small ? (sel_clone ? 1 : 0) : (sel_split ? 2 : 0);
     role[i] = r;
     f_keep[i] = r != 2; f_clone[i] = r == 1; f_split[i] = r == 2;
 }

@@ -16,6 +16,7 @@
 //                 them in index order; the block exchanges the items through LDS into digit-sorted order and
 //                 writes each digit's run contiguously at its global offset (coalesced).
 #include "gof_common.h"
+#include "gof_status.h"
 
 namespace gof {
 
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256)
 rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblocks,
         const uint32_t* __restrict__ n_dev)
 {
-    if (n_dev) n = min(n, *n_dev);            // device-side item count (sync-free forward): n is then the capacity
+    n = device_item_count(n, n_dev);            // device-side item count (sync-free forward): n is then the capacity
     // counting only (no ranks needed here): one LDS atomic per item, all 16 loads of a thread in flight together
     __shared__ uint32_t s_cnt[RS_DIGITS];
     s_cnt[threadIdx.x] = 0;
@@ -208,7 +209,7 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
            uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblocks,
            const uint32_t* __restrict__ n_dev)
 {
-    if (n_dev) n = min(n, *n_dev);
+    n = device_item_count(n, n_dev);
     __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
     __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
     __shared__ uint32_t s_gbase[RS_DIGITS];      // global start of this block's run of every digit
@@ -301,7 +302,7 @@ constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of e
 __global__ void __launch_bounds__(256)
 os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase, const uint32_t* __restrict__ n_dev)
 {
-    if (n_dev) n = min(n, *n_dev);
+    n = device_item_count(n, n_dev);
     __shared__ uint32_t s_h[OS_MAX_PASSES][RS_DIGITS];
     for (int p = 0; p < npass; p++) s_h[p][threadIdx.x] = 0;
     __syncthreads();
@@ -331,7 +332,7 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
         uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ desc,
         uint32_t* __restrict__ ticket, uint32_t* __restrict__ err, const uint32_t* __restrict__ n_dev)
 {
-    if (n_dev) n = min(n, *n_dev);
+    n = device_item_count(n, n_dev);
     __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
     __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
     __shared__ uint32_t s_gbase[RS_DIGITS];      // global start of this block's run of every digit

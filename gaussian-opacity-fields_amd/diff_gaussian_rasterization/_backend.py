@@ -439,7 +439,8 @@ class integrate_min_into:
     lowers the minimum, writes the view's colour into `color` [N, 3]: the reduction over views of reference extract_mesh.py:17-34
     (`final_color = where(alpha < final_alpha, color, final_color); final_alpha = min(final_alpha, alpha)`) without the per-view
     `ones` / `zeros` fills and the separate min / where passes.  The call returns the two buffers as alpha_integrated /
-    color_integrated and the view's base image as its colour output (gof_integrate_points_min)."""
+    color_integrated and **None as its image**: the point pass writes no image in this mode (channel 8, the per-pixel point count,
+    is not produced; gof_integrate_points_min)."""
 
     def __init__(self, alpha_min, color=None):
         self.value = (alpha_min, color)
@@ -522,8 +523,10 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
                                                 _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
                                                 _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), None,
                                                 _ptr(acc_alpha), None if acc_color is None else _ptr(acc_color), _stream()))
-            # the image handed back must not alias the cached base image of the view (a caller may write into it)
-            return rendered, (base.clone() if key is not None else base), acc_alpha, acc_color, radii, geom, binning, img
+            # No image in this mode: the point pass writes none (channel 8, the per-pixel point count, is not produced), and a copy
+            # of the view's cached base image per call was 9*H*W*4 bytes (61 MB at 1600x1063) nobody read -- the first element of
+            # the returned tuple is None (documented on integrate_min_into).
+            return rendered, None, acc_alpha, acc_color, radii, geom, binning, img
         _check(points_fn(v.ref(), rendered, PN, int(ni.value), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                         _ptr(img), img.numel(), _ptr(pws), pws.numel(), _ptr(pbin), pbin.numel(), _ptr(base), _ptr(out_color),
                                         _ptr(out_alpha), _ptr(out_color_pts), _stream()))

@@ -26,8 +26,11 @@ _ELEM = {"depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "view
 def _stdout_to_devnull():
     """The reference's integrateCUDA printf()s "ERROR: Maximal contributors are met..." once per saturated pixel
     (forward.cu:988): tens of thousands of lines that push pytest's summary out of the recorded tail.  Device printf goes to
-    fd 1 when the stream is synchronised, so fd 1 points at /dev/null from the launch to the synchronise."""
+    the C library's stdout (buffered when fd 1 is a pipe) as the runtime services the kernel's host calls, so fd 1 points at
+    /dev/null from the launch until the stream is synchronised AND the C stream is flushed."""
+    libc = C.CDLL(None)
     sys.stdout.flush()
+    libc.fflush(None)
     saved = os.dup(1)
     null = os.open(os.devnull, os.O_WRONLY)
     try:
@@ -35,6 +38,7 @@ def _stdout_to_devnull():
         yield
         torch.cuda.synchronize()
     finally:
+        libc.fflush(None)
         os.dup2(saved, 1)
         os.close(saved)
         os.close(null)
