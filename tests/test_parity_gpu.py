@@ -9,10 +9,14 @@ Bars (stated per test):
     oracle) -- BIT-EXACT;
   * normal channels (3-5): the device normalises with one v_rsq_f32 where the reference takes an fp64 sqrt and
     three IEEE divisions -- 2e-6 absolute (components are <= 1 in magnitude; measured 3e-7);
-  * backward blend gradients (fp32 atomics in arbitrary order vs double accumulation) -- 1e-4 relative to
-    the tensor's max magnitude (north_star tolerance), measured ~3e-7;
-  * K9 (per-Gaussian backward) on bit-identical inputs -- 1e-5 relative (it is an ill-conditioned
-    function of dL_dview2gaussian, so it is checked in isolation; the end-to-end figure is reported).
+  * backward blend gradients (fixed-order fp32 sums vs the oracle's double accumulation) -- north_star tolerance 1e-4; ASSERTED
+    at the round-3 measurements (profiles/r03_parity_report.md, 25 scenes) x a small factor: max-norm error <= 1e-5 of the
+    tensor's maximum (measured <= 1.5e-6), relative L2 <= 1e-5 (measured <= 1.2e-6), and ELEMENT-WISE: the 99.9th percentile of
+    |a - ref| / |ref| over the elements with |ref| > 1e-3 max|ref| <= 5e-4 (measured <= 5.8e-5) -- a max-norm bound alone lets
+    elements 100x below the maximum be 1 % off;
+  * K9 (per-Gaussian backward) on bit-identical inputs -- 1e-6 of the maximum (measured: 0, bit-equal on all 25 scenes; it is an
+    ill-conditioned function of dL_dview2gaussian, so it is checked in isolation; the end-to-end figures against the reference's
+    own error band are in the report and asserted in test_reference_gpu.py).
 """
 import math
 
@@ -37,6 +41,29 @@ def assert_image_matches(pc, oc):
     """colour / depth / alpha / distortion bit-exact; normals within 2e-6 absolute"""
     assert np.array_equal(bits(pc[EXACT_CH]), bits(oc[EXACT_CH])), "max abs diff %g" % np.abs(pc[EXACT_CH] - oc[EXACT_CH]).max()
     assert np.abs(pc[3:6] - oc[3:6]).max() <= 2e-6, np.abs(pc[3:6] - oc[3:6]).max()
+
+
+def assert_grad_close(got, ref, name, max_norm=1e-5, rel_l2=1e-5, p999=5e-4):
+    """blend gradient vs the oracle: max-norm, relative L2 and element-wise 99.9th percentile (see the module docstring)"""
+    got = np.asarray(got, np.float64).reshape(np.shape(ref)); ref = np.asarray(ref, np.float64)
+    assert np.isfinite(got).all(), name
+    m = np.abs(ref).max() if ref.size else 0.0
+    if m == 0.0:
+        assert not got.any(), name
+        return
+    d = np.abs(got - ref)
+    assert d.max() <= max_norm * m, (name, "max-norm", d.max() / m)
+    assert np.linalg.norm(d) <= rel_l2 * np.linalg.norm(ref), (name, "rel L2", np.linalg.norm(d) / np.linalg.norm(ref))
+    big = np.abs(ref) > 1e-3 * m
+    if big.sum() >= 100:
+        q = np.percentile(d[big] / np.abs(ref[big]), 99.9)
+        assert q <= p999, (name, "99.9th percentile element-wise", q)
+
+
+def assert_k9_close(got, ref, name):
+    """per-Gaussian backward on bit-identical inputs: measured bit-equal; 1e-6 of the maximum asserted"""
+    got = np.asarray(got).reshape(np.shape(ref))
+    assert np.abs(got - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-20), (name, np.abs(got - ref).max(), np.abs(ref).max())
 
 
 def assert_final_T_matches(a, b, HW):
@@ -171,15 +198,12 @@ def test_backward_fuzz_within_tolerance(seed):
     go = o.backward(dL)
     gp = _product_backward(res, dL)
     for k in ("means2D", "colors", "opacity", "view2gaussian"):
-        ref = go[k]; got = gp[k].reshape(ref.shape)
-        assert np.isfinite(got).all(), k
-        assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-30), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_grad_close(gp[k], go[k], k)
     # the per-Gaussian stage (view2gaussian backward through R_view * R_q, SH backward with the world-space view direction) on
     # bit-identical inputs: the product's own dL_dview2gaussian / dL_dcolors through the oracle's K9
     iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
     for k in ("means3D", "sh", "scales", "rotations"):
-        ref = iso[k]; got = gp[k].reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-20), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_k9_close(gp[k], iso[k], k)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
@@ -236,14 +260,12 @@ def test_backward_with_precomputed_inputs(which, mod):
     go = o.backward(dL)
     gp = _product_backward(res, dL)
     for k in ("means2D", "colors", "opacity", "view2gaussian"):
-        ref = go[k]; got = gp[k].reshape(ref.shape)
-        assert np.abs(ref).max() > 0
-        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert np.abs(go[k]).max() > 0
+        assert_grad_close(gp[k], go[k], k)
     iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
     for k in ("means3D", "scales", "rotations") + (() if "colors" in which else ("sh",)):
-        ref = iso[k]; got = gp[k].reshape(ref.shape)
-        assert np.abs(ref).max() > 0
-        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert np.abs(iso[k]).max() > 0
+        assert_k9_close(gp[k], iso[k], k)
     if "colors" in which:
         assert gp["sh"].size == 0 or not gp["sh"].any()
     assert not gp["cov3D"].any()
@@ -270,8 +292,7 @@ def test_backward_with_precomputed_inputs_through_autograd():
     go = o.backward(dL.numpy())
     assert_image_matches(color.detach().cpu().numpy(), oc)
     for name, t in (("colors", col.grad), ("view2gaussian", vg.grad), ("means2D", means2D.grad), ("opacity", leaf["opacities"].grad)):
-        ref = go[name]; got = t.cpu().numpy().reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+        assert_grad_close(t.cpu().numpy(), go[name], name)
 
 
 def test_empty_and_culled():
@@ -312,16 +333,12 @@ def test_backward_blend_gradients(name):
     go = o.backward(dL)
     gp = _product_backward(res, dL)
     for k in ("means2D", "colors", "opacity", "view2gaussian"):
-        ref = go[k]; got = gp[k].reshape(ref.shape)
-        tol = 1e-4 * max(np.abs(ref).max(), 1e-20)
-        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_grad_close(gp[k], go[k], k)
     assert not gp["cov3D"].any()
     # K9 in isolation: feed the oracle's per-Gaussian backward the PRODUCT's dL_dview2gaussian / dL_dcolors
     iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
     for k in ("means3D", "sh", "scales", "rotations"):
-        ref = iso[k]; got = gp[k].reshape(ref.shape)
-        tol = 1e-5 * max(np.abs(ref).max(), 1e-20)
-        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_k9_close(gp[k], iso[k], k)
     inv = orad <= 0
     for k, v in gp.items():
         assert not v.reshape(len(orad), -1)[inv].any(), k
@@ -365,8 +382,7 @@ def test_autograd_surface_like_render():
     assert_image_matches(rendered_image.detach().cpu().numpy(), oc)
     assert screenspace_points.grad is not None
     for name, t in (("means2D", screenspace_points.grad), ("opacity", leaf["opacities"].grad), ("sh", leaf["shs"].grad)):
-        ref = go[name]; got = t.cpu().numpy().reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+        assert_grad_close(t.cpu().numpy(), go[name], name)
     vis = (radii > 0).cpu().numpy()
     assert np.array_equal(vis, orad > 0)
 
@@ -802,8 +818,7 @@ def test_full_size_s1m_against_oracle():
     go = o.backward(dL)
     gp = _product_backward(res, dL)
     for k in ("means2D", "colors", "opacity", "view2gaussian"):
-        ref = go[k]; got = gp[k].reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_grad_close(gp[k], go[k], k)
 
 
 def test_full_size_s1m_posed_against_oracle():
@@ -826,12 +841,10 @@ def test_full_size_s1m_posed_against_oracle():
     go = o.backward(dL)
     gp = _product_backward(res, dL)
     for k in ("means2D", "colors", "opacity", "view2gaussian"):
-        ref = go[k]; got = gp[k].reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_grad_close(gp[k], go[k], k)
     iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
     for k in ("means3D", "sh", "scales", "rotations"):
-        ref = iso[k]; got = gp[k].reshape(ref.shape)
-        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), (k, np.abs(got - ref).max(), np.abs(ref).max())
+        assert_k9_close(gp[k], iso[k], k)
 
 
 def test_full_size_properties_s1m():

@@ -280,7 +280,8 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
 
 
-@pytest.mark.parametrize("name", ["small_ks01", "lego10k", "ragged", "long_lists", "mid100k"])
+@pytest.mark.parametrize("name", ["small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "posed_ragged", "posed_mid100k", "posed_mod2",
+                                  "posed_mod05_ks01", "posed_stress_box"])
 def test_parameter_gradients_within_twice_the_references_own_run_to_run_band(name):
     """product vs oracle (double accumulation in list order = the noise-free value of the reference's formulas) for the gradients
     of the Gaussian PARAMETERS, end to end (blend backward + per-Gaussian backward): relative L2 error <= 2 x the error of the
@@ -307,4 +308,5 @@ def test_parameter_gradients_within_twice_the_references_own_run_to_run_band(nam
         assert mine <= 2.0 * max(ref_err, ref_spread) + 1e-6, (k, report)
         if ref_err < 1e-4:
             assert mine < 1e-4, (k, report)
+    # the measured figures of all scenes (incl. S1M) are committed: profiles/r03_parity_report.{json,md} (tests/devtools/dev_parity_report.py)
     print("parameter-gradient errors (product, reference, reference run-to-run):", report)
