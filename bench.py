@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-full-loop", action="store_true", help="skip the full training-iteration leg (losses + Adam)")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=1_000_000, help="Gaussians of the cpu_baseline sample (default: the whole workload)")
     ap.add_argument("--no-integrate", action="store_true", help="skip the opacity-field query leg (BASELINE config 5 shape)")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the heavy-tailed scene leg (S1M-clustered: what the tile scheduler is for)")
     return ap.parse_args()
 
 
@@ -200,6 +201,8 @@ def main():
                                        "the all-gather of the colour gradient starts inside the backward and overlaps preprocess_bwd"}
         if world == 1 and not args.no_full_loop:
             out["full_loop"] = full_loop(sd, dev, W, H)
+        if world == 1 and not args.no_clustered and P == 1_000_000:
+            out["clustered"] = clustered_leg(dev, P, W, H, focal, args.kernel_size, out["ms_per_step"])
         if world == 1 and not args.no_integrate:
             out["integrate"] = integrate_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -255,7 +258,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
             if name in extra_bytes:
                 ent["design_extra_MB"] = round(extra_bytes[name] / 1e6, 2)
         kernels[name] = ent
-    fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "blend_forward")
+    fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "order_tiles", "blend_forward")
     fwd_ms = sum(kernels[k]["avg_ms"] for k in fwd_names if k in kernels)
     bwd_ms = sum(kernels[k]["avg_ms"] for k in ("backward_memsets", "blend_backward", "gather_tile_partials", "preprocess_bwd") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["calls"])
@@ -293,6 +296,56 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
             "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd, "contributing_pairs": pairs,
                          "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)}}
     return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": R, "roofline": roof}
+
+
+def clustered_leg(dev, P, W, H, focal, kernel_size, s1m_ms, steps=20, warmup=3):
+    """The same step on a HEAVY-TAILED scene (synthetic_scenes.scene_clustered, "S1M-clustered": 70 % of the Gaussians in five
+    semi-transparent blobs, 2 % large splats at the back, sparse background -- tile lists of 1300 ... 14500 entries of which 220 ...
+    2060 are walked, where S1M's tiles all cost the same): what the tile scheduler (order_tiles + pop_tile: tiles ranked by cost,
+    dealt to the XCD queues, heaviest first) is for.  An extra key next to the headline, not instead of it.  The scheduler's
+    efficiency against the work-proportional ideal (per-tile clocks of an instrumented build) and the A/B against round 2's
+    static map are in profiles/r03_tile_schedule.md."""
+    import synthetic_scenes as S
+    from gpu_common import to_dev, settings_from, product_forward_raw, fetch
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    sc = S.scene_clustered(P, W=W, H=H, focal=focal, seed=0, kernel_size=kernel_size)
+    sd = to_dev(sc, dev)
+    params = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    rast = GaussianRasterizer(settings_from(sd))
+    dL = torch.randn((9, H, W), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        means2D.grad = None
+        color, _ = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                        scales=params["scales"], rotations=params["rotations"])
+        color.backward(dL)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    B.profile_enable(True)
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    rep = B.profile_report()
+    B.profile_enable(False)
+    res = product_forward_raw(sd)
+    rg = fetch(res, "ranges").view(np.uint32).reshape(-1, 2).astype(np.int64)
+    lens = rg[:, 1] - rg[:, 0]
+    walked = fetch(res, "tile_cost").astype(np.int64)
+    pct = lambda a: [int(x) for x in np.percentile(a, [0, 50, 90, 99, 100])]   # noqa: E731
+    return {"workload": "S1M-clustered: %d Gaussians @ %dx%d, SH degree 3, kernel_size %.2f, fwd+bwd" % (P, W, H, kernel_size),
+            "ms_per_step": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps, "num_rendered": int(res["R"]),
+            "tile_list_length_pct_0_50_90_99_100": pct(lens), "entries_walked_per_tile_pct_0_50_90_99_100": pct(walked),
+            "vs_s1m_ms_per_step": round(ms / s1m_ms, 3),
+            "kernels_ms": {k: round(v["total_ms"] / max(1, v["calls"]), 4) for k, v in rep.items()}}
 
 
 def full_loop(sd, dev, W, H, steps=10, warmup=3):

@@ -56,16 +56,20 @@ __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* 
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
-                              float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
+                              float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
+                              uint32_t* tile_cost);
+__global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
-                               float4* part16, float* part17, uint8_t* part_valid, uint32_t gx, uint32_t ntiles);
+                               float4* part16, float* part17, uint8_t* part_valid, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
+                               uint32_t* tile_queue);
 __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
                                      const uint8_t* part_valid, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors, float* dL_dv2g);
 __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
-                                 uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles);
+                                 uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
+                                 uint32_t* tile_queue);
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
                                  const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
@@ -185,6 +189,10 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
     carve(p, im.point_ranges, T);
     carve(p, im.final_T, 4 * N);
     carve(p, im.n_contrib, 2 * N);
+    carve(p, im.tile_order, T + NXCD);           // [8][ceil(T / 8)]
+    carve(p, im.tile_queue, (size_t)TILE_QUEUE_WORDS);
+    carve(p, im.tile_cost, T);
+    carve(p, im.tile_order_bw, T + NXCD);
     if (out) *out = im;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -289,7 +297,20 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
                            radix_sort_error_flag(b.sort_tmp, (size_t)R, tile_bits), async_status_word());
         GOF_LAUNCH_CHECK(stream, dbg);
     }
+    // dispatch order of the tile kernels: per XCD band, longest list first (gof_common.h: pop_tile)
+    { GOF_PROFILE("order_tiles", stream);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue); }
+    GOF_LAUNCH_CHECK(stream, dbg);
     return GOF_OK;
+}
+
+// The backward's dispatch order: what a tile costs there is known exactly after the forward blend (the deepest list position one of
+// its pixels blended = the entries the backward stages and walks), so the forward call leaves the order in the image workspace.
+static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream_t stream)
+{
+    GOF_PROFILE("order_tiles", stream);
+    // (no heads here: the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, nullptr);
 }
 
 } // namespace gof
@@ -410,12 +431,14 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
         if (rc) return rc;
     } else {
         GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue);
     }
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost); }
     GOF_LAUNCH_CHECK(stream, 0);
+    order_tiles_for_backward(d, im, stream);
     GOF_HIP_CHECK(hipEventSynchronize(ev));
     if (*num_rendered_pinned_host >= GOF_SORT_FAILED_COUNT) {
         set_error("depth sort: a single-kernel radix pass timed out waiting for a predecessor block (GPU heavily oversubscribed?)");
@@ -453,7 +476,9 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles); }
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost); }
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    order_tiles_for_backward(d, im, stream);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -461,7 +486,8 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 // backward scratch: first instance of every Gaussian in GAUSSIAN-ID order ([P] u32: exclusive scan of tiles_touched -- the partial
 // records of consecutive Gaussians are consecutive in memory, so the gather streams), scan scratch, then per tile instance (R of
 // them) a validity byte, the 17th partial gradient [R] f32 and the 64-byte record of the other 16 [R][16] f32
-struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint8_t* valid; float* part17; float4* part16; };
+struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint32_t* queue; uint8_t* valid; float* part17; float4* part16; };
+constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads sit right in front of the validity bytes: one memset clears both
 static size_t bwd_scratch_layout(int32_t P, uint32_t R, void* base, BwdScratch* o)
 {
     char* p = static_cast<char*>(base);
@@ -469,7 +495,9 @@ static size_t bwd_scratch_layout(int32_t P, uint32_t R, void* base, BwdScratch* 
     BwdScratch t;
     carve(p, t.inst_off, (size_t)(P < 1 ? 1 : P));
     carve(p, t.scan_tmp, scan_tmp_words((size_t)(P < 1 ? 1 : P)));
-    carve(p, t.valid, (size_t)R + 1);
+    carve(p, t.valid, (size_t)R + 1 + BWD_QUEUE_BYTES);
+    t.queue = reinterpret_cast<uint32_t*>(t.valid);
+    t.valid += BWD_QUEUE_BYTES;
     carve(p, t.part17, (size_t)R + 1);
     carve(p, t.part16, 4 * ((size_t)R + 1));
     if (o) *o = t;
@@ -525,14 +553,14 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
           GOF_HIP_CHECK(hipMemsetAsync(p0, 0, n, stream));
           i = j;
       }
-      if (R > 0) GOF_HIP_CHECK(hipMemsetAsync(ws.valid, 0, (size_t)R, stream)); }
+      if (R > 0) GOF_HIP_CHECK(hipMemsetAsync(ws.queue, 0, BWD_QUEUE_BYTES + (size_t)R, stream)); }
 
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles);
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles, im.tile_order_bw, ws.queue);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);
@@ -620,7 +648,7 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     GOF_PROFILE("integrate_pixels", stream);
     hipLaunchKernelGGL(integrate_pixels, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
-                       out_color, b.cmask, d.gx, d.ntiles);
+                       out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -916,6 +944,9 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
     }
     else if (n == "ranges" && image_ws) { src = im.ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
     else if (n == "point_ranges" && image_ws) { src = im.point_ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
+    else if (n == "tile_cost" && image_ws) { src = im.tile_cost; count = (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 4; }
+    else if (n == "tile_order" && image_ws) { src = im.tile_order; count = (int64_t)((d.ntiles + 7) / 8 * 8); bytes = (size_t)count * 4; }        // [8][ceil(T / 8)]
+    else if (n == "tile_order_bw" && image_ws) { src = im.tile_order_bw; count = (int64_t)((d.ntiles + 7) / 8 * 8); bytes = (size_t)count * 4; }
     else if (n == "final_T" && image_ws) { src = im.final_T; count = 4 * HW; bytes = 4 * HW * 4; }
     else if (n == "n_contrib" && image_ws) { src = im.n_contrib; count = 2 * HW; bytes = 2 * HW * 4; }
     else { set_error("unknown array '%s' (or its workspace is NULL)", name); return GOF_E_INVALID; }

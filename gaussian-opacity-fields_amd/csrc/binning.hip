@@ -165,6 +165,60 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
     if (idx == L - 1) ranges[currtile].y = L;
 }
 
+// Dispatch order of the tile kernels (pop_tile, gof_common.h): ONE workgroup ranks all tiles by cost, heaviest first (counting sort
+// over quarter-octave cost buckets: the order inside a bucket -- costs within 19 % -- is whatever the atomics give and does not
+// matter), deals the ranks to the 8 XCD queues in snake order and resets the queue heads.  cost = tile-list length (forward: an
+// upper bound of what the tile walks) or what the forward measured (backward).  What it buys is measured in bench.py's "clustered" leg.
+__global__ void __launch_bounds__(1024)
+order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cost_in, uint32_t* __restrict__ order,
+            uint32_t* __restrict__ queue)
+{
+    constexpr int NB = 128;                       // bucket = 4 * floor(log2(c)) + next two bits, descending
+    __shared__ uint32_t s_cnt[NB];
+    __shared__ uint32_t s_w0;
+    const uint32_t per = (ntiles + NXCD - 1) / NXCD;
+    if (threadIdx.x < NXCD && queue) queue[threadIdx.x] = 0u;      // heads (rank r goes to XCD (r & 8 ? 7 - (r & 7) : r & 7), slot r >> 3)
+    if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    auto bucket = [&](uint32_t t) -> uint32_t {
+        const uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);
+        if (c < 4u) return NB - 1u - c;                                            // 0..3 -> the last buckets
+        const uint32_t m = 31u - (uint32_t)__builtin_clz(c);
+        const uint32_t b = 4u * m + ((c >> (m - 2u)) & 3u);                        // 8 .. 127
+        return NB - 1u - b;
+    };
+    // the first 8192 tiles keep their bucket in registers between the two passes (one round of global loads, all in flight together)
+    constexpr int KEEP = 8;
+    uint8_t mine[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) { const uint32_t i = threadIdx.x + 1024u * k; mine[k] = i < ntiles ? (uint8_t)bucket(i) : (uint8_t)0; }
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) { const uint32_t i = threadIdx.x + 1024u * k; if (i < ntiles) atomicAdd(&s_cnt[mine[k]], 1u); }
+    for (uint32_t i = threadIdx.x + 1024u * KEEP; i < ntiles; i += 1024) atomicAdd(&s_cnt[bucket(i)], 1u);
+    __syncthreads();
+    {   // exclusive scan of the 128 counters by the first two waves
+        uint32_t c = 0, inc = 0;
+        if (threadIdx.x < NB) {
+            c = s_cnt[threadIdx.x];
+            inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o); if ((threadIdx.x & 63) >= (unsigned)o) inc += up; }
+            if (threadIdx.x == 63) s_w0 = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < NB) s_cnt[threadIdx.x] = inc - c + (threadIdx.x >= 64 ? s_w0 : 0u);
+    }
+    __syncthreads();
+    auto place = [&](uint32_t i, uint32_t bkt) {
+        const uint32_t r = atomicAdd(&s_cnt[bkt], 1u);
+        const uint32_t x = (r & 8u) ? 7u - (r & 7u) : (r & 7u);
+        order[x * per + (r >> 3)] = i;
+    };
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) { const uint32_t i = threadIdx.x + 1024u * k; if (i < ntiles) place(i, mine[k]); }
+    for (uint32_t i = threadIdx.x + 1024u * KEEP; i < ntiles; i += 1024) place(i, bucket(i));
+}
+
 // debug: the reference's 64-bit sort key of every sorted instance (tile << 32 | depth bits)
 __global__ void __launch_bounds__(256)
 rebuild_keys(uint32_t R, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ gids, const float* __restrict__ depths,

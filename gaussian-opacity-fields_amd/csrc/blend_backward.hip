@@ -63,6 +63,15 @@ __device__ unsigned long long g_bw_stats[8];
 #define BSTAT_ADD(i, v)
 #endif
 
+#ifdef GOF_TILE_CLOCK
+__device__ unsigned long long g_bw_tile_clock[2][1 << 16];
+#define TILE_CLOCK_START() const unsigned long long _t0 = wall_clock64()
+#define TILE_CLOCK_END(ARR) do { if (threadIdx.x == 0 && tile < (1u << 16)) { ARR[0][tile] = _t0; ARR[1][tile] = wall_clock64(); } } while (0)
+#else
+#define TILE_CLOCK_START()
+#define TILE_CLOCK_END(ARR)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
@@ -105,15 +114,15 @@ __device__ __forceinline__ float lane_xor(float v, uint32_t lane, uint32_t mask)
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane ^ mask) << 2), __float_as_int(v)));
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
-blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-               const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
-               const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-               const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-               float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx, uint32_t ntiles)
+// one tile; called by all 256 threads of the workgroup (persistent loop in blend_backward)
+__device__ __forceinline__ void
+blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+                    const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
+                    const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                    const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
+                    float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx)
 {
-    const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
+    TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -173,7 +182,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     }
     __syncthreads();
     const uint32_t max_last = min(s_max_last, range.y - range.x);
-    if (max_last == 0) return;
+    if (max_last == 0) { TILE_CLOCK_END(g_bw_tile_clock); return; }
 
     // accum_rec / accum_normal_rec of backward.cu:824-837, 862-867 for the channel pairs (colour 0, 1), (colour 2, normal 2),
     // (normal 0, 1).  The reference folds the PREVIOUS pair into them at the start of a pair (last_alpha, last_color); here the
@@ -398,6 +407,23 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
             }
         }
     }
+    TILE_CLOCK_END(g_bw_tile_clock);
+}
+
+// one workgroup per tile, popped as the workgroup starts: deepest walk first (pop_tile, gof_common.h; order by the forward's tile_cost)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+               const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
+               const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+               const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
+               float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx, uint32_t ntiles,
+               const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
+{
+    __shared__ uint32_t s_tile;
+    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);
+    if (tile >= ntiles) return;
+    blend_backward_tile(tile, ranges, point_list, rec, conic, cmask, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
+                        inst_off, part16, part17, part_valid, gx);
 }
 
 // Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):
@@ -506,6 +532,16 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
     }
 }
 
+#ifdef GOF_TILE_CLOCK
+extern "C" int gof_debug_bw_tile_clock(unsigned long long* out, int ntiles)      // out[2][ntiles]: start, end
+{
+    (void)hipDeviceSynchronize();
+    if (ntiles > (1 << 16)) return -1;
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bw_tile_clock), sizeof(unsigned long long) * ntiles, 0);
+    (void)hipMemcpyFromSymbol(out + ntiles, HIP_SYMBOL(g_bw_tile_clock), sizeof(unsigned long long) * ntiles, sizeof(unsigned long long) * (1 << 16));
+    return 0;
+}
+#endif
 #ifdef GOF_STATS
 extern "C" int gof_debug_bw_stats(unsigned long long* out8, int reset)
 {

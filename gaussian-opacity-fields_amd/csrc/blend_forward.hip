@@ -59,17 +59,28 @@ __device__ unsigned long long g_fw_stats[8];
 #define STAT_ADD(i, v)
 #endif
 
+#ifdef GOF_TILE_CLOCK
+// developer-only (-DGOF_TILE_CLOCK): per-tile start / end of the workgroup on the constant-rate counter (100 MHz): the scheduler's
+// efficiency = sum of the durations / (concurrency x makespan), tests/devtools/dev_tile_schedule.py
+__device__ unsigned long long g_fw_tile_clock[2][1 << 16];
+#define TILE_CLOCK_START() const unsigned long long _t0 = wall_clock64()
+#define TILE_CLOCK_END(ARR) do { if (threadIdx.x == 0 && tile < (1u << 16)) { ARR[0][tile] = _t0; ARR[1][tile] = wall_clock64(); } } while (0)
+#else
+#define TILE_CLOCK_START()
+#define TILE_CLOCK_END(ARR)
+#endif
+
 #ifndef GOF_FW_WAVES
 #define GOF_FW_WAVES 4       // LDS bounds the occupancy at 5 workgroups per CU; asking for 4 leaves the allocator more room (88 VGPR, measured -1 %)
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
-blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-              const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
-              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-              uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles)
+// one tile: everything below is per tile; called by all 256 threads of the workgroup (persistent loop in blend_forward)
+__device__ __forceinline__ void
+blend_forward_tile(const uint32_t tile, uint32_t* s_tile, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+                   const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                   uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost)
 {
-    const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
+    TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
     uint32_t lx, ly;
@@ -276,8 +287,44 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
         out_color[7 * HW + pix_id] = DA.y;
         out_color[8 * HW + pix_id] = distortion;
     }
+    // what this tile cost: the deepest list position any of its pixels blended = the entries the backward stages and walks
+    {
+        uint32_t m = inside ? last_contributor : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if (tid == 0) *s_tile = 0u;
+        __syncthreads();
+        if ((tid & 63u) == 0u) atomicMax(s_tile, m);
+        __syncthreads();
+        if (tid == 0) tile_cost[tile] = *s_tile;
+    }
+    TILE_CLOCK_END(g_fw_tile_clock);
 }
 
+// one workgroup per tile; WHICH tile is decided as the workgroup starts (pop_tile, gof_common.h): heaviest first, XCD queues of equal cost
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
+blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+              const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+              uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+              uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
+{
+    __shared__ uint32_t s_tile;
+    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);
+    if (tile >= ntiles) return;
+    blend_forward_tile(tile, &s_tile, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
+}
+
+#ifdef GOF_TILE_CLOCK
+extern "C" int gof_debug_fw_tile_clock(unsigned long long* out, int ntiles)      // out[2][ntiles]: start, end
+{
+    (void)hipDeviceSynchronize();
+    if (ntiles > (1 << 16)) return -1;
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fw_tile_clock), sizeof(unsigned long long) * ntiles, 0);
+    (void)hipMemcpyFromSymbol(out + ntiles, HIP_SYMBOL(g_fw_tile_clock), sizeof(unsigned long long) * ntiles, sizeof(unsigned long long) * (1 << 16));
+    return 0;
+}
+#endif
 #ifdef GOF_STATS
 extern "C" int gof_debug_fw_stats(unsigned long long* out8, int reset)
 {

@@ -40,9 +40,11 @@ __global__ void __launch_bounds__(256)
 integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
                  const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
                  float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles)
+                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles,
+                 const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
 {
-    const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
+    __shared__ uint32_t s_tile;
+    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);      // longest list first (gof_common.h)
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;

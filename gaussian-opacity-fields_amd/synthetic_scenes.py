@@ -96,6 +96,38 @@ def scene_frustum(P, W=1600, H=1063, focal=1200.0, seed=0, sh_degree=3, sigma_px
     return scene if pose_seed is None else pose_scene(scene, pose_seed)
 
 
+def scene_clustered(P=1_000_000, W=1600, H=1063, focal=1200.0, seed=0, sh_degree=3, kernel_size=0.0, pose_seed=None,
+                    frac_clustered=0.70, frac_large=0.02, n_clusters=5):
+    """"S1M-clustered": a heavy-tailed sibling of scene_frustum for the tile scheduler (real captures have empty sky tiles next to
+    10k-entry foreground tiles; S1M's lists are 1319 +- 100 entries and every tile costs the same).  70 % of the Gaussians sit in
+    `n_clusters` compact blobs that together fill ~5 % of the frustum volume (Gaussian balls in (x/z, y/z, log z)) and are
+    semi-transparent (opacity U[0.02, 0.3]: foliage-like, a pixel blends hundreds of them before it saturates); 2 % are large
+    splats (sigma_px 30-100) at the back of the scene (depth 15-20: walls / sky, they lengthen every list without saturating
+    the front); the remaining 28 % are scene_frustum's uniform background.  Anisotropy, quaternions, SH follow scene_frustum."""
+    rng = np.random.default_rng(seed + 77)
+    sc = scene_frustum(P, W=W, H=H, focal=focal, seed=seed, sh_degree=sh_degree, kernel_size=kernel_size)
+    tanx, tany = sc["tanfovx"], sc["tanfovy"]
+    n_c = int(P * frac_clustered); n_l = int(P * frac_large)
+    means = sc["means3D"]; scales = sc["scales"]
+    cu = rng.uniform(-0.8, 0.8, (n_clusters, 2)); cz = rng.uniform(3.0, 12.0, n_clusters)
+    which = rng.integers(0, n_clusters, n_c)
+    s_rel = 0.105                                          # n blobs of relative radius s fill ~ n (4/3) pi s^3 / 8 of the (u, v, log z) box
+    u = cu[which, 0] + rng.normal(0, s_rel, n_c)
+    v = cu[which, 1] + rng.normal(0, s_rel, n_c)
+    z = cz[which] * np.exp(rng.normal(0, s_rel * 1.5, n_c))
+    idx = rng.permutation(P)
+    ic, il = idx[:n_c], idx[n_c:n_c + n_l]
+    means[ic] = np.stack([u * z * tanx, v * z * tany, z], 1).astype(np.float32)
+    base = np.exp(rng.normal(math.log(2.0), 0.5, n_c))
+    scales[ic] = (base[:, None] * z[:, None] / focal * np.exp(rng.normal(0.0, 0.5, (n_c, 3)))).astype(np.float32)
+    sc["opacities"][ic] = rng.uniform(0.02, 0.3, (n_c, 1)).astype(np.float32)
+    zl = rng.uniform(15.0, 20.0, n_l)
+    means[il] = np.stack([zl * tanx * rng.uniform(-1.0, 1.0, n_l), zl * tany * rng.uniform(-1.0, 1.0, n_l), zl], 1).astype(np.float32)
+    big = rng.uniform(30.0, 100.0, n_l)
+    scales[il] = (big[:, None] * zl[:, None] / focal * np.exp(rng.normal(0.0, 0.3, (n_l, 3)))).astype(np.float32)
+    return sc if pose_seed is None else pose_scene(sc, pose_seed)
+
+
 def _quat_to_rot(q):
     r, x, y, z = q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],

@@ -104,6 +104,10 @@ SCENES = {
     "posed_long_lists": lambda: S.scene_frustum(3000, W=32, H=32, focal=24.0, seed=4, sigma_px=6.0, pose_seed=4),
     "posed_mid100k": lambda: S.scene_frustum(100_000, W=800, H=528, focal=600.0, seed=5, pose_seed=5),
     "posed_stress_box": lambda: S.pose_scene(stress_scene(), 6),
+    # heavy-tailed tile lists (synthetic_scenes.scene_clustered: semi-transparent blobs + far large splats + sparse background): the
+    # tile scheduler (order_tiles / pop_tile) deals tiles heaviest first -- every tile must still be rendered exactly once
+    "clustered150k": lambda: S.scene_clustered(150_000, W=640, H=432, focal=480.0, seed=3),
+    "posed_clustered150k": lambda: S.scene_clustered(150_000, W=640, H=432, focal=480.0, seed=4, pose_seed=13),
     "posed_mod2": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=9, sigma_px=1.5, pose_seed=7), "scale_modifier": 2.0},
     "posed_mod05_ks01": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=10, sigma_px=5.0, kernel_size=0.1, pose_seed=8), "scale_modifier": 0.5},
 }
@@ -325,7 +329,7 @@ def _product_backward(res, dL):
     return {n: g.cpu().numpy() for n, g in zip(names, grads)}
 
 
-@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k"] + POSED)
+@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "clustered150k"] + POSED)
 def test_backward_blend_gradients(name):
     sc = SCENES[name]()
     o, oc, orad, res = _forward_pair(sc)
@@ -845,6 +849,43 @@ def test_full_size_s1m_posed_against_oracle():
     iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
     for k in ("means3D", "sh", "scales", "rotations"):
         assert_k9_close(gp[k], iso[k], k)
+
+
+def test_full_size_s1m_clustered_against_oracle():
+    """The heavy-tailed sibling of S1M at full size (1M Gaussians, 1600x1063, 24.8M instances, tile lists of 1300 ... 14500 entries,
+    220 ... 2060 of them walked): the tile kernels take their tiles from cost-ordered queues (heaviest first, dealt to the XCDs) --
+    sorted list, contributor counts, transmittances and image bit-exact, blend gradients within tolerance, and the dispatch order is
+    a permutation of the tiles with the heaviest list first."""
+    sc = S.scene_clustered(1_000_000, seed=0)
+    o, oc, orad, res = _forward_pair(sc)
+    assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad) and res["R"] > 20_000_000
+    assert _same(fetch(res, "point_list"), o.fetch("point_list"))
+    assert _same(fetch(res, "n_contrib"), o.fetch("n_contrib"))
+    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["color"].cpu().numpy(), oc)
+    rg = fetch(res, "ranges").view(np.uint32).reshape(-1, 2)
+    L = rg[:, 1].astype(np.int64) - rg[:, 0]
+    T = len(L); per = (T + 7) // 8
+    order = fetch(res, "tile_order").astype(np.int64)
+    qlen = [2 * (T >> 4) + (1 if x < min(T & 15, 8) else 0) + (1 if ((T & 15) > 8 and x >= 16 - (T & 15)) else 0) for x in range(8)]
+    tiles = np.concatenate([order[x * per:x * per + qlen[x]] for x in range(8)])
+    assert np.array_equal(np.sort(tiles), np.arange(T))                                  # every tile exactly once
+    for x in range(8):
+        q = L[order[x * per:x * per + qlen[x]]]
+        assert q[0] >= 0.8 * L.max() and (q[:-1] * 1.2 + 4 >= q[1:]).all()               # heaviest first, non-increasing up to the bucket width
+    sums = [L[order[x * per:x * per + qlen[x]]].sum() for x in range(8)]
+    assert max(sums) <= 1.02 * min(sums)                                                  # the deal balances the XCD queues
+    walked = fetch(res, "tile_cost").astype(np.int64)
+    nc = o.fetch("n_contrib").reshape(2, sc["H"], sc["W"])[0].astype(np.int64)
+    gx, gy = (sc["W"] + 15) // 16, (sc["H"] + 15) // 16
+    pad = np.zeros((gy * 16, gx * 16), np.int64); pad[:sc["H"], :sc["W"]] = nc
+    assert np.array_equal(walked, pad.reshape(gy, 16, gx, 16).max(axis=(1, 3)).reshape(-1))   # the backward's cost: deepest blended position per tile
+    assert walked.max() > 5 * np.median(walked)                                          # heavy-tailed indeed
+    dL = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
+    go = o.backward(dL)
+    gp = _product_backward(res, dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian"):
+        assert_grad_close(gp[k], go[k], k)
 
 
 def test_full_size_properties_s1m():
