@@ -156,12 +156,20 @@ def main():
     prof_steps = max(4, min(16, args.steps))
     if rank == 0:
         B.profile_enable(True)
+    if distributed:
+        reducer.profile = True                    # stream events around every phase of the exchange, on every rank
     for _ in range(prof_steps):
         step()
     fence()
     if rank == 0:
         kernel_times = B.profile_report()
         B.profile_enable(False)
+    exchange_phases = None
+    if distributed:
+        reducer.profile = False
+        mine = dict(reducer.breakdown(), rank=rank, buckets_in_place_and_packed=reducer.last_buckets)
+        exchange_phases = [None] * world
+        dist.all_gather_object(exchange_phases, mine)
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,6 +205,11 @@ def main():
             out["exchange"] = {"kind": kind, "ms": round(exchange_ms, 4), "wire_bytes_per_rank": int(wire),
                                "wire_GBps_per_rank": round(wire / (exchange_ms * 1e-3) / 1e9, 1) if exchange_ms else None,
                                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               # mean ms per step and rank of every phase (instrumented pass, not the timed one): pack = colour-gradient
+                               # pack + camera row (inside the backward), gather_wait / reduce_wait = EXPOSED part of the all-gather /
+                               # all-reduce (compute stream waiting for the communication stream), expand = SH expansion kernel,
+                               # bucket_pack / bucket_unpack = copies of gradients outside the rasterizer's allocation (none here)
+                               "per_rank_phases_ms": exchange_phases,
                                "what": "exposed time of GradientAllReducer.all_reduce() per step (max over ranks), from stream events around it; "
                                        "the all-gather of the colour gradient starts inside the backward and overlaps preprocess_bwd"}
         if world == 1 and not args.no_full_loop:
@@ -294,8 +307,25 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
                     "vector-ALU issue, not by HBM -- their roofline is under 'valu'; the HBM-bound stages are listed under 'kernels'",
             "kernels": kernels,
             "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd, "contributing_pairs": pairs,
-                         "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)}}
+                         "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)},
+            "workspace": workspace_report(B, P, W, H, R)}
     return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": R, "roofline": roof}
+
+
+def workspace_report(B, P, W, H, R):
+    """Bytes of the caller-owned workspaces of one forward + backward, and what an INSTANCE (one (tile, Gaussian) pair of the sorted
+    list) costs: sort state 16 B + contributor masks 32 B (binning workspace) + partial gradient record 69 B (backward scratch) = 117 B,
+    where the reference's BinningState holds 24 B (rasterizer_impl.h:60-70) -- a stated deviation: the masks
+    and records buy the backward without re-derived decisions and without atomics; they scale with R."""
+    lib = B.lib
+    geom, image = int(lib.gof_geom_bytes(P)), int(lib.gof_image_bytes(W, H))
+    binning, scratch = int(lib.gof_binning_bytes(R, W, H)), int(lib.gof_backward_scratch_bytes(P, R))
+    d_bin = (int(lib.gof_binning_bytes(2 * R, W, H)) - binning) / max(R, 1)
+    d_scr = (int(lib.gof_backward_scratch_bytes(P, 2 * R)) - scratch) / max(R, 1)
+    return {"geometry_bytes": geom, "image_bytes": image, "binning_bytes": binning, "backward_scratch_bytes": scratch,
+            "per_gaussian_geometry_bytes": round(geom / max(P, 1), 1), "per_instance_binning_bytes": round(d_bin, 1),
+            "per_instance_backward_scratch_bytes": round(d_scr, 1), "per_instance_total_bytes": round(d_bin + d_scr, 1),
+            "reference_per_instance_bytes": 24, "reference_per_gaussian_bytes": 119}
 
 
 def clustered_leg(dev, P, W, H, focal, kernel_size, s1m_ms, steps=20, warmup=3):
@@ -561,7 +591,36 @@ def cpu_baseline(args, W, H, focal):
     cores = int(ob.lib().gofref_num_threads())
     return {"value": round(1.0 / (t2 - t0), 4), "unit": "iters/s", "cores": cores, "kind": "port",
             "sample": "oracle (OpenMP CPU restatement of the reference) fwd+bwd on %d Gaussians (%.0f%% of the workload's count) at %dx%d, one "
-                      "iteration on the GPU box's host threads; fwd %.2fs bwd %.2fs" % (Pc, 100.0 * Pc / args.gaussians, W, H, t1 - t0, t2 - t1)}
+                      "iteration on the GPU box's host threads; fwd %.2fs bwd %.2fs" % (Pc, 100.0 * Pc / args.gaussians, W, H, t1 - t0, t2 - t1),
+            "torch_cpu": torch_cpu_baseline()}
+
+
+def torch_cpu_baseline():
+    """north_star: "next to the reference's PyTorch-CPU render path timed on the same box's host cores" -- BASELINE config 1 (lego-like
+    10 000 Gaussians @ 400x400, forward render).  The reference itself has no CPU path (gaussian_renderer/__init__.py:26 hard-wires
+    "cuda"); its CPU-runnable form is the dense PyTorch restatement oracle/render_torch_cpu.py (test infrastructure, float64 and --
+    the reference's precision -- float32), timed here beside the HIP forward of the same scene."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import render_torch_cpu as RT
+    import synthetic_scenes as S
+    from gpu_common import to_dev, product_forward_raw
+    sc = S.scene_lego_like(10_000, 400, 400, seed=0)
+    out = {"workload": "BASELINE config 1: lego-like 10000 Gaussians @ 400x400, SH degree 3, forward render", "threads": torch.get_num_threads()}
+    for name, dt in (("float32", torch.float32), ("float64", torch.float64)):
+        t0 = time.perf_counter()
+        RT.render_torch_cpu(sc, dtype=dt)
+        out["torch_cpu_%s_s" % name] = round(time.perf_counter() - t0, 3)
+    sd = to_dev(sc)
+    for _ in range(3):
+        product_forward_raw(sd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        product_forward_raw(sd)
+    torch.cuda.synchronize()
+    out["hip_forward_ms"] = round(1e3 * (time.perf_counter() - t0) / 20, 4)
+    out["renders_per_s"] = {"torch_cpu_float32": round(1.0 / out["torch_cpu_float32_s"], 3), "hip": round(1e3 / out["hip_forward_ms"], 1)}
+    return out
 
 
 if __name__ == "__main__":

@@ -121,7 +121,7 @@ act_scaling_fwd(int64_t P, const float* __restrict__ rs, const float* __restrict
     for (int c = 0; c < 3; c++) { const float s = expf(rs[3 * i + c]); out[3 * i + c] = sqrtf(s * s + ff); }     // :160-161
 }
 __global__ void __launch_bounds__(256)
-act_scaling_bwd(int64_t P, const float* __restrict__ rs, const float* __restrict__ f3, const float* __restrict__ g, float* __restrict__ grs)
+act_scaling_bwd(int64_t P, const float* __restrict__ rs, const float* __restrict__ f3, const float* g, float* grs)      // grs may alias g (in-place, activations.INPLACE_GRAD)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -149,8 +149,8 @@ act_opacity_fwd(int64_t P, const float* __restrict__ ro, const float* __restrict
     out[i] = o * coef;                                          // :194
 }
 __global__ void __launch_bounds__(256)
-act_opacity_bwd(int64_t P, const float* __restrict__ ro, const float* __restrict__ rs, const float* __restrict__ f3, const float* __restrict__ g,
-                float* __restrict__ gro, float* __restrict__ grs)
+act_opacity_bwd(int64_t P, const float* __restrict__ ro, const float* __restrict__ rs, const float* __restrict__ f3, const float* g,
+                float* gro, float* __restrict__ grs)                                                                    // gro may alias g
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -178,7 +178,7 @@ act_rotation_fwd(int64_t P, const float4* __restrict__ rr, float4* __restrict__ 
     out[i] = make_float4(r.x / d, r.y / d, r.z / d, r.w / d);
 }
 __global__ void __launch_bounds__(256)
-act_rotation_bwd(int64_t P, const float4* __restrict__ rr, const float4* __restrict__ g, float4* __restrict__ grr)
+act_rotation_bwd(int64_t P, const float4* __restrict__ rr, const float4* g, float4* grr)                                  // grr may alias g
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;

@@ -195,6 +195,21 @@ def _round_capacity(n):
     return (int(n * 1.25) + (1 << 16)) & ~0xFFFF
 
 
+class NumRendered(int):
+    """``num_rendered`` as the reference returns it -- the instance count of the frame (rasterize_points.cu:119) -- that also
+    remembers the CAPACITY the frame's binning workspace was laid out for when the sync-free forward ran (``layout``; equal to
+    the count on the two-stage path).  The backward needs the layout size to find its arrays; everything else sees the count."""
+
+    def __new__(cls, count, layout=None):
+        self = super().__new__(cls, count)
+        self.layout = int(count if layout is None else layout)
+        return self
+
+
+def _layout_count(num_rendered):
+    return int(getattr(num_rendered, "layout", num_rendered))
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         view2gaussian_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
                         image_height, image_width, sh, degree, campos, prefiltered, debug, fused=None):
@@ -203,8 +218,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
     The first frame of a (device, P, W, H) shape runs the reference's two-stage forward (instance count read back in the middle to
     size the binning buffer).  Later frames size that buffer for 1.25 x the last count and run ``gof_forward_fused`` -- no pipeline
-    bubble; the returned ``num_rendered`` is then the CAPACITY (it fixes the workspace layout for the backward); a frame that
-    needs more is redone through the two-stage path, transparently.  ``fused=False`` / ``GOF_FUSED_FORWARD=0`` disable this."""
+    bubble; the returned ``num_rendered`` is the frame's true instance count and carries, as ``.layout``, the capacity that fixes
+    the workspace layout for the backward (NumRendered); a frame that needs more is redone through the two-stage path, transparently.  ``fused=False`` / ``GOF_FUSED_FORWARD=0`` disable this."""
     v = _View(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, view2gaussian_precomp,
               viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh,
               degree, campos, prefiltered, debug)
@@ -231,7 +246,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 true_r = int(pin[0].item()) & 0xFFFFFFFF
                 if _round_capacity(true_r) > cap:
                     _capacity[shape_key] = _round_capacity(true_r)        # growing scene: stay ahead of it
-                return cap, out_color, radii, geom, binning, img
+                return NumRendered(true_r, cap), out_color, radii, geom, binning, img
             if rc != GOF_E_CAPACITY:
                 _check(rc)
             del geom, img, binning, radii                                     # too small: redo the frame below with the exact count
@@ -240,7 +255,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                       _ptr(img), img.numel(), _ptr(out_color), _stream()))
         if use_fused and not prefiltered and not debug:
             _capacity[shape_key] = max(_capacity.get(shape_key, 0), _round_capacity(rendered))
-    return rendered, out_color, radii, geom, binning, img
+    return NumRendered(rendered), out_color, radii, geom, binning, img
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
@@ -280,6 +295,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):
+            R = _layout_count(R)                  # the size the forward laid the binning workspace out for (NumRendered)
             nscratch = lib.gof_backward_scratch_bytes(P, int(R))
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
@@ -557,10 +573,10 @@ def debug_fetch(name, view, num_rendered, geom, binning, img):
     dtype, per = _FETCH[name]
     P, HW = view.P, view.H * view.W
     T = ((view.W + 15) // 16) * ((view.H + 15) // 16)
-    count = {"point_list": num_rendered, "point_list_keys": num_rendered, "ranges": 2 * T, "point_ranges": 2 * T,
+    count = {"point_list": _layout_count(num_rendered), "point_list_keys": _layout_count(num_rendered), "ranges": 2 * T, "point_ranges": 2 * T,
              "final_T": 4 * HW, "n_contrib": 2 * HW, "contrib_pairs": T, "tile_cost": T, "tile_order": (T + 7) // 8 * 8, "tile_order_bw": (T + 7) // 8 * 8}.get(name, P * per)
     out = torch.empty(count, dtype=dtype, device=view.device)
-    n = lib.gof_debug_fetch(name.encode(), view.ref(), int(num_rendered), _ptr(geom), _ptr(binning), _ptr(img),
+    n = lib.gof_debug_fetch(name.encode(), view.ref(), _layout_count(num_rendered), _ptr(geom), _ptr(binning), _ptr(img),
                             C.c_void_p(out.data_ptr()), out.numel() * out.element_size(), _stream())
     if n < 0:
         _check(int(n))

@@ -72,7 +72,11 @@ class GradientAllReducer:
             raise ValueError("sh_params: one [P,M,3] tensor or the pair (features_dc, features_rest)")
         self._sh_ops = sh_ops
         self.last_exchange = None                    # "dense" | "compressed-sh": what the last all_reduce() did (tests, logging)
+        self.last_buckets = None                     # (in-place buckets, packed tensors) of the last dense part (tests, logging)
         self._early = []                             # all-gathers started from inside the backward since the last exchange
+        self.profile = False                         # True: stream events around every phase of the exchange (bench.py --gpus N)
+        self._phases = []                            # per exchange: {phase: (start event, end event)}
+        self._cur = None
         if self.sh_params and track:
             self.enable_sh_tracking(early_gather)
 
@@ -101,13 +105,51 @@ class GradientAllReducer:
             self._sh_ops = _HipOps
         return self._sh_ops
 
+    # ---- phase timing (profile=True): events on the current stream; a phase that ends with work.wait() includes the time the
+    # compute stream sat waiting for the communication stream, i.e. the EXPOSED part of that collective
+    class _Phase:
+        def __init__(self, owner, name):
+            self.o, self.name = owner, name
+
+        def __enter__(self):
+            o = self.o
+            if o.profile and torch.cuda.is_available():
+                if o._cur is None:
+                    o._cur = {}
+                self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            o = self.o
+            if o.profile and torch.cuda.is_available():
+                self.e1.record()
+                o._cur.setdefault(self.name, []).append((self.e0, self.e1))
+            return False
+
+    def _phase(self, name):
+        return GradientAllReducer._Phase(self, name)
+
+    def breakdown(self):
+        """Mean milliseconds per exchange of every phase recorded since the last call (profile=True): pack (colour-gradient pack +
+        camera row), gather_wait (exposed all-gather), expand (SH expansion kernel), bucket_pack / bucket_unpack (copies of gradients
+        that do not share the rasterizer's allocation), reduce_wait (exposed all-reduce)."""
+        torch.cuda.synchronize()
+        out, n = {}, max(1, len(self._phases))
+        for ph in self._phases:
+            for name, evs in ph.items():
+                out[name] = out.get(name, 0.0) + sum(a.elapsed_time(b) for a, b in evs)
+        self._phases = []
+        return {k: round(v / n, 4) for k, v in out.items()}
+
     def _start_gather(self, src, world):
         """Pack this view's colour gradient (+ camera centre) and START the all-gather; returns (src, gathered, work)."""
         P = src["P"]
         dev = src["dL_dcolors"].device if "dL_dcolors" in src else src["campos"].device
         mine = torch.empty((P + 1, 3), dtype=torch.float32, device=dev)
-        self._ops().pack(src, mine)
-        mine[P].copy_(src["campos"].reshape(3))
+        with self._phase("pack"):
+            self._ops().pack(src, mine)
+            mine[P].copy_(src["campos"].reshape(3))
         gathered = torch.empty((world, P + 1, 3), dtype=torch.float32, device=dev)
         if dist.get_backend(self.group) == "nccl":
             work = dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
@@ -139,8 +181,10 @@ class GradientAllReducer:
         """Wait for the all-gather only and expand the sum over views into the SH gradients (the all-reduce of the other
         gradients, issued behind the all-gather, keeps running on the communication stream meanwhile)."""
         src, gathered, work, grads = pending
-        work.wait()
-        self._ops().expand(src, gathered, 1.0 / world if self.average else 1.0, grads)
+        with self._phase("gather_wait"):
+            work.wait()
+        with self._phase("expand"):
+            self._ops().expand(src, gathered, 1.0 / world if self.average else 1.0, grads)
 
     def _ensure(self, n, device, dtype):
         if self._flat is None or self._flat.numel() != n or self._flat.device != device:
@@ -184,45 +228,70 @@ class GradientAllReducer:
             self._sh_finish(pending, world)
         if finish_dense is not None:
             finish_dense()
+        if self.profile and self._cur is not None:
+            self._phases.append(self._cur)
+            self._cur = None
 
     def _dense_begin(self, ps, world):
-        """Start the all-reduce of the gradients of `ps`; returns the callable that completes it."""
-        bucket = self._shared_bucket([p.grad for p in ps])
-        if bucket is not None and self.wire_dtype is not None:
-            if self._wire is None or self._wire.numel() != bucket.numel() or self._wire.device != bucket.device:
-                self._wire = torch.empty(bucket.numel(), dtype=self.wire_dtype, device=bucket.device)
-            self._wire.copy_(bucket)
-            work = dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        """Start the all-reduce of the gradients of `ps`; returns the callable that completes it.  Gradients that are views of ONE
+        allocation without gaps -- the rasterizer's backward carves the parameter gradients that way, and under
+        train_epilogue.activations.INPLACE_GRAD the activation backwards keep them there -- are reduced IN PLACE, one collective per
+        such allocation; whatever is left (appearance network, foreign gradients) is packed into one flat buffer."""
+        by_storage = {}
+        for p in ps:
+            g = p.grad
+            key = (g.untyped_storage().data_ptr(), g.device, g.dtype) if g.is_contiguous() else None
+            by_storage.setdefault(key, []).append(p)
+        buckets, rest = [], []
+        for key, group in by_storage.items():
+            b = self._shared_bucket([p.grad for p in group]) if (key is not None and self.wire_dtype is None) else None
+            if b is not None and (len(group) > 1 or len(by_storage) == 1):
+                buckets.append(b)
+            else:
+                rest.extend(group)
+        if self.wire_dtype is not None and len(by_storage) == 1 and None not in by_storage:
+            bucket = self._shared_bucket([p.grad for p in ps])
+            if bucket is not None:
+                if self._wire is None or self._wire.numel() != bucket.numel() or self._wire.device != bucket.device:
+                    self._wire = torch.empty(bucket.numel(), dtype=self.wire_dtype, device=bucket.device)
+                self._wire.copy_(bucket)
+                work = dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.last_buckets = (1, 0)
 
-            def finish():
-                work.wait()
-                bucket.copy_(self._wire)
-                if self.average:
-                    bucket.div_(world)
-            return finish
-        if bucket is not None:                       # the rasterizer's backward carved them from one allocation: reduce in place
-            work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-            def finish():
-                work.wait()
-                if self.average:
-                    bucket.div_(world)
-            return finish
-        for p in ps:                                 # a non-contiguous gradient would be COPIED by reshape(-1) and the reduced values lost
-            if not p.grad.is_contiguous():
-                p.grad = p.grad.contiguous()
-        grads = [p.grad.view(-1) for p in ps]
-        n = sum(g.numel() for g in grads)
-        flat = self._ensure(n, grads[0].device, grads[0].dtype)
-        views = list(torch.split(flat, [g.numel() for g in grads]))
-        torch._foreach_copy_(views, grads)
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                def finish_wire():
+                    with self._phase("reduce_wait"):
+                        work.wait()
+                    bucket.copy_(self._wire)
+                    if self.average:
+                        bucket.div_(world)
+                return finish_wire
+        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in buckets]
+        flat = views = grads = None
+        if rest:
+            for p in rest:                           # a non-contiguous gradient would be COPIED by reshape(-1) and the reduced values lost
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+            grads = [p.grad.view(-1) for p in rest]
+            n = sum(g.numel() for g in grads)
+            flat = self._ensure(n, grads[0].device, grads[0].dtype)
+            views = list(torch.split(flat, [g.numel() for g in grads]))
+            with self._phase("bucket_pack"):
+                torch._foreach_copy_(views, grads)
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.last_buckets = (len(buckets), len(rest))
 
         def finish():
-            work.wait()
+            with self._phase("reduce_wait"):
+                for w in works:
+                    w.wait()
             if self.average:
-                flat.div_(world)
-            torch._foreach_copy_(grads, views)
+                for b in buckets:
+                    b.div_(world)
+            if rest:
+                if self.average:
+                    flat.div_(world)
+                with self._phase("bucket_unpack"):
+                    torch._foreach_copy_(grads, views)
         return finish
 
 

@@ -58,6 +58,11 @@ def pick_visible_device(local_rank, env, share=False):
 
 os.environ["HIP_VISIBLE_DEVICES"] = pick_visible_device(local_rank, os.environ, SHARE_GPU)   # before importing torch
 os.environ.pop("CUDA_VISIBLE_DEVICES", None)              # one mask only: the two would be intersected
+# RCCL between processes that each see ONE device: peer buffers are exchanged as dmabuf IPC handles, the only form this platform's
+# driver supports (without it: hipIpcGetMemHandle "invalid argument" at communicator set-up).  Nothing else of RCCL's environment is
+# touched -- channel counts (NCCL_MIN_NCHANNELS) and protocol choices stay at the library's defaults until an 8-GPU run measures them
+# (DESIGN.md section 6); whatever the user exports is passed through.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, PKG)
@@ -116,6 +121,11 @@ def main():
     GaussianModel.compute_3D_filter = lambda self, cameras: _ref_filter(self, full_camera_list(cameras))
 
     _setup = GaussianModel.training_setup
+    # the activation backwards leave the gradients of _opacity / _scaling / _rotation in the rasterizer's gradient allocation, next
+    # to _xyz's: the reducer then all-reduces that bucket in place (train_epilogue/activations.py; GOF_DP_INPLACE_ACT=0 switches it off)
+    if os.environ.get("GOF_DP_INPLACE_ACT", "1") != "0" and os.environ.get("GOF_TORCH_EPILOGUE") != "1":
+        import importlib
+        importlib.import_module("train_epilogue.activations").INPLACE_GRAD = True
 
     def training_setup(self, training_args):
         _setup(self, training_args)

@@ -15,6 +15,24 @@ from . import _backend as B
 
 lib = B.lib
 _vp, _i64 = C.c_void_p, C.c_int64
+
+# Data-parallel training (launch/run_train_dp.py sets this): the backward of an activation writes the gradient of the RAW parameter
+# over its incoming gradient -- same shape, element-wise kernels -- instead of into a fresh tensor.  The incoming gradients are the
+# rasterizer's dL_dopacity / dL_dscales / dL_drotations, segments of the ONE allocation its backward carves the parameter gradients
+# from (diff_gaussian_rasterization/_backend.py), so _opacity.grad / _scaling.grad / _rotation.grad end up next to _xyz.grad in that
+# allocation and dp.GradientAllReducer all-reduces them IN PLACE (no pack / unpack of 44 B per Gaussian).  _scaling receives a second
+# contribution from the opacity activation; autograd adds it in place to the first one it saw -- the scaling activation's, which
+# render() creates after the opacity's (gaussian_renderer/__init__.py:60,70) and which therefore runs first in the backward.  If an
+# order ever differs the reducer simply packs that tensor: correctness does not depend on it.  Off by default: a caller that keeps a
+# reference to the rasterizer's activated-parameter gradients (retain_grad, hooks) would see them overwritten.
+INPLACE_GRAD = False
+
+
+def _out_like(g, ref):
+    """where the raw-parameter gradient goes: over the incoming gradient under INPLACE_GRAD, else a fresh tensor"""
+    if INPLACE_GRAD and g.is_contiguous() and g.dtype == torch.float32 and g.device == ref.device and g.numel() == ref.numel():
+        return g.view(ref.shape)
+    return torch.empty_like(ref)
 for _name, _n in (("gof_act_scaling", 3), ("gof_act_scaling_backward", 4), ("gof_act_opacity", 4), ("gof_act_opacity_backward", 6),
                   ("gof_act_rotation", 2), ("gof_act_rotation_backward", 3)):
     getattr(lib, _name).restype = C.c_int
@@ -44,7 +62,7 @@ class _Scaling(torch.autograd.Function):
     def backward(ctx, g):
         rs, f = ctx.saved_tensors
         g = g.contiguous()
-        grs = torch.empty_like(rs)
+        grs = _out_like(g, rs)
         with torch.cuda.device(rs.device):
             B._check(lib.gof_act_scaling_backward(int(rs.shape[0]), rs.data_ptr(), f.data_ptr(), g.data_ptr(), grs.data_ptr(), B._stream()))
         return grs, None
@@ -67,7 +85,7 @@ class _Opacity(torch.autograd.Function):
     def backward(ctx, g):
         ro, rs, f = ctx.saved_tensors
         g = g.contiguous()
-        gro, grs = torch.empty_like(ro), torch.empty_like(rs)
+        gro, grs = _out_like(g, ro), torch.empty_like(rs)
         with torch.cuda.device(rs.device):
             B._check(lib.gof_act_opacity_backward(int(rs.shape[0]), ro.data_ptr(), rs.data_ptr(), f.data_ptr(), g.data_ptr(), gro.data_ptr(),
                                                   grs.data_ptr(), B._stream()))
@@ -90,7 +108,7 @@ class _Rotation(torch.autograd.Function):
     def backward(ctx, g):
         (rr,) = ctx.saved_tensors
         g = g.contiguous()
-        grr = torch.empty_like(rr)
+        grr = _out_like(g, rr)
         with torch.cuda.device(rr.device):
             B._check(lib.gof_act_rotation_backward(int(rr.shape[0]), rr.data_ptr(), g.data_ptr(), grr.data_ptr(), B._stream()))
         return grr

@@ -67,8 +67,16 @@ for k in kernels:
         if gui and c.get("SQ_ACTIVE_INST_VALU"):
             cycles = gui / 8.0
             e["gpu_cycles"] = cycles
-            e["valu_pipe_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles)          # quad-cycles -> cycles, 1024 SIMDs
-            e["valu_issue_frac"] = e["valu_pipe_busy_frac"]
+            # rocprof's VALUBusy: per-WAVE "a VALU instruction of mine is in the pipe" time (quad-cycles -> cycles) summed over the waves,
+            # over the SIMD-cycles of the launch.  Two waves of a SIMD overlap in the pipe (the next wave issues while a multi-pass
+            # instruction -- fp64, transcendental, cross-lane -- of another still executes), so the ratio is an ACTIVITY figure that can
+            # exceed 1 (integrate_pixels 1.10, integrate_points 1.43 in round 2: long fp32 division / sqrt sequences); it was labelled
+            # "pipe busy" before, which a value above 1 cannot be.  The bounded companion is the issue rate below.
+            e["valu_active_over_simd_cycles"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles)
+            e["valu_pipe_busy_frac"] = e["valu_active_over_simd_cycles"]                          # (old key, kept for bench.py's reader)
+            e["valu_issue_frac"] = min(1.0, e["valu_active_over_simd_cycles"])
+            if c.get("SQ_INSTS_VALU"):
+                e["valu_insts_per_simd_cycle"] = c["SQ_INSTS_VALU"] / (1024.0 * cycles)           # wave64 instructions issued per SIMD and cycle
         if c.get("SQ_INSTS_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
             e["cycles_per_valu_inst"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
         if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
@@ -95,14 +103,16 @@ with open(md, "w") as o:
     for k, v in sorted(((k, v) for k, v in data.items() if isinstance(v, dict) and "hbm_bytes_corrected" in v), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
         o.write("| %s | %.0f | %.1f | %.0f | %.1f |\n" % (k, v["fetch_KiB_raw"], 2 * v["fetch_KiB_raw"] * 1024 / 1e6, v["write_KiB"], v["write_KiB"] * 1024 / 1e6))
     o.write("\n## Vector-ALU counters of the kernels (separate SQ passes)\n\n"
-            "VALU pipe busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x kernel cycles); cycles per VALU instruction = pipe time / SQ_INSTS_VALU;\n"
+            "VALU active = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x kernel cycles): per-wave in-pipe time summed over the waves -- waves of a SIMD overlap\n"
+            "in the pipe, so this is an activity figure that CAN exceed 1 (it is rocprof's VALUBusy); VALU inst / SIMD-cycle = SQ_INSTS_VALU / (1024 x kernel cycles) is the bounded\n"
+            "issue rate; cycles per VALU instruction = active time / SQ_INSTS_VALU;\n"
             "lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wave-cycle split: parked at s_waitcnt / barrier (WAIT_ANY), issue stall\n"
             "(WAIT_INST_ANY), issuing (ACTIVE_INST_ANY).\n\n"
-            "| kernel | VALU insts | VALU pipe busy | cycles / VALU inst | lane utilisation | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | LDS bank conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|---|\n")
+            "| kernel | VALU insts | VALU active / SIMD-cycles | VALU inst / SIMD-cycle | cycles / VALU inst | lane utilisation | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | LDS bank conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for k, v in sorted(((k, v) for k, v in data.items() if isinstance(v, dict) and "valu_pipe_busy_frac" in v), key=lambda kv: -kv[1]["counters"].get("SQ_INSTS_VALU", 0)):
         c = v["counters"]
-        o.write("| %s | %.3e | %.2f | %.2f | %s | %s | %s | %s | %s |\n" % (
-            k, c.get("SQ_INSTS_VALU", 0), v["valu_pipe_busy_frac"], v.get("cycles_per_valu_inst", float("nan")),
+        o.write("| %s | %.3e | %.2f | %.3f | %.2f | %s | %s | %s | %s | %s |\n" % (
+            k, c.get("SQ_INSTS_VALU", 0), v["valu_pipe_busy_frac"], v.get("valu_insts_per_simd_cycle", float("nan")), v.get("cycles_per_valu_inst", float("nan")),
             "%.2f" % v["valu_lane_utilisation"] if "valu_lane_utilisation" in v else "-",
             *["%.2f" % v[n] if n in v else "-" for n in ("sq_wait_any_frac_of_wave_cycles", "sq_wait_inst_any_frac_of_wave_cycles", "sq_active_inst_any_frac_of_wave_cycles")],
             "%.2f" % (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else "-"))

@@ -209,6 +209,120 @@ def test_gradient_allreduce_world2_gloo():
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
+def _worker4(rank, world, port, ret):
+    """Four ranks, five optimiser steps of a simulated training run: uneven camera shards (10 cameras -> 3, 3, 2, 2), the compressed
+    SH exchange with the early all-gather every step, the other parameter gradients in ONE allocation (as the rasterizer's backward
+    and the in-place activation backwards leave them) next to a foreign gradient with its own storage (appearance network), and a
+    densification in the middle whose decision comes from the all-reduced statistics (the Gaussian count changes, identically on
+    every rank)."""
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-opacity-fields_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dp import GradientAllReducer, shard_views
+    from dp.reducer import all_reduce_densification_stats
+    cams = list(range(10))
+    shards = [shard_views(cams, r, world) for r in range(world)]
+    ok = [len(s_) for s_ in shards] == [3, 3, 2, 2] and sorted(sum(shards, [])) == cams
+
+    class Ops:                       # stand-in for the HIP pack / expand kernels: "basis" b_k(campos) = cos(k + sum(campos))
+        src = None
+        ready = None
+        track = staticmethod(lambda on: None)
+
+        @staticmethod
+        def set_ready(fn):
+            Ops.ready = fn
+
+        @staticmethod
+        def take():
+            s_, Ops.src = Ops.src, None
+            return s_
+
+        @staticmethod
+        def pack(src, out):
+            out[:src["P"]] = src["packed"]
+
+        @staticmethod
+        def expand(src, gathered, scale, outs):
+            Pn = src["P"]
+            tot = torch.zeros(Pn, 16, 3)
+            for v in range(gathered.shape[0]):
+                b = torch.cos(torch.arange(16, dtype=torch.float32) + gathered[v, Pn].sum())
+                tot += b[None, :, None] * gathered[v, :Pn][:, None, :]
+            tot *= scale
+            outs[0].copy_(tot[:, :1]); outs[1].copy_(tot[:, 1:])
+
+    def view_grads(view, P, step):
+        """what the backward of `view` produces at this step: (xyz, opacity, scaling, rotation) values, colour gradient, camera, foreign"""
+        gg = torch.Generator().manual_seed(1000 * step + view)
+        return ([torch.randn(P, k, generator=gg) for k in (3, 1, 3, 4)], torch.randn(P, 3, generator=gg), torch.randn(3, generator=gg),
+                torch.randn(37, generator=gg))
+
+    def dense_sh(packed, campos):
+        b = torch.cos(torch.arange(16, dtype=torch.float32) + campos.sum())
+        return b[None, :, None] * packed[:, None, :]
+
+    P = 301
+    red = None
+    for step in range(5):
+        names = ("xyz", "opacity", "scaling", "rotation")
+        params = {n: torch.zeros(P, k, requires_grad=True) for n, k in zip(names, (3, 1, 3, 4))}
+        f_dc = torch.zeros(P, 1, 3, requires_grad=True); f_rest = torch.zeros(P, 15, 3, requires_grad=True)
+        appearance = torch.zeros(37, requires_grad=True)
+        plist = [params[n] for n in names] + [f_dc, f_rest, appearance]
+        if red is None:
+            red = GradientAllReducer(plist, sh_params=[f_dc, f_rest], sh_ops=Ops)
+        red.params, red.sh_params = plist, [f_dc, f_rest]          # as the launcher does per step: densification replaces the parameters
+        view = shards[rank][step % len(shards[rank])]
+        vals, packed, campos, foreign = view_grads(view, P, step)
+        sizes = [3 * P, P, 3 * P, 4 * P]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot); tot += (n + 3) & ~3
+        bucket = torch.full((tot + 48 * P,), float("nan"))             # ... | sh segment (unused here) as the rasterizer lays it out
+        for n, v, o, sz in zip(names, vals, offs, sizes):
+            seg = bucket[o:o + sz].view(v.shape)
+            seg.copy_(v)
+            params[n].grad = seg
+        d = dense_sh(packed, campos)
+        f_dc.grad = d[:, :1].contiguous(); f_rest.grad = d[:, 1:].contiguous()
+        appearance.grad = foreign.clone()
+        Ops.src = {"P": P, "M": 16, "packed": packed, "campos": campos}
+        Ops.ready(Ops.src)                                            # the gather starts inside the backward
+        red.all_reduce()
+        views_now = [shards[r][step % len(shards[r])] for r in range(world)]
+        want = [view_grads(v, P, step) for v in views_now]
+        for i, n in enumerate(names):
+            ok = ok and torch.allclose(params[n].grad, sum(w[0][i] for w in want), atol=1e-5)
+            ok = ok and params[n].grad.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr()    # reduced in place
+        ok = ok and torch.allclose(torch.cat([f_dc.grad, f_rest.grad], 1), sum(dense_sh(w[1], w[2]) for w in want), atol=1e-4)
+        ok = ok and torch.allclose(appearance.grad, sum(w[3] for w in want), atol=1e-5)
+        ok = ok and red.last_exchange == "compressed-sh" and red.last_buckets == (1, 1) and red._early == []
+        if step == 2:          # densification: statistics accumulated per rank over different numbers of views, decision from the reduced totals
+            acc = torch.full((P, 1), float(len(shards[rank]))); acc_abs = acc * 2; denom = torch.full((P, 1), float(rank + 1))
+            radii = torch.full((P,), float(rank)); absmax = torch.full((P, 1), float(7 - rank))
+            all_reduce_densification_stats(acc, acc_abs, denom, radii, absmax)
+            ok = ok and float(acc[0]) == 10.0 and float(denom[0]) == 10.0 and float(radii[0]) == 3.0 and float(absmax[0]) == 7.0
+            P = P + int(acc[0].item()) * 3 + int(radii[0].item())     # 334: every rank grows to the same count
+    ok = ok and P == 334
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_compressed_exchange_with_densification_and_uneven_shards_world4_gloo():
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
 def test_the_dp_launcher_installs_the_camera_list_hook_in_the_module_the_filter_reads():
     """launch/run_train_dp.py must set CAMERA_LIST_HOOK in the MODULE train_epilogue.filter_3d -- the package re-exports a function
     of the same name, so `import train_epilogue.filter_3d as m` binds that function and the assignment is silently lost (found by

@@ -174,3 +174,51 @@ def test_the_exchange_runs_over_rccl_on_one_rank_and_is_the_identity():
     p.join(300)
     assert p.exitcode == 0
     assert ret.get(0, (False, "no result"))[0], dict(ret)
+
+
+def test_inplace_activation_backwards_leave_the_parameter_gradients_in_the_rasterizers_bucket():
+    """launch/run_train_dp.py's configuration (train_epilogue.activations.INPLACE_GRAD): raw parameters -> HIP activations
+    (3D-filter scaling / opacity, normalised rotation, in render()'s order) -> rasterizer -> backward.  The gradients of _xyz,
+    _opacity, _scaling, _rotation are then views of ONE allocation (the rasterizer's gradient bucket) that the reducer reduces in
+    place -- and have the same values as with fresh gradient tensors (bit for bit: the same kernels, only the output address
+    differs; the scaling gradient's two contributions are added in the same order)."""
+    import importlib
+    for p in (os.path.join(ROOT, "gaussian-opacity-fields_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import synthetic_scenes as S
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from dp import GradientAllReducer
+    act = importlib.import_module("train_epilogue.activations")
+    sc = S.scene_frustum(30_000, W=320, H=208, focal=240.0, seed=2, pose_seed=3)
+    sd = to_dev(sc)
+    g = torch.Generator().manual_seed(4)
+    raw0 = {"xyz": sd["means3D"].clone(), "opacity": torch.randn(30_000, 1, generator=g).cuda(), "scaling": torch.log(sd["scales"]),
+            "rotation": (sd["rotations"] * 1.7).contiguous()}
+    filter_3D = (sd["scales"].min(dim=1, keepdim=True).values * 0.3).contiguous()
+    dL = torch.randn((9, sd["H"], sd["W"]), generator=g).cuda()
+
+    def run(inplace):
+        act.INPLACE_GRAD = inplace
+        try:
+            raw = {k: v.clone().requires_grad_(True) for k, v in raw0.items()}
+            shs = sd["shs"].clone().requires_grad_(True)
+            means2D = torch.zeros_like(raw["xyz"], requires_grad=True)
+            opacity = act.opacity_with_3D_filter(raw["opacity"], raw["scaling"], filter_3D)      # render(): opacity first ...
+            scales = act.scaling_with_3D_filter(raw["scaling"], filter_3D)                      # ... then scales, rotations
+            rot = act.rotation(raw["rotation"])
+            color, _ = GaussianRasterizer(settings_from(sd))(means3D=raw["xyz"], means2D=means2D, shs=shs, opacities=opacity, scales=scales, rotations=rot)
+            color.backward(dL)
+            torch.cuda.synchronize()
+            return raw
+        finally:
+            act.INPLACE_GRAD = False
+    a, b = run(False), run(True)
+    grads_b = [b[k].grad for k in ("xyz", "opacity", "scaling", "rotation")]
+    bucket = GradientAllReducer._shared_bucket(grads_b)
+    assert bucket is not None and all(x.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr() for x in grads_b)
+    assert GradientAllReducer._shared_bucket([a[k].grad for k in ("xyz", "opacity", "scaling", "rotation")]) is None      # fresh tensors: would be packed
+    for k in ("xyz", "opacity", "scaling", "rotation"):
+        assert torch.isfinite(b[k].grad).all() and b[k].grad.abs().max() > 0
+        assert torch.equal(a[k].grad, b[k].grad), k

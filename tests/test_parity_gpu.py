@@ -484,7 +484,7 @@ def test_fused_forward_matches_the_two_stage_forward_and_recovers_from_a_small_c
     key = (str(sd["means3D"].device), sd["means3D"].shape[0], sd["W"], sd["H"])
     B._capacity[key] = B._round_capacity(exact["R"])
     fused = product_forward_raw(sd, fused=True)
-    assert fused["R"] == B._capacity[key] and fused["R"] > exact["R"]                 # num_rendered = capacity (workspace layout)
+    assert fused["R"] == exact["R"] and fused["R"].layout == B._capacity[key] > exact["R"]   # the true count; the layout (capacity) rides along
     assert torch.equal(fused["color"], exact["color"]) and torch.equal(fused["radii"], exact["radii"])
     for name in ("ranges", "n_contrib", "final_T"):
         assert _same(fetch(fused, name), fetch(exact, name)), name
