@@ -166,7 +166,7 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
 }
 
 // Dispatch order of the tile kernels (pop_tile, gof_common.h): ONE workgroup ranks all tiles by cost, heaviest first (counting sort
-// over quarter-octave cost buckets: the order inside a bucket -- costs within 19 % -- is whatever the atomics give and does not
+// over quarter-octave cost buckets: the order inside a bucket -- costs within 25 % -- is whatever the atomics give and does not
 // matter), deals the ranks to the 8 XCD queues in snake order and resets the queue heads.  cost = tile-list length (forward: an
 // upper bound of what the tile walks) or what the forward measured (backward).  What it buys is measured in bench.py's "clustered" leg.
 __global__ void __launch_bounds__(1024)

@@ -21,10 +21,12 @@ _vp, _i64 = C.c_void_p, C.c_int64
 # rasterizer's dL_dopacity / dL_dscales / dL_drotations, segments of the ONE allocation its backward carves the parameter gradients
 # from (diff_gaussian_rasterization/_backend.py), so _opacity.grad / _scaling.grad / _rotation.grad end up next to _xyz.grad in that
 # allocation and dp.GradientAllReducer all-reduces them IN PLACE (no pack / unpack of 44 B per Gaussian).  _scaling receives a second
-# contribution from the opacity activation; autograd adds it in place to the first one it saw -- the scaling activation's, which
-# render() creates after the opacity's (gaussian_renderer/__init__.py:60,70) and which therefore runs first in the backward.  If an
-# order ever differs the reducer simply packs that tensor: correctness does not depend on it.  Off by default: a caller that keeps a
-# reference to the rasterizer's activated-parameter gradients (retain_grad, hooks) would see them overwritten.
+# contribution from the opacity activation, and autograd would add two contributions out of place (a view of a shared allocation is
+# never accumulated into in place: torch/csrc/autograd/input_buffer.cpp); so under this flag the two activations that read _scaling
+# are ONE autograd node (_ScalingOpacity: the property evaluated first computes both, the other takes its result), whose backward
+# adds the opacity path's contribution to the scaling gradient itself, in place.  If a gradient still ends up elsewhere the reducer
+# simply packs that tensor: correctness does not depend on any of this.  Off by default: a caller that keeps a reference to the
+# rasterizer's activated-parameter gradients (retain_grad, hooks) would see them overwritten.
 INPLACE_GRAD = False
 
 
@@ -92,6 +94,58 @@ class _Opacity(torch.autograd.Function):
         return gro, grs, None
 
 
+class _ScalingOpacity(torch.autograd.Function):
+    """get_opacity_with_3D_filter and get_scaling_with_3D_filter as one node (INPLACE_GRAD): same kernels, same values; the backward
+    leaves d/d_opacity over the incoming opacity gradient and d/d_scaling (both paths summed: the scaling path first, then the
+    opacity path, the order autograd adds them in on the separate-node path) over the incoming scaling gradient."""
+
+    @staticmethod
+    def forward(ctx, raw_opacity, raw_scaling, filter_3D):
+        ro = B._need_cuda_f32(raw_opacity, "_opacity")
+        rs = B._need_cuda_f32(raw_scaling, "_scaling")
+        n = int(rs.shape[0])
+        f = _f3(filter_3D, n, rs)
+        op, sc = torch.empty_like(ro), torch.empty_like(rs)
+        with torch.cuda.device(rs.device):
+            B._check(lib.gof_act_opacity(n, ro.data_ptr(), rs.data_ptr(), f.data_ptr(), op.data_ptr(), B._stream()))
+            B._check(lib.gof_act_scaling(n, rs.data_ptr(), f.data_ptr(), sc.data_ptr(), B._stream()))
+        ctx.save_for_backward(ro, rs, f)
+        return op, sc
+
+    @staticmethod
+    def backward(ctx, g_op, g_sc):
+        ro, rs, f = ctx.saved_tensors
+        n = int(rs.shape[0])
+        gro = grs = None
+        with torch.cuda.device(rs.device):
+            if g_sc is not None:
+                g_sc = g_sc.contiguous()
+                grs = _out_like(g_sc, rs)
+                B._check(lib.gof_act_scaling_backward(n, rs.data_ptr(), f.data_ptr(), g_sc.data_ptr(), grs.data_ptr(), B._stream()))
+            if g_op is not None:
+                g_op = g_op.contiguous()
+                gro, grs_op = _out_like(g_op, ro), torch.empty_like(rs)
+                B._check(lib.gof_act_opacity_backward(n, ro.data_ptr(), rs.data_ptr(), f.data_ptr(), g_op.data_ptr(), gro.data_ptr(),
+                                                      grs_op.data_ptr(), B._stream()))
+                grs = grs_op if grs is None else grs.add_(grs_op)
+        return gro, grs, None
+
+
+def _fused_take(model, which):
+    """`which` (0 = opacity, 1 = scaling) of `model` from a _ScalingOpacity node shared with the OTHER property: whichever is read
+    first computes both and parks the other output, which the other property then takes -- once, so that every node is used for
+    exactly one (opacity, scaling) pair (render() reads opacity at gaussian_renderer/__init__.py:60 and scaling at :70; a property
+    read twice in a row simply starts a new node)."""
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (model._opacity, model._scaling, model.filter_3D)) + (torch.is_grad_enabled(),)
+    parked = getattr(model, "_gof_act_parked", None)
+    model._gof_act_parked = None
+    if parked is not None and parked[0] == key and parked[1] == which:
+        return parked[2]
+    pair = _ScalingOpacity.apply(model._opacity, model._scaling, model.filter_3D)
+    model._gof_act_parked = (key, 1 - which, pair[1 - which])
+    return pair[which]
+
+
 class _Rotation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw_rotation):
@@ -128,10 +182,14 @@ def rotation(raw_rotation):
 
 # property bodies for the reference's GaussianModel (self._scaling, self._opacity, self._rotation, self.filter_3D)
 def get_scaling_with_3D_filter(self):
+    if INPLACE_GRAD:
+        return _fused_take(self, 1)
     return scaling_with_3D_filter(self._scaling, self.filter_3D)
 
 
 def get_opacity_with_3D_filter(self):
+    if INPLACE_GRAD:
+        return _fused_take(self, 0)
     return opacity_with_3D_filter(self._opacity, self._scaling, self.filter_3D)
 
 

@@ -177,8 +177,9 @@ def test_the_exchange_runs_over_rccl_on_one_rank_and_is_the_identity():
 
 
 def test_inplace_activation_backwards_leave_the_parameter_gradients_in_the_rasterizers_bucket():
-    """launch/run_train_dp.py's configuration (train_epilogue.activations.INPLACE_GRAD): raw parameters -> HIP activations
-    (3D-filter scaling / opacity, normalised rotation, in render()'s order) -> rasterizer -> backward.  The gradients of _xyz,
+    """launch/run_train_dp.py's configuration (train_epilogue.activations.INPLACE_GRAD): raw parameters -> HIP activations through
+    the property bodies the launcher installs on GaussianModel (3D-filter opacity + scaling as ONE autograd node, normalised
+    rotation, in render()'s order) -> rasterizer -> backward.  The gradients of _xyz,
     _opacity, _scaling, _rotation are then views of ONE allocation (the rasterizer's gradient bucket) that the reducer reduces in
     place -- and have the same values as with fresh gradient tensors (bit for bit: the same kernels, only the output address
     differs; the scaling gradient's two contributions are added in the same order)."""
@@ -205,9 +206,13 @@ def test_inplace_activation_backwards_leave_the_parameter_gradients_in_the_raste
             raw = {k: v.clone().requires_grad_(True) for k, v in raw0.items()}
             shs = sd["shs"].clone().requires_grad_(True)
             means2D = torch.zeros_like(raw["xyz"], requires_grad=True)
-            opacity = act.opacity_with_3D_filter(raw["opacity"], raw["scaling"], filter_3D)      # render(): opacity first ...
-            scales = act.scaling_with_3D_filter(raw["scaling"], filter_3D)                      # ... then scales, rotations
-            rot = act.rotation(raw["rotation"])
+            class Model:                          # the attributes the property bodies read (scene/gaussian_model.py)
+                _opacity, _scaling, _rotation = raw["opacity"], raw["scaling"], raw["rotation"]
+            Model.filter_3D = filter_3D
+            m = Model()
+            opacity = act.get_opacity_with_3D_filter(m)                                         # render(): opacity first ...
+            scales = act.get_scaling_with_3D_filter(m)                                          # ... then scales, rotations
+            rot = act.get_rotation(m)
             color, _ = GaussianRasterizer(settings_from(sd))(means3D=raw["xyz"], means2D=means2D, shs=shs, opacities=opacity, scales=scales, rotations=rot)
             color.backward(dL)
             torch.cuda.synchronize()

@@ -872,7 +872,7 @@ def test_full_size_s1m_clustered_against_oracle():
     assert np.array_equal(np.sort(tiles), np.arange(T))                                  # every tile exactly once
     for x in range(8):
         q = L[order[x * per:x * per + qlen[x]]]
-        assert q[0] >= 0.8 * L.max() and (q[:-1] * 1.2 + 4 >= q[1:]).all()               # heaviest first, non-increasing up to the bucket width
+        assert q[0] >= 0.8 * L.max() and (q[:-1] * 1.25 + 4 >= q[1:]).all()              # heaviest first, non-increasing up to the bucket width (a bucket spans up to 5:4)
     sums = [L[order[x * per:x * per + qlen[x]]].sum() for x in range(8)]
     assert max(sums) <= 1.02 * min(sums)                                                  # the deal balances the XCD queues
     walked = fetch(res, "tile_cost").astype(np.int64)
