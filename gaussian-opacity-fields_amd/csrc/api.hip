@@ -58,7 +58,7 @@ __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, c
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
                               float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                               uint32_t* tile_cost);
-__global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue);
+__global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
@@ -69,11 +69,12 @@ __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint
 __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
                                  uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
-                                 uint32_t* tile_queue);
+                                 uint32_t* tile_queue, uint32_t* tile_cost);
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
                                  const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
                                  const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
-                                 float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, int acc_min, uint32_t gx, uint32_t ntiles);
+                                 float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, int acc_min, uint32_t gx, uint32_t ntiles,
+                                 const uint32_t* tile_order, uint32_t* tile_queue);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
                              const uint32_t* sort_error);
@@ -207,9 +208,10 @@ size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool
     carve(p, b.vals_alt, n);
     carve(p, b.tiles_alt, n);
     carve(p, b.sort_tmp, rs_tmp_words(n));
-    b.cmask = nullptr; b.pt_xy = nullptr; b.pt_depth = nullptr; b.pt_T = nullptr; b.pt_acc = nullptr;
+    b.cmask = nullptr; b.pt_xy = nullptr; b.pt_depth = nullptr; b.pt_T = nullptr; b.pt_acc = nullptr; b.pt_order = nullptr; b.pt_queue = nullptr;
     if (with_masks) carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
-    else { carve(p, b.pt_xy, n); carve(p, b.pt_depth, n); carve(p, b.pt_T, n); carve(p, b.pt_acc, n); }
+    else { carve(p, b.pt_xy, n); carve(p, b.pt_depth, n); carve(p, b.pt_T, n); carve(p, b.pt_acc, n);
+           carve(p, b.pt_order, T + NXCD); carve(p, b.pt_queue, (size_t)TILE_QUEUE_WORDS); }
     if (out) *out = b;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -299,7 +301,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     }
     // dispatch order of the tile kernels: per XCD band, longest list first (gof_common.h: pop_tile)
     { GOF_PROFILE("order_tiles", stream);
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue); }
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr); }
     GOF_LAUNCH_CHECK(stream, dbg);
     return GOF_OK;
 }
@@ -310,7 +312,7 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
 {
     GOF_PROFILE("order_tiles", stream);
     // (no heads here: the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, nullptr);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, nullptr, nullptr);
 }
 
 } // namespace gof
@@ -431,7 +433,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
         if (rc) return rc;
     } else {
         GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
-        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue);
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr);
     }
     { GOF_PROFILE("blend_forward", stream);
     hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
@@ -648,7 +650,7 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     GOF_PROFILE("integrate_pixels", stream);
     hipLaunchKernelGGL(integrate_pixels, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
-                       out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue);
+                       out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -728,10 +730,13 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.points2D, w.depths, pb.pt_xy, pb.pt_depth);
         GOF_LAUNCH_CHECK(stream, a->debug);
     } }
+    // dispatch order of the point pass: #points of the tile x what its pixels walked (tile_cost, left by integrate_pixels), heaviest first
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges);
+    GOF_LAUNCH_CHECK(stream, a->debug);
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, im.point_ranges, b.vals, pb.vals, rec_ptr, zfront_ptr, zstride, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
-                       base_color, out_color, out_alpha_integrated, out_color_integrated, im.n_contrib, acc_min ? 1 : 0, d.gx, d.ntiles);
+                       base_color, out_color, out_alpha_integrated, out_color_integrated, im.n_contrib, acc_min ? 1 : 0, d.gx, d.ntiles, pb.pt_order, pb.pt_queue);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }

@@ -168,10 +168,10 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
 // Dispatch order of the tile kernels (pop_tile, gof_common.h): ONE workgroup ranks all tiles by cost, heaviest first (counting sort
 // over quarter-octave cost buckets: the order inside a bucket -- costs within 25 % -- is whatever the atomics give and does not
 // matter), deals the ranks to the 8 XCD queues in snake order and resets the queue heads.  cost = tile-list length (forward: an
-// upper bound of what the tile walks) or what the forward measured (backward).  What it buys is measured in bench.py's "clustered" leg.
+// upper bound of what the tile walks), what the forward measured (backward), or that times the tile's query points (point pass).  What it buys is measured in bench.py's "clustered" leg.
 __global__ void __launch_bounds__(1024)
 order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cost_in, uint32_t* __restrict__ order,
-            uint32_t* __restrict__ queue)
+            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges)
 {
     constexpr int NB = 128;                       // bucket = 4 * floor(log2(c)) + next two bits, descending
     __shared__ uint32_t s_cnt[NB];
@@ -181,7 +181,11 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
     if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     auto bucket = [&](uint32_t t) -> uint32_t {
-        const uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);
+        uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);
+        if (times_ranges) {            // the point pass of the opacity-field query: #points of the tile x (entries its pixels walked + a fixed per-point share)
+            const unsigned long long m = (unsigned long long)(times_ranges[t].y - times_ranges[t].x) * (unsigned long long)(c + 32u);
+            c = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m;
+        }
         if (c < 4u) return NB - 1u - c;                                            // 0..3 -> the last buckets
         const uint32_t m = 31u - (uint32_t)__builtin_clz(c);
         const uint32_t b = 4u * m + ((c >> (m - 2u)) & 3u);                        // 8 .. 127

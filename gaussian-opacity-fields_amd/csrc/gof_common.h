@@ -74,6 +74,7 @@ struct BinWs {
     uint32_t* cmask;                              // [cmask_words(R, T)][256] contributor bit masks written by blend_forward
     // query-point variant (integrate): per-point data gathered into LIST order, so the point pass streams it
     float2* pt_xy; float* pt_depth; float* pt_T; float* pt_acc;   // [NI]
+    uint32_t* pt_order; uint32_t* pt_queue;                       // [T + 8], [TILE_QUEUE_WORDS]: dispatch order of integrate_points (pop_tile)
 };
 // Point workspace (replaces PointState, rasterizer_impl.h:47-55)
 struct PointWs {

@@ -41,7 +41,7 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                  const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
                  float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles,
-                 const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
+                 const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
     __shared__ uint32_t s_tile;
     const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);      // longest list first (gof_common.h)
@@ -238,6 +238,18 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
         out_color[6 * HW + pix_id] = Cdepth;
         out_color[7 * HW + pix_id] = Calpha;
     }
+    // what the point pass will walk in this tile (the deepest contributor position of its pixels): part of its dispatch cost
+    {
+        uint32_t m = inside ? last_contributor : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        __syncthreads();
+        if (tid == 0) s_tile = 0u;
+        __syncthreads();
+        if (lane == 0) atomicMax(&s_tile, m);
+        __syncthreads();
+        if (tid == 0) tile_cost[tile] = s_tile;
+    }
 }
 
 // copies what the point pass needs of the geometry workspace (64-byte records, front depths) into a compact buffer
@@ -260,9 +272,11 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                  const SplatRec* __restrict__ rec, const float* __restrict__ zfront, int zstride, const uint32_t* __restrict__ cmask, int W, int H,
                  float focal_x, float focal_y, const float2* __restrict__ pt_xy, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
                  float* __restrict__ pt_acc, const float* __restrict__ base_color, float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
-                 float* __restrict__ out_color_integrated, const uint32_t* __restrict__ n_contrib, int acc_min, uint32_t gx, uint32_t ntiles)
+                 float* __restrict__ out_color_integrated, const uint32_t* __restrict__ n_contrib, int acc_min, uint32_t gx, uint32_t ntiles,
+                 const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
 {
-    const uint32_t tile = xcd_tile_id(blockIdx.x, ntiles);
+    __shared__ uint32_t s_tile;
+    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);      // most (points x walked entries) first (gof_common.h)
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
