@@ -59,10 +59,10 @@ struct ImageWs {
     uint2* point_ranges;    // [T] integrate only
     float* final_T;         // [4][H*W]  T, dist1, dist2, distortion (forward.cu:591-594)
     uint32_t* n_contrib;    // [2][H*W]  last contributor, max contributor (forward.cu:596-597)
-    uint32_t* tile_order;   // [8][ceil(T / 8)] dispatch order of the blend kernels: per XCD band, longest tile list first (binning.hip: order_tiles)
+    uint32_t* tile_order;   // [8][ceil(T / 8)] dispatch order of the forward-side tile kernels: tiles ranked by list length, dealt to 8 XCD queues (binning.hip: order_tiles)
     uint32_t* tile_queue;   // [TILE_QUEUE_WORDS] heads of the per-XCD queues the forward-side kernels pop (zeroed by order_tiles)
     uint32_t* tile_cost;    // [T] what blend_forward measured per tile (entries walked): the backward's cost
-    uint32_t* tile_order_bw;// [8][ceil(T / 8)] dispatch order of blend_backward: per XCD band, deepest walk first (ordered by tile_cost after the forward blend)
+    uint32_t* tile_order_bw;// [8][ceil(T / 8)] dispatch order of blend_backward: ranked by tile_cost (deepest walk first) after the forward blend
 };
 constexpr int NXCD = 8;
 constexpr int TILE_QUEUE_WORDS = 64;

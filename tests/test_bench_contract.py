@@ -29,15 +29,24 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["kernel"] == "blend_backward" and r["traffic"] is None or r["traffic"] > 0
-    if "r02" in os.path.basename(_latest()):              # round 2: the blend kernels' VALU roofline + where the PMC figures come from
+    rnd = int(re.search(r"r(\d+)_bench", os.path.basename(_latest())).group(1))
+    if rnd >= 2:                                          # round 2 on: the blend kernels' VALU roofline + where the PMC figures come from
         for k in ("blend_forward", "blend_backward"):
             v = r["valu"][k]
             assert v["bound"] == "valu" and v["peak"] == 157.3 and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3
             assert abs(v["achieved"] - v["flop_per_pair"] * v["pairs"] / (v["avg_ms"] * 1e-3) / 1e12) < 0.02 * v["achieved"]
-        if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic_s1m.json")):
+        if os.path.exists(os.path.join(ROOT, "profiles", "r%02d_pmc_traffic_s1m.json" % rnd)):
             assert r["traffic_source"]["file"].startswith("profiles/") and r["traffic_source"]["kernel_sha16"]
         assert d["steps"] >= 100
         assert "integrate" in d and d["integrate"]["later_call_of_the_view"]["wall_ms"] > 0
+    if rnd >= 3:                                          # round 3: the heavy-tailed leg, the workspace footprint, the PyTorch-CPU render beside the HIP forward
+        cl = d["clustered"]
+        assert "S1M-clustered" in cl["workload"] and cl["ms_per_step"] > 0 and cl["num_rendered"] > 20_000_000
+        assert cl["entries_walked_per_tile_pct_0_50_90_99_100"][4] > 5 * cl["entries_walked_per_tile_pct_0_50_90_99_100"][1]      # heavy-tailed indeed
+        ws = r["workspace"]
+        assert 100 <= ws["per_instance_total_bytes"] <= 130 and ws["reference_per_instance_bytes"] == 24
+        tc = d["cpu_baseline"]["torch_cpu"]
+        assert "400x400" in tc["workload"] and tc["torch_cpu_float32_s"] > 0 and tc["hip_forward_ms"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -91,5 +100,5 @@ def test_the_committed_pmc_pass_was_collected_on_the_current_blend_kernels():
     f = os.path.join(ROOT, "profiles", b.PMC_FILE)
     if not os.path.exists(f):
         import pytest
-        pytest.skip("no round-2 PMC pass committed yet")
+        pytest.skip("no PMC pass of this round committed yet")
     assert json.load(open(f))["_kernel_sha16"] == b.kernel_sha16()
