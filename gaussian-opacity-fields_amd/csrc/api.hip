@@ -63,7 +63,7 @@ __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, 
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
                                float4* part16, float* part17, uint8_t* part_valid, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
-                               uint32_t* tile_queue);
+                               uint32_t* tile_queue, const uint32_t* tile_lens);
 __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
                                      const uint8_t* part_valid, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors, float* dL_dv2g);
 __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
@@ -100,6 +100,7 @@ void set_error(const char* fmt, ...)
 namespace {
 std::mutex g_status_mutex;
 volatile uint32_t* g_status_host = nullptr;
+uint32_t* g_status_dev = nullptr;
 }
 static uint32_t* async_status_word()
 {
@@ -108,9 +109,12 @@ static uint32_t* async_status_word()
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         std::memset(p, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return nullptr; }
         g_status_host = static_cast<volatile uint32_t*>(p);
+        g_status_dev = static_cast<uint32_t*>(d);
     }
-    return const_cast<uint32_t*>(g_status_host);       // unified addressing: the host pointer of mapped pinned memory is valid on the device
+    return g_status_dev;
 }
 static int take_async_status()
 {
@@ -190,10 +194,10 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
     carve(p, im.point_ranges, T);
     carve(p, im.final_T, 4 * N);
     carve(p, im.n_contrib, 2 * N);
-    carve(p, im.tile_order, T + NXCD);           // [8][ceil(T / 8)]
+    carve(p, im.tile_order, (size_t)NXCD * tile_queue_stride((uint32_t)T));
     carve(p, im.tile_queue, (size_t)TILE_QUEUE_WORDS);
     carve(p, im.tile_cost, T);
-    carve(p, im.tile_order_bw, T + NXCD);
+    carve(p, im.tile_order_bw, (size_t)NXCD * tile_queue_stride((uint32_t)T));
     if (out) *out = im;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -211,7 +215,7 @@ size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool
     b.cmask = nullptr; b.pt_xy = nullptr; b.pt_depth = nullptr; b.pt_T = nullptr; b.pt_acc = nullptr; b.pt_order = nullptr; b.pt_queue = nullptr;
     if (with_masks) carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
     else { carve(p, b.pt_xy, n); carve(p, b.pt_depth, n); carve(p, b.pt_T, n); carve(p, b.pt_acc, n);
-           carve(p, b.pt_order, T + NXCD); carve(p, b.pt_queue, (size_t)TILE_QUEUE_WORDS); }
+           carve(p, b.pt_order, (size_t)NXCD * tile_queue_stride((uint32_t)T)); carve(p, b.pt_queue, (size_t)TILE_QUEUE_WORDS); }
     if (out) *out = b;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -299,7 +303,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
                            radix_sort_error_flag(b.sort_tmp, (size_t)R, tile_bits), async_status_word());
         GOF_LAUNCH_CHECK(stream, dbg);
     }
-    // dispatch order of the tile kernels: per XCD band, longest list first (gof_common.h: pop_tile)
+    // dispatch order of the tile kernels: every XCD an equal share of every cost class, heaviest first (gof_common.h: pop_tile)
     { GOF_PROFILE("order_tiles", stream);
     hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr); }
     GOF_LAUNCH_CHECK(stream, dbg);
@@ -311,8 +315,8 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
 static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream_t stream)
 {
     GOF_PROFILE("order_tiles", stream);
-    // (no heads here: the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, nullptr, nullptr);
+    // (queue lengths at tile_queue[40..47]; the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr);
 }
 
 } // namespace gof
@@ -562,7 +566,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles, im.tile_order_bw, ws.queue);
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles, im.tile_order_bw, ws.queue, im.tile_queue + TILE_QUEUE_WORDS / 2 + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);
@@ -950,8 +954,9 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
     else if (n == "ranges" && image_ws) { src = im.ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
     else if (n == "point_ranges" && image_ws) { src = im.point_ranges; count = 2 * (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 8; }
     else if (n == "tile_cost" && image_ws) { src = im.tile_cost; count = (int64_t)d.ntiles; bytes = (size_t)d.ntiles * 4; }
-    else if (n == "tile_order" && image_ws) { src = im.tile_order; count = (int64_t)((d.ntiles + 7) / 8 * 8); bytes = (size_t)count * 4; }        // [8][ceil(T / 8)]
-    else if (n == "tile_order_bw" && image_ws) { src = im.tile_order_bw; count = (int64_t)((d.ntiles + 7) / 8 * 8); bytes = (size_t)count * 4; }
+    else if (n == "tile_order" && image_ws) { src = im.tile_order; count = (int64_t)NXCD * tile_queue_stride(d.ntiles); bytes = (size_t)count * 4; }
+    else if (n == "tile_order_bw" && image_ws) { src = im.tile_order_bw; count = (int64_t)NXCD * tile_queue_stride(d.ntiles); bytes = (size_t)count * 4; }
+    else if (n == "tile_queue" && image_ws) { src = im.tile_queue; count = TILE_QUEUE_WORDS; bytes = (size_t)count * 4; }
     else if (n == "final_T" && image_ws) { src = im.final_T; count = 4 * HW; bytes = 4 * HW * 4; }
     else if (n == "n_contrib" && image_ws) { src = im.n_contrib; count = 2 * HW; bytes = 2 * HW * 4; }
     else { set_error("unknown array '%s' (or its workspace is NULL)", name); return GOF_E_INVALID; }

@@ -165,20 +165,33 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
     if (idx == L - 1) ranges[currtile].y = L;
 }
 
-// Dispatch order of the tile kernels (pop_tile, gof_common.h): ONE workgroup ranks all tiles by cost, heaviest first (counting sort
-// over quarter-octave cost buckets: the order inside a bucket -- costs within 25 % -- is whatever the atomics give and does not
-// matter), deals the ranks to the 8 XCD queues in snake order and resets the queue heads.  cost = tile-list length (forward: an
-// upper bound of what the tile walks), what the forward measured (backward), or that times the tile's query points (point pass).  What it buys is measured in bench.py's "clustered" leg.
+// Dispatch order of the tile kernels (pop_tile, gof_common.h).  ONE workgroup:
+//   1. classifies every tile by cost into half-octave buckets (costs of a bucket within 3:2), heaviest bucket first;
+//   2. ranks the tiles of a bucket STABLY by tile id (wave w owns a contiguous range of tile ids and walks it in order: rank =
+//      tiles of the bucket in earlier waves + earlier steps + lower lanes, the latter from 7 ballots);
+//   3. gives every XCD one EIGHTH of every bucket in that order (rotated by the number of tiles in heavier buckets): every XCD gets (to within one tile per bucket) the same number
+//      of tiles of every cost class -- equal counts and equal work -- and its share of a bucket is a spatially contiguous run of
+//      tiles, so the tiles an XCD renders still share their Gaussians' records in its private L2 (a uniform scene gets round 2's
+//      contiguous band per XCD back; dealing single ranks round-robin balanced as well but doubled the L2 -> fabric reads);
+//   4. writes XCD e's queue (its shares of the buckets, heaviest bucket first) to order[e * stride ...], its length to
+//      queue[8 + e], and resets the heads queue[e].
+// cost = tile-list length (forward: an upper bound of what the tile walks), what the forward measured (backward), or that times
+// the tile's query points (point pass).  What it buys is measured in bench.py's "clustered" leg (profiles/r03_tile_schedule.md).
 __global__ void __launch_bounds__(1024)
 order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cost_in, uint32_t* __restrict__ order,
             uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges)
 {
-    constexpr int NB = 128;                       // bucket = 4 * floor(log2(c)) + next two bits, descending
-    __shared__ uint32_t s_cnt[NB];
-    __shared__ uint32_t s_w0;
-    const uint32_t per = (ntiles + NXCD - 1) / NXCD;
-    if (threadIdx.x < NXCD && queue) queue[threadIdx.x] = 0u;      // heads (rank r goes to XCD (r & 8 ? 7 - (r & 7) : r & 7), slot r >> 3)
-    if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0u;
+    constexpr int NB = 128;                       // bucket = 2 * floor(log2(c)) + next bit, descending (64 used; quarter-octave classes ordered
+                                                  // more finely but cut an XCD's share into more, shorter runs: +30 % L2 -> fabric reads in the backward)
+    constexpr int NW = 16;                        // waves of the workgroup
+    __shared__ uint32_t s_wc[NW][NB];             // per (wave, bucket): count, then the running stable rank base
+    __shared__ uint32_t s_n[NB];                  // tiles per bucket
+    __shared__ uint32_t s_g[NB];                  // tiles in heavier buckets (rotates the eighths: small buckets go round the XCDs)
+    __shared__ uint32_t s_off[NXCD][NB];          // queue position of XCD e's share of bucket b
+    __shared__ uint32_t s_carry[NXCD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t stride = tile_queue_stride(ntiles);
+    for (uint32_t k = tid; k < NW * NB; k += 1024) (&s_wc[0][0])[k] = 0u;
     __syncthreads();
     auto bucket = [&](uint32_t t) -> uint32_t {
         uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);
@@ -186,41 +199,82 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
             const unsigned long long m = (unsigned long long)(times_ranges[t].y - times_ranges[t].x) * (unsigned long long)(c + 32u);
             c = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m;
         }
-        if (c < 4u) return NB - 1u - c;                                            // 0..3 -> the last buckets
+        if (c < 2u) return NB - 1u - c;                                            // 0, 1 -> the last buckets
         const uint32_t m = 31u - (uint32_t)__builtin_clz(c);
-        const uint32_t b = 4u * m + ((c >> (m - 2u)) & 3u);                        // 8 .. 127
+        const uint32_t b = 2u * m + ((c >> (m - 1u)) & 1u);                        // 2 .. 63: half-octave classes (costs of a class within 3:2)
         return NB - 1u - b;
     };
-    // the first 8192 tiles keep their bucket in registers between the two passes (one round of global loads, all in flight together)
+    // wave w owns tile ids [w * chunk, (w + 1) * chunk), walked 64 at a time; the first 8 steps keep their bucket in registers
+    const uint32_t chunk = ((ntiles + NW - 1) / NW + 63u) & ~63u;
+    const uint32_t t0 = wave * chunk, t1 = min(ntiles, t0 + chunk);
+    const uint32_t steps = t1 > t0 ? (t1 - t0 + 63u) / 64u : 0u;
     constexpr int KEEP = 8;
     uint8_t mine[KEEP];
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const uint32_t i = threadIdx.x + 1024u * k; mine[k] = i < ntiles ? (uint8_t)bucket(i) : (uint8_t)0; }
+    for (int k = 0; k < KEEP; k++) { const uint32_t i = t0 + 64u * k + lane; mine[k] = ((uint32_t)k < steps && i < t1) ? (uint8_t)bucket(i) : (uint8_t)0; }
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const uint32_t i = threadIdx.x + 1024u * k; if (i < ntiles) atomicAdd(&s_cnt[mine[k]], 1u); }
-    for (uint32_t i = threadIdx.x + 1024u * KEEP; i < ntiles; i += 1024) atomicAdd(&s_cnt[bucket(i)], 1u);
+    for (int k = 0; k < KEEP; k++) { const uint32_t i = t0 + 64u * k + lane; if ((uint32_t)k < steps && i < t1) atomicAdd(&s_wc[wave][mine[k]], 1u); }
+    for (uint32_t k = KEEP; k < steps; k++) { const uint32_t i = t0 + 64u * k + lane; if (i < t1) atomicAdd(&s_wc[wave][bucket(i)], 1u); }
     __syncthreads();
-    {   // exclusive scan of the 128 counters by the first two waves
-        uint32_t c = 0, inc = 0;
-        if (threadIdx.x < NB) {
-            c = s_cnt[threadIdx.x];
-            inc = c;
+    {   // per bucket: exclusive prefix over the waves (ascending tile id), total n_b; then G_b = tiles in heavier buckets
+        uint32_t run = 0, inc = 0;
+        if (tid < NB) {
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o); if ((threadIdx.x & 63) >= (unsigned)o) inc += up; }
-            if (threadIdx.x == 63) s_w0 = inc;
+            for (int w = 0; w < NW; w++) { const uint32_t c = s_wc[w][tid]; s_wc[w][tid] = run; run += c; }
+            s_n[tid] = run;
+            inc = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o); if (lane >= (unsigned)o) inc += up; }
+            if (tid == 63u) s_carry[0] = inc;
         }
         __syncthreads();
-        if (threadIdx.x < NB) s_cnt[threadIdx.x] = inc - c + (threadIdx.x >= 64 ? s_w0 : 0u);
+        if (tid < NB) s_g[tid] = inc - run + (tid >= 64u ? s_carry[0] : 0u);
     }
     __syncthreads();
-    auto place = [&](uint32_t i, uint32_t bkt) {
-        const uint32_t r = atomicAdd(&s_cnt[bkt], 1u);
-        const uint32_t x = (r & 8u) ? 7u - (r & 7u) : (r & 7u);
-        order[x * per + (r >> 3)] = i;
+    {   // queue position of every (XCD x, bucket b) share: thread (x, b), exclusive scan over b inside each group of 128 threads.
+        // XCD x takes the eighth e = (x - G_b) mod 8 of bucket b: a bucket of fewer than 8 tiles continues the round where the
+        // heavier buckets stopped (the handful of heaviest tiles does not pile up on XCD 0), a large one is split into 8 runs
+        const uint32_t x = tid >> 7, b = tid & 127u;
+        const uint32_t n = s_n[b];
+        const uint32_t e = (x - s_g[b]) & 7u;
+        const uint32_t lo = (e * n + 7u) >> 3, hi = ((e + 1u) * n + 7u) >> 3;      // ceil(e n / 8) .. ceil((e + 1) n / 8): ranks of the e-th eighth
+        const uint32_t share = hi - lo;
+        uint32_t inc = share;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o); if (lane >= (unsigned)o) inc += up; }
+        __syncthreads();                                                           // (s_carry[0] of the previous step has been read)
+        if ((tid & 127u) == 63u) s_carry[x] = inc;                                 // total of the group's first wave
+        __syncthreads();
+        const uint32_t before = (b >= 64u) ? s_carry[x] : 0u;
+        s_off[x][b] = before + inc - share;
+        if (b == 127u && queue) { queue[x] = 0u; queue[NXCD + x] = before + inc; }  // head, length
+    }
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    auto place = [&](uint32_t i, bool live, uint32_t bkt) {          // called by the whole wave (ballots), tiles in ascending id
+        uint64_t peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 7; bit++) {
+            const uint64_t bal = __ballot((bkt >> bit) & 1u);
+            peers &= ((bkt >> bit) & 1u) ? bal : ~bal;
+        }
+        if (live) {
+            const uint32_t base = s_wc[wave][bkt];
+            const uint32_t r = base + (uint32_t)__popcll(peers & lt);               // stable rank of tile i inside its bucket
+            if ((peers & lt) == 0ull) s_wc[wave][bkt] = base + (uint32_t)__popcll(peers);      // the group's lowest lane advances the wave's base
+            const uint32_t n = s_n[bkt];
+            uint32_t e = (uint32_t)(((unsigned long long)r * 8ull) / n);            // the eighth this rank falls into:
+            e = e > 7u ? 7u : e;                                                    // floor(8 r / n) = e  <=>  ceil(e n / 8) <= r < ceil((e + 1) n / 8)
+            const uint32_t lo = (e * n + 7u) >> 3;
+            const uint32_t x = (e + s_g[bkt]) & 7u;                                 // the XCD that takes this eighth of this bucket
+            order[x * stride + s_off[x][bkt] + (r - lo)] = i;
+        }
     };
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const uint32_t i = threadIdx.x + 1024u * k; if (i < ntiles) place(i, mine[k]); }
-    for (uint32_t i = threadIdx.x + 1024u * KEEP; i < ntiles; i += 1024) place(i, bucket(i));
+    for (int k = 0; k < KEEP; k++) {
+        if ((uint32_t)k < steps) { const uint32_t i = t0 + 64u * k + lane; place(i, i < t1, i < t1 ? (uint32_t)mine[k] : 0xFFu); }      // steps is wave-uniform
+    }
+    for (uint32_t k = KEEP; k < steps; k++) { const uint32_t i = t0 + 64u * k + lane; place(i, i < t1, i < t1 ? bucket(i) : 0xFFu); }
 }
 
 // debug: the reference's 64-bit sort key of every sorted instance (tile << 32 | depth bits)

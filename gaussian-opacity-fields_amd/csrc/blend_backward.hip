@@ -417,10 +417,10 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
                float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx, uint32_t ntiles,
-               const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
+               const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, const uint32_t* __restrict__ tile_lens)
 {
     __shared__ uint32_t s_tile;
-    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_backward_tile(tile, ranges, point_list, rec, conic, cmask, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
                         inst_off, part16, part17, part_valid, gx);

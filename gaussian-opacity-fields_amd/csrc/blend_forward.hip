@@ -310,7 +310,7 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
               uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
     __shared__ uint32_t s_tile;
-    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_forward_tile(tile, &s_tile, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
 }

@@ -59,10 +59,10 @@ struct ImageWs {
     uint2* point_ranges;    // [T] integrate only
     float* final_T;         // [4][H*W]  T, dist1, dist2, distortion (forward.cu:591-594)
     uint32_t* n_contrib;    // [2][H*W]  last contributor, max contributor (forward.cu:596-597)
-    uint32_t* tile_order;   // [8][ceil(T / 8)] dispatch order of the forward-side tile kernels: tiles ranked by list length, dealt to 8 XCD queues (binning.hip: order_tiles)
-    uint32_t* tile_queue;   // [TILE_QUEUE_WORDS] heads of the per-XCD queues the forward-side kernels pop (zeroed by order_tiles)
+    uint32_t* tile_order;   // [8][tile_queue_stride(T)] dispatch order of the forward-side tile kernels: per XCD queue, by list length (binning.hip: order_tiles)
+    uint32_t* tile_queue;   // [TILE_QUEUE_WORDS] [0..7] heads / [8..15] lengths of the forward-side queues, [32..47] the backward's lengths (its heads: scratch)
     uint32_t* tile_cost;    // [T] what blend_forward measured per tile (entries walked): the backward's cost
-    uint32_t* tile_order_bw;// [8][ceil(T / 8)] dispatch order of blend_backward: ranked by tile_cost (deepest walk first) after the forward blend
+    uint32_t* tile_order_bw;// [8][tile_queue_stride(T)] dispatch order of blend_backward: by tile_cost (deepest walk first), written after the forward blend
 };
 constexpr int NXCD = 8;
 constexpr int TILE_QUEUE_WORDS = 64;
@@ -151,40 +151,39 @@ __device__ __forceinline__ uint32_t xcd_tile_id(uint32_t bid, uint32_t ntiles)
     return t;   // may be >= ntiles for the padded tail: caller checks
 }
 inline uint32_t xcd_padded_tiles(uint32_t ntiles) { return (ntiles + 7) / 8 * 8; }
-// Tile assignment for scenes whose tiles do NOT cost the same (round 3; binning.hip: order_tiles).  All tiles are ranked by cost,
-// heaviest first, and DEALT to the 8 XCDs in snake order (ranks 0..7 -> XCD 0..7, ranks 8..15 -> XCD 7..0, ...): every XCD gets the
-// same number of tiles and, to within one tile, the same total cost, each queue sorted heaviest first.  A workgroup pops the head
-// of its XCD's queue as it STARTS (one atomic): the i-th workgroup to start on an XCD renders that XCD's i-th heaviest tile whatever
-// its blockIdx, so a heavy tile never begins last, and the light ones fill the tail.  (One workgroup per tile, not persistent
-// ones: the SIMD arbiter serves the OLDEST wave first, so the youngest of a set of persistent workgroups crawls through its first --
-// heaviest -- tile until the old ones retire; measured, the first tiles popped took the whole kernel.  With contiguous bands per XCD
-// instead of a deal an XCD owns exactly #tiles / 8 workgroups and none is left to help a heavy band.)  Exactly ntiles pops
-// succeed over a grid of >= ntiles workgroups (a workgroup whose own queue is empty tries the others), so every tile is rendered
-// exactly once; results do not depend on the assignment.  The XCD is read from the hardware (HW_REG_XCC_ID; blockIdx % 8 observed
-// equivalent): affinity for speed only.  Must be called by all threads of the workgroup (one barrier).  0xFFFFFFFF = no tile left.
-// queue[0..7] = heads, order[x * per + i] = i-th tile of XCD x (per = ceil(ntiles / 8)).
-// length of XCD x's queue: rank r goes to XCD (r & 8 ? 7 - (r & 7) : r & 7), slot r >> 3
-__host__ __device__ __forceinline__ uint32_t tile_queue_length(uint32_t ntiles, uint32_t x)
-{
-    const uint32_t rem = ntiles & 15u;
-    return 2u * (ntiles >> 4) + (x < (rem < 8u ? rem : 8u) ? 1u : 0u) + ((rem > 8u && x >= 16u - rem) ? 1u : 0u);
-}
-__device__ __forceinline__ uint32_t pop_tile(const uint32_t* __restrict__ order, uint32_t* __restrict__ queue, uint32_t ntiles, uint32_t* s_slot)
+// Tile assignment for scenes whose tiles do NOT cost the same (round 3; binning.hip: order_tiles).  The tiles are classified by
+// cost (half-octave buckets) and every XCD is given the same share of every cost class -- equal tile counts (the dispatcher hands
+// each XCD #tiles / 8 workgroups) and equal work -- as spatially contiguous runs of tiles (L2 locality), its queue sorted heaviest
+// class first.  A workgroup pops the head of its XCD's queue as it STARTS (one atomic): the i-th workgroup to start on an XCD
+// renders that XCD's i-th heaviest tile whatever its blockIdx, so a heavy tile never begins last and the light ones fill the tail.
+// (One workgroup per tile, not persistent ones: the SIMD arbiter serves the OLDEST wave first, so the youngest of a set of
+// persistent workgroups crawls through its first -- heaviest -- tile until the old ones retire; measured, the first tiles popped
+// took the whole kernel.  Contiguous bands of equal tile COUNT per XCD with stealing do not balance either: an XCD owns exactly
+// #tiles / 8 workgroups, so none is left to help a heavy band.)  Exactly ntiles pops succeed over a grid of >= ntiles workgroups
+// (a workgroup whose own queue is empty tries the others: queue lengths may differ from the workgroup supply by a few tiles), so
+// every tile is rendered exactly once; results do not depend on the assignment.  The XCD is read from the hardware
+// (HW_REG_XCC_ID; blockIdx % 8 observed equivalent): affinity for speed only.  Must be called by all threads of the workgroup
+// (one barrier).  0xFFFFFFFF = no tile left.
+// heads[0..7] / lens[0..7] (order_tiles writes queue[0..7] = 0 and queue[8..15] = lengths; the backward keeps its heads in its own
+// scratch, cleared per call), order[x * tile_queue_stride(ntiles) + i] = i-th tile of XCD x.
+__host__ __device__ __forceinline__ uint32_t tile_queue_stride(uint32_t ntiles) { return (ntiles + NXCD - 1) / NXCD + 128u; }   // + one per cost bucket (rounding of the shares)
+__device__ __forceinline__ uint32_t pop_tile(const uint32_t* __restrict__ order, uint32_t* __restrict__ heads, const uint32_t* __restrict__ lens,
+                                             uint32_t ntiles, uint32_t* s_slot)
 {
 #ifdef GOF_STATIC_TILES       // developer A/B (tests/devtools/dev_tile_schedule.py): round 2's static map (contiguous band per XCD, ascending)
     return xcd_tile_id(blockIdx.x, ntiles);
 #endif
     if (threadIdx.x == 0) {
-        const uint32_t per = (ntiles + NXCD - 1) / NXCD;
+        const uint32_t stride = tile_queue_stride(ntiles);
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3u << 11) | (0u << 6) | 20u) & (NXCD - 1);      // hwreg(HW_REG_XCC_ID, 0, 4)
         uint32_t tile = 0xFFFFFFFFu;
         for (uint32_t k = 0; k < NXCD; k++) {
             const uint32_t x = (xcc + k) & (NXCD - 1);
-            const uint32_t n = tile_queue_length(ntiles, x);
+            const uint32_t n = lens[x];
             // (an exhausted head keeps growing: compare first so that the common case costs one atomic)
-            if (__hip_atomic_load(&queue[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) continue;
-            const uint32_t pos = atomicAdd(&queue[x], 1u);
-            if (pos < n) { tile = order[x * per + pos]; break; }
+            if (__hip_atomic_load(&heads[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) continue;
+            const uint32_t pos = atomicAdd(&heads[x], 1u);
+            if (pos < n) { tile = order[x * stride + pos]; break; }
         }
         *s_slot = tile;
     }

@@ -44,7 +44,7 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                  const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
     __shared__ uint32_t s_tile;
-    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);      // longest list first (gof_common.h)
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_tile);      // longest list first (gof_common.h)
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
@@ -276,7 +276,7 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                  const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
 {
     __shared__ uint32_t s_tile;
-    const uint32_t tile = pop_tile(tile_order, tile_queue, ntiles, &s_tile);      // most (points x walked entries) first (gof_common.h)
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_tile);      // most (points x walked entries) first (gof_common.h)
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;

@@ -565,7 +565,7 @@ _FETCH = {"depths": (torch.float32, 1), "means2D": (torch.float32, 2), "conic_op
           "view2gaussian": (torch.float32, 10), "tiles_touched": (torch.int32, 1),
           "clamped": (torch.uint8, 3), "point_list": (torch.int32, 0), "point_list_keys": (torch.int64, 0),
           "ranges": (torch.int32, 0), "point_ranges": (torch.int32, 0), "final_T": (torch.float32, 0), "n_contrib": (torch.int32, 0),
-          "contrib_pairs": (torch.int32, 0), "tile_cost": (torch.int32, 0), "tile_order": (torch.int32, 0), "tile_order_bw": (torch.int32, 0)}
+          "contrib_pairs": (torch.int32, 0), "tile_cost": (torch.int32, 0), "tile_order": (torch.int32, 0), "tile_order_bw": (torch.int32, 0), "tile_queue": (torch.int32, 0)}
 
 
 def debug_fetch(name, view, num_rendered, geom, binning, img):
@@ -574,7 +574,7 @@ def debug_fetch(name, view, num_rendered, geom, binning, img):
     P, HW = view.P, view.H * view.W
     T = ((view.W + 15) // 16) * ((view.H + 15) // 16)
     count = {"point_list": _layout_count(num_rendered), "point_list_keys": _layout_count(num_rendered), "ranges": 2 * T, "point_ranges": 2 * T,
-             "final_T": 4 * HW, "n_contrib": 2 * HW, "contrib_pairs": T, "tile_cost": T, "tile_order": (T + 7) // 8 * 8, "tile_order_bw": (T + 7) // 8 * 8}.get(name, P * per)
+             "final_T": 4 * HW, "n_contrib": 2 * HW, "contrib_pairs": T, "tile_cost": T, "tile_order": 8 * ((T + 7) // 8 + 128), "tile_order_bw": 8 * ((T + 7) // 8 + 128), "tile_queue": 64}.get(name, P * per)
     out = torch.empty(count, dtype=dtype, device=view.device)
     n = lib.gof_debug_fetch(name.encode(), view.ref(), _layout_count(num_rendered), _ptr(geom), _ptr(binning), _ptr(img),
                             C.c_void_p(out.data_ptr()), out.numel() * out.element_size(), _stream())

@@ -23,7 +23,7 @@ from diff_gaussian_rasterization import _backend as B  # noqa: E402
 SCENES = {"s1m": lambda: S.scene_frustum(1_000_000, seed=0), "s1m_clustered": lambda: S.scene_clustered(1_000_000, seed=0)}
 
 
-def tile_stats(fn, ntiles, order=None):
+def tile_stats(fn, ntiles, order=None, qlen=None):
     out = (C.c_ulonglong * (2 * ntiles))()
     assert fn(out, ntiles) == 0
     a = np.frombuffer(out, dtype=np.uint64).astype(np.int64)
@@ -41,12 +41,10 @@ def tile_stats(fn, ntiles, order=None):
     grid = np.linspace(st.min(), en.max(), 21)[1:-1]
     extra["running_tiles_at_5pct_steps"] = [int(((st <= g) & (en > g)).sum()) for g in grid]
     if order is not None and ok.all():
-        per = (ntiles + 7) // 8
+        stride = (ntiles + 7) // 8 + 128
         xcd_of = np.zeros(ntiles, dtype=np.int64)
         for x in range(8):
-            q = order[x * per:(x + 1) * per]
-            n = 2 * (ntiles >> 4) + (1 if x < min(ntiles & 15, 8) else 0) + (1 if ((ntiles & 15) > 8 and x >= 16 - (ntiles & 15)) else 0)
-            xcd_of[q[:n]] = x
+            xcd_of[order[x * stride:x * stride + int(qlen[x])]] = x
         extra["queue_finish_us"] = [round(float(en[xcd_of == x].max() - st.min()) / 100, 1) for x in range(8)]
         extra["queue_busy_us"] = [round(float(dur[xcd_of == x].sum()) / 100, 1) for x in range(8)]
     top = np.argsort(-dur)[:5]
@@ -86,9 +84,9 @@ def main():
         if hasattr(B.lib, "gof_debug_fw_tile_clock"):
             nt = len(L)
             product_forward_raw(sd); torch.cuda.synchronize()
-            out["blend_forward_tiles"] = tile_stats(B.lib.gof_debug_fw_tile_clock, nt, fetch(res, "tile_order").astype(np.int64))
+            out["blend_forward_tiles"] = tile_stats(B.lib.gof_debug_fw_tile_clock, nt, fetch(res, "tile_order").astype(np.int64), fetch(res, "tile_queue")[8:16])
             bwd(); torch.cuda.synchronize()
-            out["blend_backward_tiles"] = tile_stats(B.lib.gof_debug_bw_tile_clock, nt, fetch(res, "tile_order_bw").astype(np.int64))
+            out["blend_backward_tiles"] = tile_stats(B.lib.gof_debug_bw_tile_clock, nt, fetch(res, "tile_order_bw").astype(np.int64), fetch(res, "tile_queue")[40:48])
         print(json.dumps(out), flush=True)
 
 

@@ -865,16 +865,21 @@ def test_full_size_s1m_clustered_against_oracle():
     assert_image_matches(res["color"].cpu().numpy(), oc)
     rg = fetch(res, "ranges").view(np.uint32).reshape(-1, 2)
     L = rg[:, 1].astype(np.int64) - rg[:, 0]
-    T = len(L); per = (T + 7) // 8
+    T = len(L); stride = (T + 7) // 8 + 128
     order = fetch(res, "tile_order").astype(np.int64)
-    qlen = [2 * (T >> 4) + (1 if x < min(T & 15, 8) else 0) + (1 if ((T & 15) > 8 and x >= 16 - (T & 15)) else 0) for x in range(8)]
-    tiles = np.concatenate([order[x * per:x * per + qlen[x]] for x in range(8)])
-    assert np.array_equal(np.sort(tiles), np.arange(T))                                  # every tile exactly once
-    for x in range(8):
-        q = L[order[x * per:x * per + qlen[x]]]
-        assert q[0] >= 0.8 * L.max() and (q[:-1] * 1.25 + 4 >= q[1:]).all()              # heaviest first, non-increasing up to the bucket width (a bucket spans up to 5:4)
-    sums = [L[order[x * per:x * per + qlen[x]]].sum() for x in range(8)]
-    assert max(sums) <= 1.02 * min(sums)                                                  # the deal balances the XCD queues
+    qlen = fetch(res, "tile_queue").astype(np.int64)[8:16]
+    assert qlen.sum() == T and abs(qlen - T / 8).max() <= 16                            # (nearly) as many tiles per XCD as the dispatcher hands it workgroups
+    queues = [order[x * stride:x * stride + qlen[x]] for x in range(8)]
+    assert np.array_equal(np.sort(np.concatenate(queues)), np.arange(T))                 # every tile exactly once
+    for q_ in queues:
+        q = L[q_]
+        assert q[0] >= 0.5 * L.max() and (q[:-1] * 1.5 + 4 >= q[1:]).all()               # heaviest first, non-increasing up to the bucket width (a bucket spans up to 3:2)
+    sums = [L[q_].sum() for q_ in queues]
+    assert max(sums) <= 1.03 * min(sums)                                                  # every XCD gets the same share of every cost class
+    # ... as spatially contiguous runs: most neighbours in a queue are neighbours on the screen (same or adjacent tile row)
+    gx_ = (sc["W"] + 15) // 16
+    near = np.mean([np.mean(np.abs(np.diff(q_ // gx_)) <= 1) for q_ in queues])
+    assert near > 0.6, near
     walked = fetch(res, "tile_cost").astype(np.int64)
     nc = o.fetch("n_contrib").reshape(2, sc["H"], sc["W"])[0].astype(np.int64)
     gx, gy = (sc["W"] + 15) // 16, (sc["H"] + 15) // 16
