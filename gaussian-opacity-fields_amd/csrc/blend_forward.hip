@@ -75,7 +75,7 @@ __device__ unsigned long long g_fw_tile_clock[2][1 << 16];
 #endif
 // one tile: everything below is per tile; called by all 256 threads of the workgroup (persistent loop in blend_forward)
 __device__ __forceinline__ void
-blend_forward_tile(const uint32_t tile, uint32_t* s_tile, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                    const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                    uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost)
@@ -104,7 +104,7 @@ blend_forward_tile(const uint32_t tile, uint32_t* s_tile, const uint2* __restric
 #ifdef GOF_CULL_AUDIT
     __shared__ uint32_t s_cand[TILE_PIX / 32][TILE_PIX];
 #endif
-    __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
+    uint32_t* const s_tile = &s_mask[0][0];      // (the epilogue's scratch word: the masks are dead by then)
     // footprint conic, SoA: s_cf[c][entry], c = {m00, 2 m01, m11, 2 m02, 2 m12, m22}; read as float4 = one coefficient of 4 entries
     __shared__ f4 s_cf[6][TILE_PIX / 4];
     uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
@@ -288,16 +288,19 @@ blend_forward_tile(const uint32_t tile, uint32_t* s_tile, const uint2* __restric
         out_color[8 * HW + pix_id] = distortion;
     }
     // what this tile cost: the deepest list position any of its pixels blended = the entries the backward stages and walks
+#ifndef GOF_NO_TILE_COST      // (developer A/B: what the epilogue costs)
     {
         uint32_t m = inside ? last_contributor : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        __syncthreads();                            // every thread has read the popped tile id / its last mask words
         if (tid == 0) *s_tile = 0u;
         __syncthreads();
         if ((tid & 63u) == 0u) atomicMax(s_tile, m);
         __syncthreads();
         if (tid == 0) tile_cost[tile] = *s_tile;
     }
+#endif
     TILE_CLOCK_END(g_fw_tile_clock);
 }
 
@@ -309,10 +312,13 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
               uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
               uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
-    __shared__ uint32_t s_tile;
-    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_tile);
+    // The kernel's LDS must stay at 32 000 B: 25 allocation granules of 1280 B, five workgroups per CU.  One more word -- a
+    // separate slot for the popped tile id -- made it 26 granules and FOUR workgroups per CU (blend_forward 0.886 -> 0.93 ms,
+    // measured), so the tile id travels through the first word of the candidate masks, which are free before and after a tile.
+    __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_mask[0][0]);
     if (tile >= ntiles) return;
-    blend_forward_tile(tile, &s_tile, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
+    blend_forward_tile(tile, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
 }
 
 #ifdef GOF_TILE_CLOCK

@@ -875,7 +875,7 @@ def test_full_size_s1m_clustered_against_oracle():
         q = L[q_]
         assert q[0] >= 0.5 * L.max() and (q[:-1] * 1.5 + 4 >= q[1:]).all()               # heaviest first, non-increasing up to the bucket width (a bucket spans up to 3:2)
     sums = [L[q_].sum() for q_ in queues]
-    assert max(sums) <= 1.03 * min(sums)                                                  # every XCD gets the same share of every cost class
+    assert max(sums) <= 1.10 * min(sums)      # every XCD gets the same NUMBER of tiles of every cost class; inside a class (3:2) the spatial split leaves a few per cent
     # ... as spatially contiguous runs: most neighbours in a queue are neighbours on the screen (same or adjacent tile row)
     gx_ = (sc["W"] + 15) // 16
     near = np.mean([np.mean(np.abs(np.diff(q_ // gx_)) <= 1) for q_ in queues])
