@@ -938,7 +938,7 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     lib = os.path.join(root, "gaussian-opacity-fields_amd", "lib", "libgof_hip_audit.so")
     assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
     names = ["s1m", "s1m_ks01", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
-             "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01"]
+             "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01", "clustered150k", "posed_clustered150k"]
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib),
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]

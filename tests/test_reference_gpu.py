@@ -170,7 +170,7 @@ def _pin_forward(sc, image_tol=2e-5):
 
 @pytest.mark.parametrize("name", ["tiny", "one", "small_ks0", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "stress_box",
                                   "posed_tiny", "posed_small_ks01", "posed_ragged", "posed_long_lists", "posed_mid100k", "posed_stress_box",
-                                  "posed_mod2", "posed_mod05_ks01"])
+                                  "posed_mod2", "posed_mod05_ks01", "clustered150k", "posed_clustered150k"])
 def test_oracle_pinned_to_reference_on_the_scene_table(name):
     from test_parity_gpu import SCENES
     _pin_forward(SCENES[name]())
