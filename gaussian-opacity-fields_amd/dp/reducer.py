@@ -277,7 +277,13 @@ class GradientAllReducer:
             views = list(torch.split(flat, [g.numel() for g in grads]))
             with self._phase("bucket_pack"):
                 torch._foreach_copy_(views, grads)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            wire = flat
+            if self.wire_dtype is not None:          # opt-in reduced-precision wire format, also when the gradients had to be packed
+                if self._wire is None or self._wire.numel() != n or self._wire.device != flat.device:
+                    self._wire = torch.empty(n, dtype=self.wire_dtype, device=flat.device)
+                wire = self._wire
+                wire.copy_(flat)
+            works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.last_buckets = (len(buckets), len(rest))
 
         def finish():
@@ -288,6 +294,8 @@ class GradientAllReducer:
                 for b in buckets:
                     b.div_(world)
             if rest:
+                if wire is not flat:
+                    flat.copy_(wire)
                 if self.average:
                     flat.div_(world)
                 with self._phase("bucket_unpack"):
