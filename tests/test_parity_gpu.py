@@ -108,6 +108,8 @@ SCENES = {
     # tile scheduler (order_tiles / pop_tile) deals tiles heaviest first -- every tile must still be rendered exactly once
     "clustered150k": lambda: S.scene_clustered(150_000, W=640, H=432, focal=480.0, seed=3),
     "posed_clustered150k": lambda: S.scene_clustered(150_000, W=640, H=432, focal=480.0, seed=4, pose_seed=13),
+    # 32 640 tiles: the tile scheduler's waves own more than 8 x 64 tiles each (order_tiles beyond its register-resident part)
+    "wide4k": lambda: S.scene_frustum(60_000, W=3840, H=2176, focal=2900.0, seed=6, sigma_px=4.0, pose_seed=14),
     "posed_mod2": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=9, sigma_px=1.5, pose_seed=7), "scale_modifier": 2.0},
     "posed_mod05_ks01": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=10, sigma_px=5.0, kernel_size=0.1, pose_seed=8), "scale_modifier": 0.5},
 }
@@ -329,7 +331,7 @@ def _product_backward(res, dL):
     return {n: g.cpu().numpy() for n, g in zip(names, grads)}
 
 
-@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "clustered150k"] + POSED)
+@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "clustered150k", "wide4k"] + POSED)
 def test_backward_blend_gradients(name):
     sc = SCENES[name]()
     o, oc, orad, res = _forward_pair(sc)
@@ -416,7 +418,7 @@ def test_integrate_matches_oracle():
     assert (a[-2:] == 1.0).all()          # points outside the image keep the initial 1.0 (rasterize_points.cu:277)
 
 
-@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k"] + POSED)
+@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k", "wide4k"] + POSED)
 def test_integrate_bit_exact_on_scene(name):
     """The opacity-field query on the forward's scene table (incl. the cull stress scene: sub-pixel far splats, needles,
     splats containing the camera plane, opacities around 1/255): every output bit-identical to the oracle.  Query points =
