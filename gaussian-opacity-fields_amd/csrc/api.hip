@@ -326,7 +326,8 @@ using namespace gof;
 extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
-int gof_abi_version(void) { return 6; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib
+int gof_abi_version(void) { return 7; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
+                                          // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
