@@ -271,7 +271,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
             if name in extra_bytes:
                 ent["design_extra_MB"] = round(extra_bytes[name] / 1e6, 2)
         kernels[name] = ent
-    fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "order_tiles", "blend_forward")
+    fwd_names = ("preprocess_fwd", "sort_gaussians_by_depth", "scan_tiles", "emit_instances", "sort_instances_by_tile", "tile_ranges", "order_tiles", "blend_forward", "order_tiles_bw")
     fwd_ms = sum(kernels[k]["avg_ms"] for k in fwd_names if k in kernels)
     bwd_ms = sum(kernels[k]["avg_ms"] for k in ("backward_memsets", "blend_backward", "gather_tile_partials", "preprocess_bwd") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["calls"])

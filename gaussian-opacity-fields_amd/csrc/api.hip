@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -312,9 +313,16 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
 
 // The backward's dispatch order: what a tile costs there is known exactly after the forward blend (the deepest list position one of
 // its pixels blended = the entries the backward stages and walks), so the forward call leaves the order in the image workspace.
+// developer A/B (GOF_BW_ORDER_BY_LENGTH=1): the backward pops the forward's queues (cost = list length) and the second launch is skipped
+static bool bw_order_by_length()
+{
+    static const bool on = [] { const char* e = getenv("GOF_BW_ORDER_BY_LENGTH"); return e && e[0] == '1'; }();
+    return on;
+}
 static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream_t stream)
 {
-    GOF_PROFILE("order_tiles", stream);
+    if (bw_order_by_length()) return;
+    GOF_PROFILE("order_tiles_bw", stream);
     // (queue lengths at tile_queue[40..47]; the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
     hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr);
 }
@@ -567,7 +575,8 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles, im.tile_order_bw, ws.queue, im.tile_queue + TILE_QUEUE_WORDS / 2 + NXCD);
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles,
+                           bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);

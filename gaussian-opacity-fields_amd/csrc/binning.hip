@@ -208,13 +208,43 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
     const uint32_t chunk = ((ntiles + NW - 1) / NW + 63u) & ~63u;
     const uint32_t t0 = wave * chunk, t1 = min(ntiles, t0 + chunk);
     const uint32_t steps = t1 > t0 ? (t1 - t0 + 63u) / 64u : 0u;
+    // Counting without LDS atomics: in a uniform scene all 64 lanes of a wave hold the same one or two classes, and a same-address
+    // ds_add serialises its lanes (~3.5 cycles each; 16 waves x 7 steps of it were 10 of this kernel's 15 us).  The 7 ballots that
+    // rank a tile among the same-class lanes of its step give the count as well: the group's lowest lane adds it, plainly (a wave
+    // owns its row of s_wc, a step has one leader per class).  Rank and count of the first 8 steps stay in registers for the placement.
     constexpr int KEEP = 8;
-    uint8_t mine[KEEP];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    auto match = [&](bool live, uint32_t bkt, uint32_t& rank, uint32_t& lead_cnt) {      // whole wave
+        uint64_t peers = __ballot(live);
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const uint32_t i = t0 + 64u * k + lane; mine[k] = ((uint32_t)k < steps && i < t1) ? (uint8_t)bucket(i) : (uint8_t)0; }
+        for (int bit = 0; bit < 7; bit++) {
+            const uint64_t bal = __ballot((bkt >> bit) & 1u);
+            peers &= ((bkt >> bit) & 1u) ? bal : ~bal;
+        }
+        rank = (uint32_t)__popcll(peers & lt);
+        lead_cnt = (live && (peers & lt) == 0ull) ? (uint32_t)__popcll(peers) : 0u;     // > 0 only in the group's lowest lane
+    };
+    uint8_t mine[KEEP], rk[KEEP], lc[KEEP];
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const uint32_t i = t0 + 64u * k + lane; if ((uint32_t)k < steps && i < t1) atomicAdd(&s_wc[wave][mine[k]], 1u); }
-    for (uint32_t k = KEEP; k < steps; k++) { const uint32_t i = t0 + 64u * k + lane; if (i < t1) atomicAdd(&s_wc[wave][bucket(i)], 1u); }
+    for (int k = 0; k < KEEP; k++) { const uint32_t i = t0 + 64u * k + lane; mine[k] = ((uint32_t)k < steps && i < t1) ? (uint8_t)bucket(i) : (uint8_t)0xFF; }
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) {
+        rk[k] = 0; lc[k] = 0;
+        if ((uint32_t)k < steps) {                                               // steps is wave-uniform
+            const uint32_t i = t0 + 64u * k + lane;
+            uint32_t r_, c_;
+            match(i < t1, mine[k], r_, c_);
+            rk[k] = (uint8_t)r_; lc[k] = (uint8_t)c_;                             // (both <= 64)
+            if (c_) s_wc[wave][mine[k]] += c_;
+        }
+    }
+    for (uint32_t k = KEEP; k < steps; k++) {
+        const uint32_t i = t0 + 64u * k + lane;
+        const uint32_t bkt = i < t1 ? bucket(i) : 0xFFu;
+        uint32_t r_, c_;
+        match(i < t1, bkt, r_, c_);
+        if (c_) s_wc[wave][bkt] += c_;
+    }
     __syncthreads();
     {   // per bucket: exclusive prefix over the waves (ascending tile id), total n_b; then G_b = tiles in heavier buckets
         uint32_t run = 0, inc = 0;
@@ -250,31 +280,36 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
         if (b == 127u && queue) { queue[x] = 0u; queue[NXCD + x] = before + inc; }  // head, length
     }
     __syncthreads();
-    const uint64_t lt = (1ull << lane) - 1ull;
-    auto place = [&](uint32_t i, bool live, uint32_t bkt) {          // called by the whole wave (ballots), tiles in ascending id
-        uint64_t peers = __ballot(live);
-#pragma unroll
-        for (int bit = 0; bit < 7; bit++) {
-            const uint64_t bal = __ballot((bkt >> bit) & 1u);
-            peers &= ((bkt >> bit) & 1u) ? bal : ~bal;
-        }
+    auto place = [&](uint32_t i, bool live, uint32_t bkt, uint32_t rank, uint32_t lead_cnt) {
         if (live) {
-            const uint32_t base = s_wc[wave][bkt];
-            const uint32_t r = base + (uint32_t)__popcll(peers & lt);               // stable rank of tile i inside its bucket
-            if ((peers & lt) == 0ull) s_wc[wave][bkt] = base + (uint32_t)__popcll(peers);      // the group's lowest lane advances the wave's base
+            const uint32_t base = s_wc[wave][bkt];                                  // tiles of this class in earlier waves and earlier steps
+            const uint32_t r = base + rank;                                         // stable rank of tile i inside its class
+            if (lead_cnt) s_wc[wave][bkt] = base + lead_cnt;                        // the group's lowest lane advances the wave's base
             const uint32_t n = s_n[bkt];
-            uint32_t e = (uint32_t)(((unsigned long long)r * 8ull) / n);            // the eighth this rank falls into:
-            e = e > 7u ? 7u : e;                                                    // floor(8 r / n) = e  <=>  ceil(e n / 8) <= r < ceil((e + 1) n / 8)
+            // the eighth this rank falls into: floor(8 r / n) = e  <=>  ceil(e n / 8) <= r < ceil((e + 1) n / 8) -- seven compares
+            // against the thresholds instead of an integer division
+            uint32_t e = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < 8; k++) e += (r >= ((k * n + 7u) >> 3)) ? 1u : 0u;
             const uint32_t lo = (e * n + 7u) >> 3;
-            const uint32_t x = (e + s_g[bkt]) & 7u;                                 // the XCD that takes this eighth of this bucket
+            const uint32_t x = (e + s_g[bkt]) & 7u;                                 // the XCD that takes this eighth of this class
             order[x * stride + s_off[x][bkt] + (r - lo)] = i;
         }
     };
 #pragma unroll
     for (int k = 0; k < KEEP; k++) {
-        if ((uint32_t)k < steps) { const uint32_t i = t0 + 64u * k + lane; place(i, i < t1, i < t1 ? (uint32_t)mine[k] : 0xFFu); }      // steps is wave-uniform
+        if ((uint32_t)k < steps) {
+            const uint32_t i = t0 + 64u * k + lane;
+            place(i, i < t1, mine[k], rk[k], lc[k]);
+        }
     }
-    for (uint32_t k = KEEP; k < steps; k++) { const uint32_t i = t0 + 64u * k + lane; place(i, i < t1, i < t1 ? bucket(i) : 0xFFu); }
+    for (uint32_t k = KEEP; k < steps; k++) {
+        const uint32_t i = t0 + 64u * k + lane;
+        const uint32_t bkt = i < t1 ? bucket(i) : 0xFFu;
+        uint32_t r_, c_;
+        match(i < t1, bkt, r_, c_);
+        place(i, i < t1, bkt, r_, c_);
+    }
 }
 
 // debug: the reference's 64-bit sort key of every sorted instance (tile << 32 | depth bits)
