@@ -78,7 +78,7 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  const uint32_t* tile_order, uint32_t* tile_queue);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
-                             const uint32_t* sort_error);
+                             const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
@@ -297,7 +297,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
-    GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
+    // (im.ranges was cleared by gather_rects in stage 1 of this frame: gof_forward_prepare / gof_forward_fused)
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
         hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev,
@@ -344,7 +344,7 @@ size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_l
 size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
 
 // preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
-static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream)
+static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream)
 {
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
@@ -367,7 +367,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, int32_t* radi
     // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
     // scanned in place
     hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, g.dkey_b, g.dval_b, g.order_off,
-                       radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32));
+                       radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles);
     GOF_HIP_CHECK(device_scan_u32(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
                                   total_dev_out, stream)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
@@ -387,10 +387,11 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     if (!radii || !geom_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
     if (geom_bytes < gof_geom_bytes(a->P)) { set_error("geometry workspace too small: %zu < %zu", geom_bytes, gof_geom_bytes(a->P)); return GOF_E_WORKSPACE; }
     if (image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace too small"); return GOF_E_WORKSPACE; }
-    GeomWs g;
+    GeomWs g; ImageWs im;
     geom_layout(a->P, aligned_base(geom_ws), &g);
+    image_layout(a->W, a->H, aligned_base(image_ws), &im);
     const uint32_t* total_dev = nullptr;
-    rc = forward_stage1(a, g, radii, &total_dev, stream);
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream);
     if (rc) return rc;
     // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
     uint32_t host_words[2] = { 0, 0 };
@@ -434,7 +435,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     bin_layout(capacity, a->W, a->H, aligned_base(binning_ws), &b, true);
     const Dims d = dims_of(a);
     const uint32_t* total_dev = nullptr;
-    rc = forward_stage1(a, g, radii, &total_dev, stream);
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream);
     if (rc) return rc;
     static thread_local hipEvent_t ev = nullptr;
     if (!ev) GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -445,7 +446,6 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
         rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
         if (rc) return rc;
     } else {
-        GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
         hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr);
     }
     { GOF_PROFILE("blend_forward", stream);

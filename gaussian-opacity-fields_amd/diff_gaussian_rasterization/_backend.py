@@ -287,11 +287,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         g_sh = (bucket[offs[4]:offs[4] + sizes[4]].view(P, 1, 3), bucket[offs[5]:offs[5] + sizes[5]].view(P, 15, 3))
     else:
         g_sh = bucket[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
-    # what the blend ACCUMULATES into (and the dead dL_dcov3D) must be zero-filled: one allocation, no padding, so that the library
-    # clears it with a single memset (widest rows first: every segment stays 8-byte aligned)
-    acc = torch.empty(22 * P, **f)
-    g_v2g = acc[:10 * P].view(P, 10); g_cov3D = acc[10 * P:16 * P].view(P, 6)
-    g_means2D = acc[16 * P:19 * P].view(P, 3); g_colors = acc[19 * P:22 * P].view(P, 3)
+    # dL_dview2gaussian / dL_dmeans2D / dL_dcolors are written completely by the library (gather_tile_partials).  dL_dcov3D is a DEAD
+    # output of the reference (always zero: its consumer is commented out, backward.cu:627-630, rasterize_points.cu:166): without a
+    # cov3D_precomp to hand it to, it is returned as a stride-0 view of one zero -- same values, no 24 B per Gaussian to allocate and
+    # clear every iteration; with cov3D_precomp a real zero tensor is produced (the library clears it).
+    acc = torch.empty(16 * P, **f)
+    g_v2g = acc[:10 * P].view(P, 10)
+    g_means2D = acc[10 * P:13 * P].view(P, 3); g_colors = acc[13 * P:16 * P].view(P, 3)
+    want_cov3D = isinstance(cov3D_precomp, torch.Tensor) and cov3D_precomp.numel() > 0
+    g_cov3D = torch.empty((P, 6), **f) if want_cov3D else torch.zeros(1, **f).expand(P, 6)
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):
@@ -300,7 +304,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),
-                    _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D),
+                    _ptr(g_means2D), _ptr(g_colors), _ptr(g_opacity), _ptr(g_means3D), _ptr(g_cov3D) if want_cov3D else None,
                     _ptr(g_sh[0] if v.split_sh else g_sh), _ptr(g_sh[1]) if v.split_sh else None,
                     _ptr(g_scales), _ptr(g_rot), _ptr(g_v2g), _ptr(scratch), nscratch, _stream())
             track = _sh_track["on"] and M > 0
