@@ -127,6 +127,7 @@ def main():
     if not quick:
         table["s1m"] = lambda: S.scene_frustum(1_000_000, seed=0)
         table["s1m_posed"] = lambda: S.scene_frustum(1_000_000, seed=0, pose_seed=0)
+        table["s1m_clustered"] = lambda: S.scene_clustered(1_000_000, seed=0)
     rep = {"tool": "tests/devtools/dev_parity_report.py", "gpu": torch.cuda.get_device_name(0),
            "definitions": {"max_norm": "max|a-ref| / max|ref|", "rel_l2": "||a-ref|| / ||ref||",
                            "p999_elem": "99.9th percentile of |a-ref|/|ref| over elements with |ref| > 1e-3 max|ref|",

@@ -10,11 +10,11 @@ Bars (stated per test):
   * normal channels (3-5): the device normalises with one v_rsq_f32 where the reference takes an fp64 sqrt and
     three IEEE divisions -- 2e-6 absolute (components are <= 1 in magnitude; measured 3e-7);
   * backward blend gradients (fixed-order fp32 sums vs the oracle's double accumulation) -- north_star tolerance 1e-4; ASSERTED
-    at the round-3 measurements (profiles/r03_parity_report.md, 25 scenes) x a small factor: max-norm error <= 1e-5 of the
+    at the round-3 measurements (profiles/r03_parity_report.md, 29 scenes) x a small factor: max-norm error <= 1e-5 of the
     tensor's maximum (measured <= 1.5e-6), relative L2 <= 1e-5 (measured <= 1.2e-6), and ELEMENT-WISE: the 99.9th percentile of
     |a - ref| / |ref| over the elements with |ref| > 1e-3 max|ref| <= 5e-4 (measured <= 5.8e-5) -- a max-norm bound alone lets
     elements 100x below the maximum be 1 % off;
-  * K9 (per-Gaussian backward) on bit-identical inputs -- 1e-6 of the maximum (measured: 0, bit-equal on all 25 scenes; it is an
+  * K9 (per-Gaussian backward) on bit-identical inputs -- 1e-6 of the maximum (measured: 0, bit-equal on all 29 scenes; it is an
     ill-conditioned function of dL_dview2gaussian, so it is checked in isolation; the end-to-end figures against the reference's
     own error band are in the report and asserted in test_reference_gpu.py).
 """
