@@ -31,7 +31,7 @@ __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const 
                                const float* dL_dv2g, const float* dL_dcolor, float* dL_dmeans, float* dL_dsh, float* dL_dsh_rest,
                                float* dL_dscales, float* dL_drots);
 __global__ void preprocess_points(int PN, const float* points3D, Cam cam, int W, int H, float focal_x, float focal_y,
-                                  float2* points2D, float* depths, uint32_t* tiles_touched);
+                                  float4* pos, uint32_t* tiles_touched);
 __global__ void mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present);
 __global__ void sh_grad_pack(int P, const float* dL_dcolor, const uint8_t* clamped, const int32_t* radii, float* packed);
 template <int MC>
@@ -49,7 +49,7 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
 int radix_passes(int end_bit);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
                                uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity);
-__global__ void point_keys(int PN, const float2* points2D, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
+__global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev, const uint32_t* sort_error,
                             uint32_t* async_status);
@@ -79,7 +79,7 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
                              const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
-__global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float2* points2D, const float* depths, float2* pt_xy, float* pt_depth);
+__global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float4* pos, float2* pt_xy, float* pt_depth);
 
 // ---- error text --------------------------------------------------------------------------------------
 static thread_local std::string g_error;
@@ -225,8 +225,7 @@ size_t point_layout(int32_t PN, void* base, PointWs* out)
     PointWs w;
     char* p = static_cast<char*>(base);
     const size_t n = (size_t)PN;
-    carve(p, w.depths, n);
-    carve(p, w.points2D, n);
+    carve(p, w.pos, n);
     carve(p, w.tiles_touched, n);
     carve(p, w.point_offsets, n);
     carve(p, w.T_state, n);
@@ -630,7 +629,7 @@ int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     hipLaunchKernelGGL(preprocess_points, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, points3D, cam, a->W, a->H,
-                       d.focal_x, d.focal_y, w.points2D, w.depths, w.tiles_touched);
+                       d.focal_x, d.focal_y, w.pos, w.tiles_touched);
     GOF_LAUNCH_CHECK(stream, a->debug);
     GOF_HIP_CHECK(device_scan_u32(w.tiles_touched, nullptr, w.point_offsets, (size_t)PN, true, w.scan_tmp, nullptr, stream));
     GOF_LAUNCH_CHECK(stream, a->debug);
@@ -729,7 +728,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         const bool odd = radix_passes(key_bits) & 1;
         uint32_t* t_in = odd ? pb.tiles_alt : pb.tiles;
         uint32_t* v_in = odd ? pb.vals_alt : pb.vals;
-        hipLaunchKernelGGL(point_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.points2D, w.point_offsets, w.tiles_touched,
+        hipLaunchKernelGGL(point_keys, dim3((PN + 255) / 256), dim3(256), 0, stream, PN, w.pos, w.point_offsets, w.tiles_touched,
                            t_in, v_in, d.gx, d.gy);
         GOF_LAUNCH_CHECK(stream, a->debug);
         rc = sort_by_tile(pb, NI, t_in, v_in, key_bits, stream);
@@ -741,7 +740,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr,
                            radix_sort_error_flag(pb.sort_tmp, (size_t)NI, (int)higher_msb(d.ntiles) + 8), async_status_word());
         GOF_LAUNCH_CHECK(stream, a->debug);
-        hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.points2D, w.depths, pb.pt_xy, pb.pt_depth);
+        hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.pos, pb.pt_xy, pb.pt_depth);
         GOF_LAUNCH_CHECK(stream, a->debug);
     } }
     // dispatch order of the point pass: #points of the tile x what its pixels walked (tile_cost, left by integrate_pixels), heaviest first

@@ -113,14 +113,14 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
 // re-count of the tile's deepest point, which integrate_points finds explicitly -- so the 4 depth passes are dropped, and
 // grouping by pixel lets neighbouring lanes of integrate_points walk the SAME contributor mask.
 __global__ void __launch_bounds__(256)
-point_keys(int PN, const float2* __restrict__ points2D, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
+point_keys(int PN, const float4* __restrict__ pos, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx, uint32_t gy)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= PN) return;
     if (tiles_touched[idx] > 0) {
         const uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
-        const float2 p = points2D[idx];
+        const float4 p = pos[idx];
         const int x = (int)min(gx - 1, (uint32_t)max(0, (int)(p.x / TILE_X)));
         const int y = (int)min(gy - 1, (uint32_t)max(0, (int)(p.y / TILE_Y)));
         const uint32_t lx = ((uint32_t)p.x - (uint32_t)x * TILE_X) & (TILE_X - 1), ly = ((uint32_t)p.y - (uint32_t)y * TILE_Y) & (TILE_Y - 1);
@@ -130,16 +130,18 @@ point_keys(int PN, const float2* __restrict__ points2D, const uint32_t* __restri
 }
 
 // per-point data in LIST order (tile-major, depth within the tile): the point pass of integrate reads it once per staged batch,
-// a gather by point id there would touch a different DRAM sector per point per batch
+// a gather by point id there would touch a different DRAM sector per point per batch.  Position and depth of a point are one
+// 16-byte line (PointWs::pos): ONE random sector per point here, where two arrays cost two (this gather was half of bin_points)
 __global__ void __launch_bounds__(256)
-gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const float2* __restrict__ points2D, const float* __restrict__ depths,
+gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ pos,
                      float2* __restrict__ pt_xy, float* __restrict__ pt_depth)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NI) return;
     const uint32_t id = sorted_ids[i];
-    pt_xy[i] = points2D[id];
-    pt_depth[i] = depths[id];
+    const float4 p = pos[id];
+    pt_xy[i] = make_float2(p.x, p.y);
+    pt_depth[i] = p.z;
 }
 
 // replaces cudaMemset + identifyTileRanges (rasterizer_impl.cu:365-373, 149-171); ranges must be zeroed before.

@@ -78,7 +78,8 @@ struct BinWs {
 };
 // Point workspace (replaces PointState, rasterizer_impl.h:47-55)
 struct PointWs {
-    float* depths; float2* points2D; uint32_t* tiles_touched; uint32_t* point_offsets;   // offsets: inclusive scan
+    float4* pos;            // [PN] {pixel x, pixel y, view depth, -} of a point inside the image: ONE 16-byte line for the random read of gather_sorted_points
+    uint32_t* tiles_touched; uint32_t* point_offsets;   // offsets: inclusive scan
     float* T_state;         // [PN] running transmittance of each query point (integrate pass 2)
     uint32_t* scan_tmp;     // scan_tmp_words(PN) words
 };

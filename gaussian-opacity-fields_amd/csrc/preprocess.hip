@@ -663,7 +663,7 @@ GOF_K9_INST(0) GOF_K9_INST(1) GOF_K9_INST(2)
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 preprocess_points(int PN, const float* __restrict__ points3D, Cam cam, int W, int H, float focal_x, float focal_y,
-                  float2* __restrict__ points2D, float* __restrict__ depths, uint32_t* __restrict__ tiles_touched)
+                  float4* __restrict__ pos, uint32_t* __restrict__ tiles_touched)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= PN) return;
@@ -674,8 +674,7 @@ preprocess_points(int PN, const float* __restrict__ points3D, Cam cam, int W, in
         const float pix = (float)((double)(focal_x * pv.x / (pv.z + 0.0000001f)) + W / 2.);
         const float piy = (float)((double)(focal_y * pv.y / (pv.z + 0.0000001f)) + H / 2.);
         if (!(pix < 0 || pix >= W || piy < 0 || piy >= H)) {
-            depths[idx] = pv.z;
-            points2D[idx] = make_float2(pix, piy);
+            pos[idx] = make_float4(pix, piy, pv.z, 0.0f);       // projected position + depth (forward.cu:758-760) as one 16-byte line
             touched = 1;
         }
     }
