@@ -83,3 +83,15 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in text and "oracle_binding" not in text and "gofref_" not in text, os.path.join(dirpath, f)
+
+
+def test_num_rendered_is_the_count_and_carries_the_layout_size():
+    """RasterizeGaussiansCUDA returns the instance count of the frame (rasterize_points.cu:119); on the sync-free forward the binning
+    workspace is laid out for a capacity >= that count, which only the backward needs: an int that remembers it."""
+    from diff_gaussian_rasterization import _backend as B
+    n = B.NumRendered(8_837_593, 11_075_584)
+    assert n == 8_837_593 and isinstance(n, int) and n + 1 == 8_837_594 and "%d" % n == "8837593"
+    assert n.layout == 11_075_584 and B._layout_count(n) == 11_075_584
+    m = B.NumRendered(123)
+    assert m.layout == 123 and B._layout_count(m) == 123 and B._layout_count(77) == 77       # a plain int (two-stage path, C callers) is its own layout
+    assert B._round_capacity(8_837_593) >= int(8_837_593 * 1.25) and B._round_capacity(0) == 1 << 16
