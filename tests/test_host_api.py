@@ -73,7 +73,8 @@ def test_no_cpu_fallback():
 
 
 def test_product_does_not_import_oracle():
-    """The oracle is test infrastructure: nothing under gaussian-opacity-fields_amd/ may reference it."""
+    """The oracle and the host emulation of the kernels (tests/hipemu) are test infrastructure: nothing under
+    gaussian-opacity-fields_amd/ may reference either."""
     import os
     pkg = os.path.dirname(os.path.dirname(os.path.abspath(dgr.__file__)))
     for dirpath, _, files in os.walk(pkg):
@@ -83,6 +84,7 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in text and "oracle_binding" not in text and "gofref_" not in text, os.path.join(dirpath, f)
+                assert "hipemu" not in text.lower() and "libgof_hip_emu" not in text, os.path.join(dirpath, f)
 
 
 def test_num_rendered_is_the_count_and_carries_the_layout_size():
