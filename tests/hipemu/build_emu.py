@@ -43,7 +43,7 @@ def build(asan=False, force=False, extra_flags=(), tag="", verbose=False):
              "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-unused-value", "-Wno-pass-failed",
              "-I", os.path.join(HERE, "include"), "-I", CSRC, "-DGOF_HIPEMU=1"] + list(extra_flags)
     if asan:
-        flags += ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        flags += ["-fsanitize=address,undefined", "-fno-sanitize=pointer-overflow", "-fno-omit-frame-pointer"]      # (the layout functions size a workspace by carving from a null base)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "hipemu_rt.cpp"),
                                                                 os.path.join(ROOT, "include", "gof_hip.h"), __file__]
