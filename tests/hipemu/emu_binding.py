@@ -34,10 +34,24 @@ def load(asan=False, extra_flags=(), tag=""):
     return _libs[key]
 
 
-def _aligned(nbytes, dtype=np.uint8, align=256):
-    raw = np.zeros(int(nbytes) + align, dtype=np.uint8)
+GUARD = 4096
+_guards = []          # (what, guard view): every workspace handed to the library has GUARD bytes of 0xA5 behind its stated size
+
+
+def _aligned(nbytes, dtype=np.uint8, align=256, what="workspace"):
+    raw = np.zeros(int(nbytes) + align + GUARD, dtype=np.uint8)
     off = (-raw.ctypes.data) % align
+    g = raw[off + int(nbytes):off + int(nbytes) + GUARD]
+    g[:] = 0xA5
+    _guards.append((what, int(nbytes), g))
+    if len(_guards) > 256:
+        del _guards[:128]
     return raw[off:off + int(nbytes)].view(dtype)
+
+
+def guards_intact():
+    """-> list of (what, size) of the workspaces allocated so far whose guard bytes were overwritten (a write past the stated size)"""
+    return [(w, n) for w, n, g in _guards if not (g == 0xA5).all()]
 
 
 def _f32(a):
@@ -87,12 +101,12 @@ class EmuScene:
 
     def forward(self):
         lib = self.lib
-        self.geom = _aligned(lib.gof_geom_bytes(self.P)); self.img = _aligned(lib.gof_image_bytes(self.W, self.H))
+        self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
         self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
-        self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H))
+        self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
         self.color = np.zeros((9, self.H, self.W), np.float32)
         self._check(lib.gof_forward_render(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
                                            _p(self.img), self.img.size, _p(self.color), None))
@@ -108,7 +122,7 @@ class EmuScene:
             v.fill(np.nan)          # the library must write every element it owns
         g["cov3D"].fill(0)
         nscratch = lib.gof_backward_scratch_bytes(P, self.R)
-        scratch = _aligned(nscratch)
+        scratch = _aligned(nscratch, what="backward scratch")
         self._check(lib.gof_backward(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
                                      _p(self.img), self.img.size, _p(dl), _p(g["means2D"]), _p(g["colors"]), _p(g["opacity"]), _p(g["means3D"]), None,
                                      _p(g["sh"]) if M else None, None, _p(g["scales"]), _p(g["rotations"]), _p(g["view2gaussian"]), _p(scratch), nscratch, None))
@@ -136,21 +150,39 @@ class EmuScene:
         """-> (out_color [9,H,W], alpha_integrated [N], color_integrated [N,3], radii): gof_integrate_view + prepare_points + points."""
         lib = self.lib
         pts = _f32(points3D); PN = int(pts.shape[0])
-        self.geom = _aligned(lib.gof_geom_bytes(self.P)); self.img = _aligned(lib.gof_image_bytes(self.W, self.H))
+        self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
         self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
-        self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H))
+        self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
         base = np.zeros((9, self.H, self.W), np.float32)
         self._check(lib.gof_integrate_view(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
                                            _p(self.img), self.img.size, _p(base), None))
-        pws = _aligned(lib.gof_point_bytes(PN))
+        pws = _aligned(lib.gof_point_bytes(PN), what="point ws")
         ni = C.c_uint32(0)
         self._check(lib.gof_integrate_prepare_points(C.byref(self.args), PN, _p(pts), _p(pws), pws.size, C.byref(ni), None))
         self.NI = int(ni.value)
-        pbin = _aligned(lib.gof_point_binning_bytes(self.NI, self.W, self.H))
+        pbin = _aligned(lib.gof_point_binning_bytes(self.NI, self.W, self.H), what="point binning")
         alpha = np.ones(PN, np.float32); colp = np.zeros((PN, 3), np.float32)
         self._check(lib.gof_integrate_points(C.byref(self.args), self.R, PN, self.NI, _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
                                              _p(self.img), self.img.size, _p(pws), pws.size, _p(pbin), pbin.size, _p(base), _p(base), _p(alpha), _p(colp), None))
         return base, alpha, colp, self.radii
+
+    def forward_fused(self, capacity, guard=4096):
+        """gof_forward_fused (the sync-free forward: binning workspace sized for `capacity` instances, the count read on the device).
+        The binning workspace is allocated at EXACTLY gof_binning_bytes(capacity) with `guard` bytes of 0xA5 behind it.
+        -> (rc, true instance count, guard intact?)"""
+        lib = self.lib
+        self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
+        nb = int(lib.gof_binning_bytes(int(capacity), self.W, self.H))
+        raw = _aligned(nb + guard)
+        raw[nb:] = 0xA5
+        self.binning = raw[:nb]
+        self.radii = np.zeros(self.P, np.int32)
+        self.color = np.zeros((9, self.H, self.W), np.float32)
+        pinned = np.zeros(4, np.uint32)
+        rc = lib.gof_forward_fused(C.byref(self.args), int(capacity), _p(self.geom), self.geom.size, _p(self.binning), nb, _p(self.img), self.img.size,
+                                   _p(self.radii), _p(self.color), _p(pinned), None)
+        self.R = int(capacity)           # the layout size: what fetch() / backward() have to be given on this path
+        return rc, int(pinned[0]), bool((raw[nb:] == 0xA5).all())

@@ -25,6 +25,13 @@ if not os.path.exists(build_emu.CXX):
     pytest.skip("no host clang++ (%s) to build the emulated library" % build_emu.CXX, allow_module_level=True)
 import emu_binding as E  # noqa: E402
 
+@pytest.fixture(autouse=True)
+def _no_write_past_a_workspace():
+    """every workspace the tests hand to the library is allocated at EXACTLY the size its gof_*_bytes() states, with guard bytes behind"""
+    yield
+    assert E.guards_intact() == []
+
+
 FAST = ["tiny", "one", "small_ks0", "small_ks01", "long_lists", "stress_box", "posed_tiny", "posed_small_ks01", "posed_long_lists",
         "posed_stress_box", "posed_mod2", "posed_mod05_ks01"]
 MEDIUM = ["lego10k", "posed_ragged", "posed_clustered150k"]
@@ -136,3 +143,48 @@ def test_emulator_reports_divergent_cross_lane_use():
     assert "all ok" in r.stdout
     r = subprocess.run([out, "diverge"], capture_output=True, text=True)
     assert r.returncode != 0 and "DIFFERENT cross-lane operations" in r.stderr
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_emulated_fuzz_forward_integrate_backward(seed):
+    """the GPU suite's randomised small scenes (image size, focal length, splat size from sub-pixel to tile-covering, anisotropy,
+    opacity regimes, depth range, kernel size, SH degree, pose, scale_modifier): forward and opacity query bit-exact, blend
+    gradients within the GPU suite's bars"""
+    sc = TP._fuzz_scene(seed)
+    o, oc, orad, e, pc, prad = _pair(sc)
+    assert e.R == o.num_rendered() and np.array_equal(prad, orad)
+    for arr in TP.INT_ARRAYS:
+        assert TP._same(e.fetch(arr), o.fetch(arr)), arr
+    assert np.array_equal(bits(e.fetch("final_T")), bits(o.fetch("final_T")))
+    TP.assert_image_matches(pc, oc)
+    dL = np.random.default_rng(seed).normal(size=oc.shape).astype(np.float32)
+    go = o.backward(dL); gp = e.backward(dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian"):
+        TP.assert_grad_close(gp[k], go[k], k)
+    pts = np.ascontiguousarray(S.tetra_points(sc)[:20000], dtype=np.float32)
+    io, ia, icol, _ = o.integrate(pts)
+    c, a, colp, _ = e.integrate(pts)
+    assert np.array_equal(bits(c), bits(io)) and np.array_equal(bits(a), bits(ia)) and np.array_equal(bits(colp), bits(icol))
+
+
+def test_emulated_sync_free_forward_respects_its_capacity():
+    """gof_forward_fused: every launch behind the scan is sized for the caller's capacity and reads the true count on the device.
+    With room to spare and with EXACTLY the count it renders the two-stage forward's image; one instance short it returns
+    GOF_E_CAPACITY -- and in every case nothing is written behind a binning workspace allocated at exactly its stated size."""
+    sc = TP.SCENES["posed_mod2"]()
+    e = E.EmuScene(sc)
+    want, _ = e.forward()
+    want = want.copy(); R = e.R
+    list_two_stage = e.fetch("point_list").copy()
+    for cap in (R + 12345, R):
+        f = E.EmuScene(sc)
+        rc, count, intact = f.forward_fused(cap)
+        assert rc == 0 and count == R and intact, (cap, rc, count, intact)
+        assert np.array_equal(bits(f.color), bits(want))
+        assert np.array_equal(f.fetch("point_list")[:R], list_two_stage)
+        g = f.backward(np.ones_like(want))                  # the backward finds its arrays through the capacity's layout
+        assert all(np.isfinite(v).all() for v in g.values())
+    for cap in (R - 1, R // 2, 64):
+        f = E.EmuScene(sc)
+        rc, count, intact = f.forward_fused(cap)
+        assert rc == -5 and count == R and intact, (cap, rc, count, intact)          # GOF_E_CAPACITY, the true count reported
