@@ -339,3 +339,92 @@ def test_the_dp_launcher_installs_the_camera_list_hook_in_the_module_the_filter_
     src = open(os.path.join(pkg, "launch", "run_train_dp.py")).read()
     assert "import train_epilogue.filter_3d as" not in src.replace("(not `import train_epilogue.filter_3d as m`", "")
     assert 'importlib.import_module("train_epilogue.filter_3d")' in src
+
+
+def _worker_emu(rank, world, port, ret):
+    """world-2 data-parallel step with the REAL kernels: every rank renders ITS view of the same replica Gaussians through the
+    rasterizer's source compiled for the host (tests/hipemu), the parameter gradients of the views are summed by
+    GradientAllReducer, the densification statistics by all_reduce_densification_stats."""
+    for p in (os.path.join(ROOT, "gaussian-opacity-fields_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hipemu")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HIPEMU_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import emu_binding as E
+    import synthetic_scenes as S
+    from dp import GradientAllReducer, shard_views
+    from dp.reducer import all_reduce_densification_stats
+    base = S.scene_frustum(2500, W=128, H=96, focal=100.0, seed=31, kernel_size=0.1)
+    views = [S.pose_scene(base, 40 + v, spread=0.0) if v else base for v in range(world)]   # (same cloud, camera v; spread 0: all in view)
+    # pose_scene moves cloud AND camera together; a replica needs ONE cloud seen by different cameras: keep view 0's Gaussians,
+    # take view v's camera
+    def view(v):
+        sc = dict(views[0])
+        for k in ("viewmatrix", "projmatrix", "campos"):
+            sc[k] = views[v][k]
+        return sc
+
+    def grads_of(v):
+        e = E.EmuScene(view(v))
+        color, radii = e.forward()
+        dL = np.random.default_rng(7 + v).normal(size=color.shape).astype(np.float32)     # stands for d loss / d image of view v
+        g = e.backward(dL)
+        return g, radii
+
+    mine = shard_views(list(range(world)), rank, world)
+    assert mine == [rank]
+    g, radii = grads_of(rank)
+    names = ["means3D", "sh", "opacity", "scales", "rotations"]
+    params = [torch.zeros(g[n].shape).requires_grad_(True) for n in names]
+    for p, n in zip(params, names):
+        p.grad = torch.from_numpy(g[n].copy())
+    GradientAllReducer(params).all_reduce()
+    # densification statistics of the step (train.py:255-264): visibility counts SUM, screen radii MAX
+    denom = torch.from_numpy((radii > 0).astype(np.float32)).reshape(-1, 1)
+    accum = torch.from_numpy(np.linalg.norm(g["means2D"][:, :2], axis=1, keepdims=True).astype(np.float32)) * denom
+    accum_abs = accum.clone()
+    max_r = torch.from_numpy(radii.astype(np.float32))
+    all_reduce_densification_stats(accum, accum_abs, denom, max_r)
+    # what ONE process gets from all the views
+    ok = True
+    tot = {n: np.zeros_like(g[n]) for n in names}; den = np.zeros((len(radii), 1), np.float32); mr = np.zeros(len(radii), np.float32)
+    acc = np.zeros((len(radii), 1), np.float32)
+    for v in range(world):
+        gv, rv = grads_of(v)
+        for n in names:
+            tot[n] = tot[n] + gv[n]
+        d = (rv > 0).astype(np.float32).reshape(-1, 1)
+        den += d; mr = np.maximum(mr, rv.astype(np.float32))
+        acc += np.linalg.norm(gv["means2D"][:, :2], axis=1, keepdims=True).astype(np.float32) * d
+    for p, n in zip(params, names):
+        ok = ok and np.array_equal(p.grad.numpy(), tot[n])           # two summands: the all-reduce's sum is the same fp32 addition
+    ok = ok and np.array_equal(denom.numpy(), den) and np.array_equal(max_r.numpy(), mr) and np.array_equal(accum.numpy(), acc)
+    ok = ok and bool(den.max() == world) and bool((tot["means3D"] != 0).any())
+    # replicas stay identical: every rank holds the same reduced gradients (checked through a gather of checksums)
+    chk = torch.tensor([float(np.abs(p.grad.numpy()).sum()) for p in params], dtype=torch.float64)
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_step_with_the_kernels_run_from_source_on_the_host():
+    hip = os.path.join(ROOT, "tests", "hipemu")
+    sys.path.insert(0, hip)
+    import pytest
+    build_emu = pytest.importorskip("build_emu")
+    if not os.path.exists(build_emu.CXX):
+        pytest.skip("no host clang++ to build the emulated library")
+    build_emu.build()                                     # once, before the ranks start
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_emu, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
