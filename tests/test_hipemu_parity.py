@@ -188,3 +188,26 @@ def test_emulated_sync_free_forward_respects_its_capacity():
         f = E.EmuScene(sc)
         rc, count, intact = f.forward_fused(cap)
         assert rc == -5 and count == R and intact, (cap, rc, count, intact)          # GOF_E_CAPACITY, the true count reported
+
+
+def test_emulated_cull_audit_counts_no_dropped_pair():
+    """the instrumented build (-DGOF_STATS -DGOF_CULL_AUDIT: the consumption walks EVERY list entry and counts the pairs the exact
+    path accepts that the footprint-conic scan had not marked) run from source on the host: 0 dropped on the stress scenes, the
+    table's posed scenes and 24 fuzz seeds -- the GPU suite's audit (test_the_cull_scan_drops_no_pair_the_exact_path_accepts)
+    without a GPU, at the sizes the CPU affords"""
+    import ctypes as C
+    lib = E.load(extra_flags=("-DGOF_STATS", "-DGOF_CULL_AUDIT"), tag="audit")
+    out = (C.c_ulonglong * 8)()
+    scenes = [TP.SCENES[k]() for k in ("stress_box", "posed_stress_box", "long_lists", "posed_long_lists", "posed_mod2", "posed_mod05_ks01", "small_ks01", "posed_ragged")]
+    scenes += [TP._fuzz_scene(s) for s in range(24)]
+    scenes.append(S.scene_frustum(40_000, W=320, H=208, focal=240.0, seed=7, sigma_px=0.4, zmin=5.0, zmax=80.0, pose_seed=9))     # far sub-pixel splats
+    total = 0
+    for sc in scenes:
+        lib.gof_debug_fw_stats(out, 1)
+        e = E.EmuScene(sc, lib=lib)
+        e.forward()
+        lib.gof_debug_fw_stats(out, 1)
+        s = list(out)
+        assert s[6] == 0, ("pairs dropped by the cull scan", s[6], s[3])
+        total += s[3]
+    assert total > 2_000_000          # accepted pairs examined
