@@ -116,7 +116,8 @@ static inline void release_block_barrier(Block* b)
 {
     b->res_and[b->bar_gen & 1] = b->acc_and;
     b->res_or[b->bar_gen & 1] = b->acc_or;
-    b->acc_and = 1; b->acc_or = 0;
+    b->res_count[b->bar_gen & 1] = b->acc_count;
+    b->acc_and = 1; b->acc_or = 0; b->acc_count = 0;
     b->bar_arrived = 0;
     b->bar_gen++;
     b->spin = 0;
@@ -152,6 +153,15 @@ static inline void release_group(Wave& w, Scope scope, unsigned lane, Block* b)
     s.parity[g] = parity ^ 1;
     s.gen[g]++;
     b->spin = 0;
+}
+
+void block_barrier_count(int pred, int* r_count)
+{
+    Block* b = t_block;
+    const unsigned gen = b->bar_gen;
+    b->acc_count += (pred != 0);
+    block_barrier(1, nullptr, nullptr);
+    *r_count = b->res_count[gen & 1];
 }
 
 void block_barrier(int pred, int* r_and, int* r_or)
@@ -245,7 +255,7 @@ static void run_block(const char* name, dim3 grid, dim3 dim, unsigned linear, si
     b.nthreads = dim.x * dim.y * dim.z;
     b.nwaves = (b.nthreads + 63) / 64;
     b.alive = b.nthreads;
-    b.acc_and = 1; b.acc_or = 0;
+    b.acc_and = 1; b.acc_or = 0; b.acc_count = 0;
     b.body = &body;
     b.kernel_name = name;
     std::vector<Fiber> fibers(b.nthreads);

@@ -130,7 +130,7 @@ struct Block {
     dim3 grid, dim, bid;
     unsigned nthreads, nwaves, alive, cur;
     unsigned bar_arrived, bar_gen;
-    int acc_and, acc_or, res_and[2], res_or[2];
+    int acc_and, acc_or, acc_count, res_and[2], res_or[2], res_count[2];
     unsigned spin;
     Fiber* fibers;
     Wave* waves;
@@ -144,6 +144,7 @@ extern thread_local Fiber* t_fiber;
 void launch(const char* name, dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void yield();
 void block_barrier(int pred, int* r_and, int* r_or);
+void block_barrier_count(int pred, int* r_count);
 // every alive lane of the wave deposits `mine`; returns the wave's 64 deposits (valid until the lane's next cross-lane operation)
 // and the mask of lanes that took part
 const uint64_t* wave_exchange(uint64_t mine, uint64_t* active, const char* what, Scope scope = SCOPE_WAVE);
