@@ -31,7 +31,9 @@
  * Python restatements (utils/sh_utils.py eval_sh, scene/gaussian_model.py
  * get_view2gaussian/get_covariance, utils/tetmesh.py) through tests/golden/, (b) operator
  * by operator against the vendored GLM (oracle/check_glm.cpp), and (c) end to end against the
- * reference CUDA sources themselves compiled for gfx950 (oracle/_ref, GPU tests).
+ * reference CUDA sources themselves compiled for gfx950 (oracle/_ref, GPU tests) and (d) against the
+ * same sources compiled for the HOST on top of tests/hipemu (oracle/_ref/libgof_cudaref_host.so,
+ * tests/test_reference_host.py in the CPU suite): K1 floats, keys, sorted list, ranges bit-exact.
  */
 #include <algorithm>
 #include <cmath>
