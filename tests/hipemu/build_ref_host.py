@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/submodules/diff-gaussian-rasterization"
 OUT = os.path.join(ROOT, "oracle", "_ref")
 LIB = os.path.join(OUT, "libgof_cudaref_host.so")
+KNN = "/root/reference/submodules/simple-knn"
+KNN_LIB = os.path.join(OUT, "libgof_knnref_host.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 LAUNCH = re.compile(r"(\b\w+(?:\s*<[^<>;(){}]*>)?)\s*<<\s*<(.*?)>>\s*>\s*\(", re.S)
@@ -100,5 +102,36 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_knn(force=False):
+    """the reference's simple-knn (submodules/simple-knn/simple_knn.cu: Morton sort + 1024-point boxes + exact 3-NN), same treatment,
+    behind oracle/ref_knn_capi.cpp"""
+    if not os.path.isdir(KNN):
+        return None
+    deps = [os.path.join(KNN, "simple_knn.cu"), os.path.join(KNN, "simple_knn.h"), os.path.join(ROOT, "oracle", "ref_knn_capi.cpp"),
+            os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "hipemu_rt.cpp"), __file__]
+    for d, _, fs in os.walk(os.path.join(HERE, "ref_shim_host")):
+        deps += [os.path.join(d, f) for f in fs]
+    if not force and os.path.exists(KNN_LIB) and all(os.path.getmtime(KNN_LIB) >= os.path.getmtime(d) for d in deps):
+        return KNN_LIB
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="tmp_host.", dir=OUT)
+    try:
+        inc = ["-I", os.path.join(HERE, "ref_shim_host"), "-I", os.path.join(HERE, "include"), "-I", KNN]
+        flags = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-w", "-ffp-contract=off", "-mfma", "-mavx2", "-fno-strict-aliasing", "-pthread",
+                 "-Wno-c++11-narrowing", "-include", "cfloat"]
+        src = os.path.join(tmp, "simple_knn.cu.cpp")
+        open(src, "w").write(_launches_to_calls(open(os.path.join(KNN, "simple_knn.cu")).read()))
+        objs = []
+        for name, path in (("knn", src), ("capi", os.path.join(ROOT, "oracle", "ref_knn_capi.cpp")), ("rt", os.path.join(HERE, "hipemu_rt.cpp"))):
+            obj = os.path.join(tmp, name + ".o")
+            subprocess.check_call([CXX] + flags + inc + ["-c", path, "-o", obj])
+            objs.append(obj)
+        subprocess.check_call([CXX, "-shared", "-pthread", "-o", KNN_LIB] + objs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return KNN_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_knn(force="--force" in sys.argv))

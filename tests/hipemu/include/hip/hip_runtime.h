@@ -94,6 +94,7 @@ inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 template <class T> inline hipError_t hipHostGetDevicePointer(T** d, void* h, unsigned f) { return hipHostGetDevicePointer((void**)d, h, f); }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemuEvent; return hipSuccess; }

@@ -17,6 +17,17 @@ struct DeviceScan {
         return cudaSuccess;
     }
 };
+struct DeviceReduce {
+    template <class In, class Out, class Op, class T>
+    static cudaError_t Reduce(void* tmp, size_t& bytes, In in, Out out, int n, Op op, T init)
+    {
+        if (!tmp) { bytes = 16; return cudaSuccess; }
+        T acc = init;
+        for (int i = 0; i < n; i++) acc = op(acc, in[i]);
+        *out = acc;
+        return cudaSuccess;
+    }
+};
 struct DeviceRadixSort {
     template <class K, class V>
     static cudaError_t SortPairs(void* tmp, size_t& bytes, const K* kin, K* kout, const V* vin, V* vout, int n, int begin_bit = 0, int end_bit = (int)sizeof(K) * 8)

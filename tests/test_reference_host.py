@@ -117,3 +117,34 @@ def test_the_kernels_source_run_on_the_host_against_the_references_kernels_run_o
     assert np.array_equal(e.fetch("point_list").view(np.uint32), ref.fetch("point_list"))
     assert np.array_equal(e.fetch("ranges").view(np.uint32), ref.fetch("ranges"))
     assert np.abs(pc - rc).max() <= 2e-5 * max(1.0, np.abs(rc).max())
+
+
+@pytest.mark.parametrize("n,kind", [(4, "uniform"), (255, "uniform"), (5000, "uniform"), (6000, "clustered"), (3000, "line"), (4000, "duplicates")])
+def test_knn_oracle_and_emulated_kernel_pinned_to_the_references_simple_knn_run_on_the_host(n, kind):
+    """simple_knn.cu (Morton sort + 1024-point boxes + exact 3-NN) compiled for the host the same way: the numpy oracle
+    (oracle/knn_oracle.py) and the product's knn kernel run from source (tests/hipemu) both give its values bit for bit"""
+    import ctypes as C
+    import test_knn
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import knn_oracle as KO
+    lib_path = build_ref_host.build_knn()
+    if lib_path is None:
+        pytest.skip("no /root/reference/submodules/simple-knn here")
+    L = C.CDLL(lib_path)
+    L.knnref_mean_dist3.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    pts = np.ascontiguousarray(test_knn._cloud(n, 7 + n, kind), np.float32)
+    ref = np.zeros(n, np.float32)
+    assert L.knnref_mean_dist3(n, C.c_void_p(pts.ctypes.data), C.c_void_p(ref.ctypes.data)) == 0
+    want = KO.mean_dist3(pts)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(ref), fin) and np.array_equal(ref[fin], want[fin])
+    build_emu = pytest.importorskip("build_emu")
+    import emu_binding as E
+    lib = E.load()
+    lib.gof_knn_ws_bytes.restype = C.c_size_t; lib.gof_knn_ws_bytes.argtypes = [C.c_int64]
+    lib.gof_knn_mean_dist3.restype = C.c_int
+    lib.gof_knn_mean_dist3.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    got = np.zeros(n, np.float32)
+    nb = lib.gof_knn_ws_bytes(n); ws = E._aligned(nb)
+    assert lib.gof_knn_mean_dist3(n, E._p(pts), E._p(got), E._p(ws), nb, None) == 0
+    assert np.array_equal(got[fin], ref[fin])
