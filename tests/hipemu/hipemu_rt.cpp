@@ -79,10 +79,10 @@ static void release_slab(Slab s)
     std::fprintf(stderr, "hipemu: DEADLOCK in kernel %s, workgroup (%u,%u,%u): %u fibers alive, barrier has %u\n", b->kernel_name, b->bid.x, b->bid.y,
                  b->bid.z, b->alive, b->bar_arrived);
     unsigned shown = 0;
-    for (unsigned i = 0; i < b->nthreads && shown < 24; i++) {
+    for (unsigned i = 0; i < b->nthreads && shown < (std::getenv("HIPEMU_VERBOSE") ? 1024u : 24u); i++) {
         const Fiber& f = b->fibers[i];
         if (f.done) continue;
-        if (i > 0 && !b->fibers[i - 1].done && b->fibers[i - 1].wait_what == f.wait_what && i + 1 < b->nthreads) continue;
+        if (!std::getenv("HIPEMU_VERBOSE") && i > 0 && !b->fibers[i - 1].done && b->fibers[i - 1].wait_what == f.wait_what && i + 1 < b->nthreads) continue;
         std::fprintf(stderr, "  thread %u (wave %u lane %u) waits at: %s\n", i, f.wave, f.lane, f.wait_what ? f.wait_what : "(running)");
         shown++;
     }
@@ -99,14 +99,51 @@ static inline void switch_to(Block* b, unsigned next)
     hipemu_switch(&me->sp, to->sp);
 }
 
+// HIPEMU_ORDER: which runnable fiber goes next when one blocks.  The hardware fixes no order between the waves of a workgroup, and
+// within a wave it executes every lane of an instruction together, so between two synchronisation points no result may depend on
+// the order the emulator happens to run lanes in.  "forward" (default) visits fibers in ascending order, "reverse" in descending
+// order, "random:<seed>" picks pseudo-randomly: a parity test that passes under one order and fails under another has found either
+// a missing barrier between waves or an unlisted lock-step point (build_emu.py: LOCKSTEP_POINTS) inside one.
+static int order_mode(unsigned* seed)
+{
+    static int mode = -1; static unsigned s0 = 1;
+    if (mode < 0) {
+        const char* e = std::getenv("HIPEMU_ORDER");
+        mode = 0;
+        if (e && std::strcmp(e, "reverse") == 0) mode = 1;
+        else if (e && std::strncmp(e, "random", 6) == 0) { mode = 2; s0 = e[6] == ':' ? (unsigned)std::atoi(e + 7) * 2654435761u + 1u : 12345u; }
+    }
+    *seed = s0;
+    return mode;
+}
+
 void yield()
 {
     Block* b = t_block;
-    if (++b->spin > 8u * b->nthreads + 64u) deadlock(b);
+    unsigned seed;
+    const int mode = order_mode(&seed);
+    // (a fiber that waits is re-run only to look at its gate again; the bound is on such looks without anybody arriving anywhere --
+    // generous under the random order, where the one fiber that can make progress is drawn with probability 1 / #alive)
+    if (++b->spin > (mode == 2 ? 256u : 8u) * b->nthreads + 64u) deadlock(b);
     unsigned n = b->cur;
-    for (unsigned k = 0; k < b->nthreads; k++) {
-        n = (n + 1 == b->nthreads) ? 0 : n + 1;
-        if (!b->fibers[n].done) break;
+    if (mode == 2) {
+        // a few uniform draws for a runnable fiber, then the first runnable one in ascending order from the last draw
+        for (int tries = 0; tries < 8; tries++) {
+            b->rng = b->rng * 1664525u + 1013904223u + seed;
+            n = (b->rng >> 8) % b->nthreads;
+            if (!b->fibers[n].done && n != b->cur) break;
+        }
+        for (unsigned k = 0; k < b->nthreads; k++) {
+            if (!b->fibers[n].done && n != b->cur) break;
+            n = (n + 1 == b->nthreads) ? 0 : n + 1;
+        }
+        if (b->fibers[n].done) return;
+    } else {
+        for (unsigned k = 0; k < b->nthreads; k++) {
+            if (mode == 1) n = (n == 0) ? b->nthreads - 1 : n - 1;
+            else n = (n + 1 == b->nthreads) ? 0 : n + 1;
+            if (!b->fibers[n].done) break;
+        }
     }
     if (n == b->cur) return;
     switch_to(b, n);

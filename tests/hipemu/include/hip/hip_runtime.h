@@ -132,7 +132,7 @@ struct Block {
     unsigned nthreads, nwaves, alive, cur;
     unsigned bar_arrived, bar_gen;
     int acc_and, acc_or, acc_count, res_and[2], res_or[2], res_count[2];
-    unsigned spin;
+    unsigned spin, rng;
     Fiber* fibers;
     Wave* waves;
     void* dyn_lds;

@@ -211,3 +211,18 @@ def test_emulated_cull_audit_counts_no_dropped_pair():
         assert s[6] == 0, ("pairs dropped by the cull scan", s[6], s[3])
         total += s[3]
     assert total > 2_000_000          # accepted pairs examined
+
+
+@pytest.mark.parametrize("order", ["reverse", "random:7"])
+def test_results_do_not_depend_on_the_order_the_emulator_runs_fibers_in(order):
+    """The hardware fixes no order between the waves of a workgroup and runs all lanes of an instruction together, so between two
+    synchronisation points no result may depend on the order the emulator happens to run fibers in (ascending by default).  The
+    same parity tests under a descending and a pseudo-random order (HIPEMU_ORDER, read once per process: a subprocess): a failure
+    here is a missing barrier between waves or an unlisted lock-step point inside one (build_emu.py: LOCKSTEP_POINTS)."""
+    import subprocess
+    sel = "posed_small_ks01 or posed_stress_box or posed_long_lists or posed_mod2 or small_ks0 or precomputed or fuzz_forward_integrate_backward"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "(%s) and not order" % sel, "-p", "no:cacheprovider"],
+                       env=dict(os.environ, HIPEMU_ORDER=order), capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
