@@ -1,0 +1,54 @@
+"""BASELINE's headline configuration (S1M: 1M Gaussians @ 1600x1063, SH degree 3) through the kernels' SOURCE run on the host
+(tests/hipemu) against the oracle -- the full-size parity check of tests/test_parity_gpu.py::test_full_size_s1m_* without a GPU.
+Minutes on 8 cores; writes gpurun_out/r03_hipemu_full_size.json (copied to profiles/ by hand).
+    python tests/devtools/dev_hipemu_full_size.py [s1m] [s1m_posed] [s1m_clustered]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hipemu"), os.path.join(ROOT, "gaussian-opacity-fields_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import emu_binding as E  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+import synthetic_scenes as S  # noqa: E402
+import test_parity_gpu as TP  # noqa: E402
+from gpu_common import bits  # noqa: E402
+
+SCENES = {"s1m": lambda: S.scene_frustum(1_000_000, seed=0), "s1m_posed": lambda: S.scene_frustum(1_000_000, seed=0, pose_seed=0),
+          "s1m_clustered": lambda: S.scene_clustered(1_000_000, seed=0)}
+
+if __name__ == "__main__":
+    rep = {}
+    for name in (sys.argv[1:] or ["s1m"]):
+        sc = SCENES[name]()
+        t = time.time(); o = ob.OracleScene(sc); oc, orad = o.forward(); t_of = time.time() - t
+        e = E.EmuScene(sc)
+        t = time.time(); pc, prad = e.forward(); t_ef = time.time() - t
+        P = len(orad); vis = orad > 0
+        r = {"P": P, "W": sc["W"], "H": sc["H"], "R": e.R, "R_equal": e.R == o.num_rendered(), "radii_equal": bool(np.array_equal(prad, orad)),
+             "seconds": {"oracle_forward": round(t_of, 1), "emulated_forward": round(t_ef, 1)}}
+        for arr in TP.K1_ARRAYS:
+            a = e.fetch(arr).reshape(P, -1)[vis]; b = o.fetch(arr).reshape(P, -1)[vis]
+            r["K1_%s_bit_equal" % arr] = bool(TP._same(a, b))
+        for arr in TP.INT_ARRAYS:
+            r["%s_bit_equal" % arr] = bool(TP._same(e.fetch(arr), o.fetch(arr)))
+        r["final_T_bit_equal"] = bool(np.array_equal(bits(e.fetch("final_T")), bits(o.fetch("final_T"))))
+        ex = TP.EXACT_CH
+        r["image_ch_0_1_2_6_7_8_bit_equal"] = bool(np.array_equal(bits(pc[ex]), bits(oc[ex])))
+        r["normals_max_abs"] = float(np.abs(pc[3:6] - oc[3:6]).max())
+        dL = np.random.default_rng(17).normal(size=oc.shape).astype(np.float32)
+        t = time.time(); go = o.backward(dL); t_ob = time.time() - t
+        t = time.time(); gp = e.backward(dL); t_eb = time.time() - t
+        r["seconds"].update(oracle_backward=round(t_ob, 1), emulated_backward=round(t_eb, 1))
+        r["blend_backward_max_norm_error"] = {k: float(np.abs(gp[k].reshape(go[k].shape) - go[k]).max() / (np.abs(go[k]).max() + 1e-30)) for k in ("means2D", "colors", "opacity", "view2gaussian")}
+        iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
+        r["K9_on_identical_inputs_max_norm_error"] = {k: float(np.abs(gp[k].reshape(iso[k].shape) - iso[k]).max() / (np.abs(iso[k]).max() + 1e-30)) for k in ("means3D", "sh", "scales", "rotations")}
+        r["guards_intact"] = E.guards_intact() == []
+        rep[name] = r
+        print(name, json.dumps(r), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r03_hipemu_full_size.json"), "w") as f:
+        json.dump({"tool": "tests/devtools/dev_hipemu_full_size.py", "what": "csrc/*.hip compiled for the host (tests/hipemu) vs the oracle at BASELINE's full size, no GPU", "scenes": rep}, f, indent=1)
