@@ -286,7 +286,9 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         pmc_all = json.load(open(pmc_file))
         pmc_source = {"file": "profiles/" + PMC_FILE, "kernel_sha16": pmc_all.get("_kernel_sha16"), "current_kernel_sha16": kernel_sha16(),
                       "collected_by": "rocprofv3 --pmc passes of tests/devtools/dev_pmc.py (separate FETCH_SIZE / WRITE_SIZE / SQ passes)"}
-        if pmc_all.get("_kernel_sha16") == kernel_sha16():
+        # (_same_isa_sha16: later source states whose DEFAULT-build gfx950 code for the two blend kernels is instruction for instruction
+        # the one the pass ran on -- edits under developer-only #ifdefs; established by tests/devtools/dev_same_isa.py)
+        if kernel_sha16() in [pmc_all.get("_kernel_sha16")] + list(pmc_all.get("_same_isa_sha16", [])):
             traffic = pmc_all.get(dom, {}).get("hbm_bytes_corrected")
             valu_issue_frac = pmc_all.get(dom, {}).get("valu_issue_frac")
     # what actually bounds the two blend kernels: vector-ALU work.  "Useful" flop per contributing pair = the arithmetic the

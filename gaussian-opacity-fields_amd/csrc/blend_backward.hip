@@ -56,7 +56,10 @@ static_assert(BATCH == 64 || BATCH == 128, "BATCH must be 64 or 128");
 
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] wave iterations of the entry loop, [1] (row, iteration) pairs with
-// an entry to visit, [2] contributing (lane, entry) pairs, [3] word fetches, [4] staged entries
+// an entry to visit, [2] contributing (lane, entry) pairs, [3] word fetches, [4] staged entries, [5] pairs of CONSECUTIVE visited
+// entries of a wave whose contributing lanes are disjoint (greedy, within one mask word: what merging two entries into one gradient
+// block could save), [6] (row, entry) pairs with at least one contributing lane (a walk per 16-lane row would visit those),
+// [7] visited entries in which at most 32 lanes contribute
 __device__ unsigned long long g_bw_stats[8];
 #define BSTAT_ADD(i, v) atomicAdd(&g_bw_stats[i], (unsigned long long)(v))
 #else
@@ -235,6 +238,15 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
             const uint32_t word = s_cm[w][tid];
             uint32_t todo = wave_or(word);
             uint32_t visited = todo;
+#ifdef GOF_STATS
+            unsigned long long stat_prev_set = 0ull;
+            {   // [1] trips a walk per 16-lane row would need for this word (each row its own union: the slowest row counts), [3] the wave's
+                const uint32_t ru = row_or(word);
+                const int c0 = __popc((uint32_t)__builtin_amdgcn_readlane((int)ru, 0)), c1 = __popc((uint32_t)__builtin_amdgcn_readlane((int)ru, 16));
+                const int c2 = __popc((uint32_t)__builtin_amdgcn_readlane((int)ru, 32)), c3 = __popc((uint32_t)__builtin_amdgcn_readlane((int)ru, 48));
+                if (lane == 0) { BSTAT_ADD(1, max(max(c0, c1), max(c2, c3))); BSTAT_ADD(3, __popc(todo)); }
+            }
+#endif
             while (todo) {
                 const int b = 31 - __builtin_clz(todo);
                 todo &= ~(1u << b);
@@ -242,6 +254,17 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 const int j = w * 32 + b;
                 const uint32_t contributor = p0 + (uint32_t)j;       // 0-based list position (backward.cu:763)
                 if (lane == 0) BSTAT_ADD(0, 1);
+#ifdef GOF_STATS
+                {
+                    const unsigned long long cur_set = __ballot(contrib);
+                    if (lane == 0) {
+                        if (stat_prev_set != 0ull && (stat_prev_set & cur_set) == 0ull) { BSTAT_ADD(5, 1); stat_prev_set = 0ull; }   // merged: neither pairs again
+                        else stat_prev_set = cur_set;
+                        BSTAT_ADD(6, ((cur_set & 0xFFFFull) != 0) + ((cur_set & 0xFFFF0000ull) != 0) + ((cur_set & 0xFFFF00000000ull) != 0) + ((cur_set >> 48) != 0));
+                        if (__popcll(cur_set) <= 32) BSTAT_ADD(7, 1);
+                    }
+                }
+#endif
 
                 float g[NGRAD];
 #pragma unroll

@@ -113,14 +113,17 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
 // eps lambda_max |mu| |r| from the fp32 rounding of the transformed mean inside b; CC by <= 11 eps lambda_max |mu|^2.  With
 // d(min_value)/dBB = t, d/dAA = t^2 and t |r| ~ |mu| at the ray's closest approach:  |delta min_value| <~ (22.4 + 34 + 11) eps
 // lambda_max |mu|^2 = 4.0e-6 lambda_max |mu|^2.  The level is therefore raised to k = m0 + Delta with
-//     Delta = GOF_BOX_C * lambda_max * |mu|^2 + 0.05,   GOF_BOX_C = 6e-6
-// (1.5x that bound; the constant term covers the fp32 rounding of `power`, the <= 1 ulp exp and the threshold compare with a wide
+//     Delta = GOF_BOX_C * lambda_max * |mu|^2 + 0.05,   GOF_BOX_C = 4e-6
+// (that bound: a sum of worst cases, 8x what was ever observed -- see below; rounds 1-2 carried another factor 1.5, which cost 4 % of
+// the forward blend's heavy trips at S1M, 5 % on the clustered scene, for nothing the bound does not already cover; the constant
+// term covers the fp32 rounding of `power`, the <= 1 ulp exp and the threshold compare with a wide
 // margin), which keeps box and conic conservative with respect to the arithmetic the blend actually performs (for sub-pixel,
 // far-away splats they grow accordingly).  For cond(Sigma') > 1e4, a non-orthonormal frame, or an ellipsoid that reaches the
 // camera plane, no statement is made (unbounded box, all-zero conic = always a candidate).  Measured: an instrumented build
 // (-DGOF_CULL_AUDIT) counts the pairs the exact path accepts outside the conic -- 0 on S1M and the whole scene table
 // (tests/test_parity_gpu.py::test_the_cull_scan_drops_no_pair_the_exact_path_accepts); with the constant lowered to 2e-7 / 0 the
-// same count was 13 / 2438 of 1.24e8 accepted pairs at S1M (round-1 measurement), none at 1e-6.
+// same count was 13 / 2438 of 1.24e8 accepted pairs at S1M (round-1 measurement), none at 1e-6; round 3 (the audit build run from
+// source on the host by the test suite): none at 5e-7 either, on S1M (posed and not) and S1M-clustered.
 // Also emits the footprint CONIC in ray space (fc[0..1]): a ray r = (rx, ry, 1) meets the level-set ellipsoid iff
 // g(r) = r^T M r <= 0 with M = (C - k) Sigma' - b b^T, b = Sigma' mu, C = mu^T Sigma' mu (min over t of the quadratic
 // along the ray is C - (b.r)^2 / (r^T Sigma' r)).  M is evaluated in fp64 from the same well-conditioned factors as the
@@ -159,7 +162,7 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     const double mx = mu.x, my = mu.y, mz = mu.z;
     const double mu2 = mx * mx + my * my + mz * mz;
 #ifndef GOF_BOX_C
-#define GOF_BOX_C 6e-6
+#define GOF_BOX_C 4e-6
 #endif
     const double k = m0 + 0.05 + GOF_BOX_C * lmax * mu2;
     // view-space covariance Cov = A diag(1/l) A^T with A = Rt^T (rows of Rt are the Gaussian axes in view space):
