@@ -28,13 +28,25 @@ FLOP_PER_PAIR_FWD = 85       # forward.cu:504-575 per contributing pair (DESIGN.
 FLOP_PER_PAIR_BWD = 190      # backward.cu:771-952 per contributing pair, incl. its 19 accumulating adds
 
 
-def kernel_sha16():
-    """Hash of the sources of the two blend kernels (+ the shared header): identifies what a committed PMC pass was collected on."""
+def kernel_sha16(kernel=None):
+    """Hash of the sources of the two blend kernels (+ the shared header) -- or, with `kernel`, of that kernel's file + the header:
+    identifies what a committed PMC pass was collected on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("blend_forward.hip", "blend_backward.hip", "gof_common.h"):
+    files = ("blend_forward.hip", "blend_backward.hip", "gof_common.h") if kernel is None else (kernel + ".hip", "gof_common.h")
+    for f in files:
         h.update(open(os.path.join(ROOT, "gaussian-opacity-fields_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def pmc_pass_is_current(pmc_all, kernel):
+    """Was the committed counter pass collected on the code `kernel` has now?  Either the recorded source hash of that kernel's file
+    (+ header) is the current one, or the current one is listed as a later source state with the SAME default-build gfx950 code
+    (edits under developer-only #ifdefs; established by tests/devtools/dev_same_isa.py)."""
+    if kernel_sha16() in [pmc_all.get("_kernel_sha16")] + list(pmc_all.get("_same_isa_sha16", [])):
+        return True
+    cur = kernel_sha16(kernel)
+    return cur in [pmc_all.get("_sha16_by_kernel", {}).get(kernel)] + list(pmc_all.get("_same_isa_sha16_by_kernel", {}).get(kernel, []))
 
 
 def parse():
@@ -286,9 +298,8 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         pmc_all = json.load(open(pmc_file))
         pmc_source = {"file": "profiles/" + PMC_FILE, "kernel_sha16": pmc_all.get("_kernel_sha16"), "current_kernel_sha16": kernel_sha16(),
                       "collected_by": "rocprofv3 --pmc passes of tests/devtools/dev_pmc.py (separate FETCH_SIZE / WRITE_SIZE / SQ passes)"}
-        # (_same_isa_sha16: later source states whose DEFAULT-build gfx950 code for the two blend kernels is instruction for instruction
-        # the one the pass ran on -- edits under developer-only #ifdefs; established by tests/devtools/dev_same_isa.py)
-        if kernel_sha16() in [pmc_all.get("_kernel_sha16")] + list(pmc_all.get("_same_isa_sha16", [])):
+        pmc_source["current_sha16_of_the_dominant_kernel"] = kernel_sha16(dom)
+        if pmc_pass_is_current(pmc_all, dom):
             traffic = pmc_all.get(dom, {}).get("hbm_bytes_corrected")
             valu_issue_frac = pmc_all.get(dom, {}).get("valu_issue_frac")
     # what actually bounds the two blend kernels: vector-ALU work.  "Useful" flop per contributing pair = the arithmetic the

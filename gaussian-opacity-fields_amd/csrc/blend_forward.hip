@@ -108,10 +108,16 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
     // footprint conic, SoA: s_cf[c][entry], c = {m00, 2 m01, m11, 2 m02, 2 m12, m22}; read as float4 = one coefficient of 4 entries
     __shared__ f4 s_cf[6][TILE_PIX / 4];
     uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
-    // evaluation-error margin of the unit-normalised conic (sum |M_ij| = 1): 5 fp32 roundings of partial sums bounded by
-    // max(1, |r|^2), plus the fp32 rounding of the coefficients -> 3e-6 x that bound is > 4x what can occur
+    // evaluation-error margin of the unit-normalised conic (sum |M_ij| = 1, the doubled off-diagonal coefficients counted doubled):
+    // the Horner form below is five FMAs and one add, each rounding a partial sum bounded by B = max(1, rx^2, ry^2) -- 6 eps B,
+    // eps = 2^-24 -- plus the fp32 rounding of the six coefficients, <= eps B together: 7 eps B = 4.2e-7 B (the ray is the fp32 ray
+    // the exact path uses: no error there).  1e-6 B is 2.4x that.  (Rounds 1-2 carried 3e-6: in min_value units the margin is worth
+    // ~ margin x lambda |mu|^2, i.e. as much as the allowance of the level itself at S1M -- 5 % of the heavy trips.)
     const f2 RX = { rx, rx }, RY = { ry, ry }, RXY = { rx, ry };
-    const float cone_margin = 3e-6f * fmaxf(1.0f, fmaxf(rx * rx, ry * ry));
+#ifndef GOF_CONE_MARGIN
+#define GOF_CONE_MARGIN 1e-6f
+#endif
+    const float cone_margin = GOF_CONE_MARGIN * fmaxf(1.0f, fmaxf(rx * rx, ry * ry));
     const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
 
     bool done = !inside;

@@ -30,6 +30,7 @@ def asm_of(path_in_csrc):
 def main():
     rev = sys.argv[1]
     same = True
+    same_by = {}
     for f in FILES:
         cur = asm_of(os.path.join(CSRC, f))
         tmp = os.path.join(CSRC, "_same_isa_tmp_" + f)          # (inside csrc so that the relative includes resolve; headers: working tree)
@@ -41,18 +42,21 @@ def main():
                 os.remove(tmp)
         ok = cur == old
         same &= ok
+        same_by[f[:-4]] = ok
         print("%-22s %s (%d lines of device assembly)" % (f, "identical" if ok else "DIFFERENT", len(cur)))
     hdr = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", rev, "--", "gaussian-opacity-fields_amd/csrc/gof_common.h"]).returncode == 0
     print("gof_common.h           %s since %s" % ("unchanged" if hdr else "CHANGED (the comparison above used the working tree's header for both states)", rev))
-    if same and hdr and "--record" in sys.argv:
+    if hdr and "--record" in sys.argv:
         import bench
         f = os.path.join(ROOT, "profiles", bench.PMC_FILE)
         d = json.load(open(f))
-        cur = bench.kernel_sha16()
-        if cur != d["_kernel_sha16"] and cur not in d.get("_same_isa_sha16", []):
-            d.setdefault("_same_isa_sha16", []).append(cur)
-            json.dump(d, open(f, "w"), indent=1)
-            print("recorded", cur, "in", f)
+        for k, ok in same_by.items():            # per kernel: the bench line quotes the dominant kernel's counters only
+            cur = bench.kernel_sha16(k)
+            known = [d.get("_sha16_by_kernel", {}).get(k)] + d.get("_same_isa_sha16_by_kernel", {}).get(k, [])
+            if ok and cur not in known:
+                d.setdefault("_same_isa_sha16_by_kernel", {}).setdefault(k, []).append(cur)
+                print("recorded", k, cur, "in", f)
+        json.dump(d, open(f, "w"), indent=1)
     sys.exit(0 if (same and hdr) else 1)
 
 
