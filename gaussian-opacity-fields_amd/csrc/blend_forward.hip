@@ -52,7 +52,7 @@ constexpr int FW_CHUNK = GOF_FW_CHUNK;
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] scanned wave-entries, [1] candidate
 // (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active,
-// [6] (GOF_CULL_AUDIT) pairs the exact path accepts that the cull scan had dropped
+// [6] (GOF_CULL_AUDIT) pairs the exact path accepts that the cull scan had dropped, [7] scanned wave-entries with a candidate in the wave
 __device__ unsigned long long g_fw_stats[8];
 #define STAT_ADD(i, v) atomicAdd(&g_fw_stats[i], (unsigned long long)(v))
 #else
@@ -197,6 +197,13 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
             s_mask[w][tid] = word;
             if ((tid & 63) == 0) STAT_ADD(0, min(32, valid));
             STAT_ADD(1, __popc(word));
+#ifdef GOF_STATS
+            {   // [7] scanned (wave, entry) pairs in which at least one pixel of the wave is a candidate
+                uint32_t any = 0;
+                for (int bq = 0; bq < 32; bq++) any |= (__ballot((word >> bq) & 1u) != 0ull) ? (1u << bq) : 0u;
+                if ((tid & 63) == 0) STAT_ADD(7, __popc(any));
+            }
+#endif
         }
 
         // ---- phase 2: every lane consumes its own candidates in list order ----
