@@ -36,6 +36,17 @@
 
 namespace gof {
 
+#ifdef GOF_STATS
+// developer-only instrumentation (never in the shipped build) of the opacity-field query's POINT pass: [0] (point, entry) pairs walked
+// (set bits of the pixel's contributor mask), [1] skipped by the front-depth test, [2] evaluated, [3] accepted (alpha >= 1/255),
+// [4] wave trips of the bit loop, [5] lane-trips with a bit to process; PIXEL pass: [6] candidates popped, [7] of them used by a sub-ray
+__device__ unsigned long long g_int_stats[8];
+#define ISTAT_ADD(i, v) atomicAdd(&g_int_stats[i], (unsigned long long)(v))
+#else
+#define ISTAT_ADD(i, v)
+#endif
+
+
 __global__ void __launch_bounds__(256)
 integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
                  const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
@@ -355,14 +366,22 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
             int w = 0;
             uint32_t mask = s_used[0][lp];
             while (true) {
+#ifdef GOF_STATS
+                const unsigned long long with_bits = __ballot(mask != 0u);
+                if (with_bits == 0ull) { if (++w >= 8) break; mask = s_used[w][lp]; continue; }
+                if ((tid & 63u) == (uint32_t)__builtin_ctzll(with_bits)) ISTAT_ADD(4, 1);
+#else
                 if (__ballot(mask != 0u) == 0ull) { if (++w >= 8) break; mask = s_used[w][lp]; continue; }
+#endif
                 if (mask == 0u) continue;
+                ISTAT_ADD(5, 1); ISTAT_ADD(0, 1);
                 const int bit = __ffs((int)mask) - 1;
                 mask &= mask - 1;
                 const int j = w * 32 + bit;
                 // the query point lies in front of everything this Gaussian can reach with alpha >= 1/255 (t is clamped
                 // to the point's depth below): certainly skipped by the alpha test
-                if (ray_depth < s_zfront[j]) continue;
+                if (ray_depth < s_zfront[j]) { ISTAT_ADD(1, 1); continue; }
+                ISTAT_ADD(2, 1);
                 const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
                 const float n0 = a4.x * rx + a4.y * ry + a4.z;
                 const float n1 = a4.y * rx + a4.w * ry + b4.x;
@@ -375,6 +394,7 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                 const float power = -0.5f * (AA * t * t + BB * t + CC);
                 const float alpha = fminf(0.99f, c4.z * gexpf(power));
                 if (alpha < 1.0f / 255.0f) continue;
+                ISTAT_ADD(3, 1);
                 const float test_T = T * (1 - alpha);
                 acc += alpha * T;
                 T = test_T;
@@ -445,5 +465,15 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
         out_color[8 * HW + pix_id] = (float)total;
     }
 }
+
+#ifdef GOF_STATS
+extern "C" int gof_debug_int_stats(unsigned long long* out8, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_int_stats), sizeof(g_int_stats));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_int_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 } // namespace gof
