@@ -168,6 +168,23 @@ def pose_scene(scene, seed, spread=3.0):
     return out
 
 
+def other_view(scene, k=1, angle=0.06, shift=0.12):
+    """The SAME Gaussians seen by another camera: view k of a small orbit around the scene's own camera (camera-to-world rotation by
+    k * angle about the y axis composed with the scene's, centre moved by k * shift along the camera's x and -y axes) -- what a
+    data-parallel step renders on rank k.  Only viewmatrix / projmatrix / campos change; most of the cloud stays in view."""
+    V = scene["viewmatrix"].astype(np.float64)               # world-to-view, transposed (row-vector convention)
+    R0 = V[:3, :3]                                           # = camera-to-world rotation (view_t[:3,:3] = R)
+    c0 = np.linalg.inv(V)[3, :3]
+    a = k * angle
+    Ry = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+    R = R0 @ Ry
+    c = c0 + R0 @ np.array([k * shift, -0.5 * k * shift, 0.0])
+    out = {key: (v.copy() if isinstance(v, np.ndarray) else v) for key, v in scene.items()}
+    fovx, fovy = 2 * math.atan(scene["tanfovx"]), 2 * math.atan(scene["tanfovy"])
+    out.update(camera(scene["W"], scene["H"], fovx, fovy, R=R, T=-R.T @ c))
+    return out
+
+
 def scene_lego_like(P=10_000, W=400, H=400, seed=0, sh_degree=3, bg=(1.0, 1.0, 1.0), kernel_size=0.0):
     rng = np.random.default_rng(seed)
     fovx = 0.6911112070083618

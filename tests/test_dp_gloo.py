@@ -355,14 +355,8 @@ def _worker_emu(rank, world, port, ret):
     from dp import GradientAllReducer, shard_views
     from dp.reducer import all_reduce_densification_stats
     base = S.scene_frustum(2500, W=128, H=96, focal=100.0, seed=31, kernel_size=0.1)
-    views = [S.pose_scene(base, 40 + v, spread=0.0) if v else base for v in range(world)]   # (same cloud, camera v; spread 0: all in view)
-    # pose_scene moves cloud AND camera together; a replica needs ONE cloud seen by different cameras: keep view 0's Gaussians,
-    # take view v's camera
-    def view(v):
-        sc = dict(views[0])
-        for k in ("viewmatrix", "projmatrix", "campos"):
-            sc[k] = views[v][k]
-        return sc
+    def view(v):                       # one cloud (the replica), camera v of a small orbit
+        return S.other_view(base, v) if v else base
 
     def grads_of(v):
         e = E.EmuScene(view(v))
@@ -399,7 +393,7 @@ def _worker_emu(rank, world, port, ret):
     for p, n in zip(params, names):
         ok = ok and np.array_equal(p.grad.numpy(), tot[n])           # two summands: the all-reduce's sum is the same fp32 addition
     ok = ok and np.array_equal(denom.numpy(), den) and np.array_equal(max_r.numpy(), mr) and np.array_equal(accum.numpy(), acc)
-    ok = ok and bool(den.max() == world) and bool((tot["means3D"] != 0).any())
+    ok = ok and bool(den.max() == world) and all(bool((np.abs(grads_of(v)[0]["means3D"]).max() > 0)) for v in range(world))     # every view sees (and moves) the cloud
     # replicas stay identical: every rank holds the same reduced gradients (checked through a gather of checksums)
     chk = torch.tensor([float(np.abs(p.grad.numpy()).sum()) for p in params], dtype=torch.float64)
     gathered = [torch.zeros_like(chk) for _ in range(world)]

@@ -213,3 +213,93 @@ def test_emulated_marching_tets_match_oracle(n):
     for const in (-1.0, 1.0):
         ids, pos, esdf, esc, faces = _mtets(lib, verts, tets, np.full(len(verts), const, np.float32), scales)
         assert len(ids) == 0 and len(faces) == 0
+
+
+@pytest.fixture()
+def emu_all(emu, monkeypatch):
+    """... and the modules that bind the library handle at import (filter_3d, activations): handle swapped, the signatures the
+    package declared on the product library mirrored onto the emulated one, torch.cuda.device() a no-op."""
+    import importlib
+    A = importlib.import_module("train_epilogue.activations")      # (the package re-exports functions of the same names)
+    F = importlib.import_module("train_epilogue.filter_3d")
+    A, F = sys.modules["train_epilogue.activations"], sys.modules["train_epilogue.filter_3d"]
+    real = F.lib
+    for mod in (F, A):
+        monkeypatch.setattr(mod, "lib", emu)
+    for name in ("gof_filter3d_ws_bytes", "gof_compute_3d_filter", "gof_add_densification_stats", "gof_act_scaling", "gof_act_scaling_backward",
+                 "gof_act_opacity", "gof_act_opacity_backward", "gof_act_rotation", "gof_act_rotation_backward"):
+        f_real, f_emu = getattr(real, name), getattr(emu, name)
+        f_emu.argtypes, f_emu.restype = f_real.argtypes, f_real.restype
+    monkeypatch.setattr(torch.cuda, "device", lambda *a, **k: contextlib.nullcontext())
+    return emu
+
+
+@pytest.mark.parametrize("P,ncam", [(1, 1), (1000, 3), (60_000, 12)])
+def test_emulated_compute_3d_filter_matches_oracle(emu_all, P, ncam):
+    import types
+    import train_epilogue as T
+    rng = np.random.default_rng(P + ncam)
+    xyz = rng.uniform(-2.0, 2.0, (P, 3)).astype(np.float32)
+    if P == 1:
+        xyz[:] = 0.0
+    cams = []
+    for i in range(ncam):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        cams.append(types.SimpleNamespace(R=R, T=np.array([0.0, 0.0, 4.0]) + rng.normal(0, 0.2, 3), focal_x=float(rng.uniform(400, 1300)),
+                                          focal_y=float(rng.uniform(400, 1300)), image_width=int(rng.integers(300, 1700)), image_height=int(rng.integers(300, 1100))))
+    got = T.filter_3d(torch.from_numpy(xyz), T.camera_table(cams, "cpu")).numpy()
+    ref = O.compute_3d_filter(torch.from_numpy(xyz), cams).numpy()
+    got, ref = got.ravel(), ref.ravel()
+    bad = np.abs(got - ref) > 2e-6 * np.abs(ref)           # (a point exactly on a threshold may flip for one camera: tests/test_train_epilogue_gpu.py)
+    assert bad.mean() <= 1e-4, "%d of %d points differ" % (bad.sum(), bad.size)
+    # nothing seen by any camera: fails like the reference (max of an empty tensor)
+    cam = types.SimpleNamespace(R=np.eye(3), T=np.array([0.0, 0.0, -10.0]), focal_x=500.0, focal_y=500.0, image_width=640, image_height=480)
+    with pytest.raises(RuntimeError):
+        T.filter_3d(torch.zeros((10, 3)), T.camera_table([cam], "cpu"))
+
+
+def test_emulated_add_densification_stats_matches_oracle(emu_all):
+    import types
+    import train_epilogue as T
+    P = 50_003
+    g = torch.Generator().manual_seed(12)
+    st = [torch.zeros((P, 1)) for _ in range(4)]
+    model = types.SimpleNamespace(xyz_gradient_accum=st[0].clone(), xyz_gradient_accum_abs=st[1].clone(), xyz_gradient_accum_abs_max=st[2].clone(), denom=st[3].clone())
+    for it in range(4):
+        grad = torch.randn((P, 3), generator=g) * (10.0 ** (-it * 3))
+        grad[:, 2] = grad[:, 2].abs()
+        filt = torch.rand(P, generator=g) < 0.6
+        O.add_densification_stats(st[0], st[1], st[2], st[3], grad, filt)
+        T.add_densification_stats(model, types.SimpleNamespace(grad=grad), filt)
+    for name, ref in zip(("xyz_gradient_accum", "xyz_gradient_accum_abs", "xyz_gradient_accum_abs_max", "denom"), st):
+        assert torch.allclose(getattr(model, name), ref, rtol=1e-6, atol=1e-30), name
+    assert torch.equal(model.denom, st[3])
+
+
+def test_emulated_activations_match_oracle(emu_all):
+    import types
+    import train_epilogue as T
+    P = 20_000
+    g = torch.Generator().manual_seed(44)
+    rs = torch.randn((P, 3), generator=g) * 2.0 - 4.0
+    ro = torch.randn((P, 1), generator=g) * 4.0
+    rr = torch.randn((P, 4), generator=g); rr[:10] = 0.0
+    f3 = torch.rand((P, 1), generator=g) * 0.1; f3[:1000] = 0.0
+    ws, wo, wr = (torch.randn(s_, generator=g) for s_ in ((P, 3), (P, 1), (P, 4)))
+    model = types.SimpleNamespace(_scaling=rs.clone().requires_grad_(True), _opacity=ro.clone().requires_grad_(True),
+                                  _rotation=rr.clone().requires_grad_(True), filter_3D=f3)
+    A = T.activations
+    s, o, r = A.get_scaling_with_3D_filter(model), A.get_opacity_with_3D_filter(model), A.get_rotation(model)
+    ((s * ws).sum() + (o * wo).sum() + (r * wr).sum()).backward()
+    trs, tro, trr = (a.clone().requires_grad_(True) for a in (rs, ro, rr))
+    so, oo, ro_ = O.scaling_with_3D_filter(trs, f3), O.opacity_with_3D_filter(tro, trs, f3), O.rotation(trr)
+    gs, go, gr = torch.autograd.grad((so * ws).sum() + (oo * wo).sum() + (ro_ * wr).sum(), [trs, tro, trr])
+    for a, ref, name in zip((s, o, r), (so, oo, ro_), ("scaling", "opacity", "rotation")):
+        np.testing.assert_allclose(a.detach().numpy(), ref.detach().numpy(), rtol=3e-6, atol=1e-30, err_msg=name)
+    for a, ref, name in zip((model._scaling.grad, model._opacity.grad, model._rotation.grad), (gs, go, gr), ("g_scaling", "g_opacity", "g_rotation")):
+        assert np.isfinite(a.numpy()).all(), name
+        _close(a.numpy(), ref.numpy(), 1e-5, name)

@@ -226,3 +226,44 @@ def test_results_do_not_depend_on_the_order_the_emulator_runs_fibers_in(order):
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_emulated_compressed_sh_gradient_exchange_equals_the_dense_sum():
+    """Data-parallel exchange of the SH gradient in compressed form (include/gof_hip.h: gof_sh_grad_pack / gof_sh_grad_expand;
+    dp/reducer.py): dL_dsh[k] = basis_k(direction) * dL_dRGB (masked by the forward's clamp flags), so a rank sends 12 B per Gaussian
+    -- its colour gradient -- plus the camera centre, and every rank expands the sum over the views locally, in rank order.  With
+    the real kernels (run from source on the host): the expansion of two views' packed gradients equals the sum of the two views'
+    dense dL_dsh from the backward -- every element the same number (a zero may carry the other sign: basis x 0) -- for the
+    [P,16,3] layout and for the split (dc, rest) layout; scale = 1/2 averages."""
+    import ctypes as C
+    lib = E.load()
+    base = S.scene_frustum(2500, W=128, H=96, focal=100.0, seed=31, kernel_size=0.1)
+    views = [base, S.other_view(base, 1)]                       # one cloud, two cameras
+    P, M = base["means3D"].shape[0], base["shs"].shape[1]
+    dense, packed = [], np.zeros((2, P + 1, 3), np.float32)
+    for v, sc in enumerate(views):
+        e = E.EmuScene(sc)
+        color, radii = e.forward()
+        g = e.backward(np.random.default_rng(7 + v).normal(size=color.shape).astype(np.float32))
+        dense.append(g["sh"].copy())
+        rc = lib.gof_sh_grad_pack(P, E._p(g["colors"]), E._p(e.geom), e.geom.size, E._p(radii), E._p(packed[v]), None)
+        assert rc == 0, lib.gof_last_error()
+        packed[v, P] = sc["campos"]
+    assert (dense[0] != 0).any() and (dense[1] != 0).any()
+    want = dense[0] + dense[1]
+    means = np.ascontiguousarray(base["means3D"], np.float32)
+    vs = (P + 1) * 3
+    base_ptr = packed.ctypes.data
+    # one [P, M, 3] tensor
+    out = np.full((P, M, 3), np.nan, np.float32)
+    rc = lib.gof_sh_grad_expand(P, int(base["sh_degree"]), M, 2, E._p(means), C.c_void_p(base_ptr + 12 * P), vs, C.c_void_p(base_ptr), vs, 1.0,
+                                C.c_void_p(out.ctypes.data), 3 * M, C.c_void_p(out.ctypes.data + 12), 3 * M, None)
+    assert rc == 0, lib.gof_last_error()
+    assert np.array_equal(out, want) and not (want[bits(out) != bits(want)] != 0).any()
+    # split layout (features_dc [P,1,3], features_rest [P,15,3]) and the averaging scale
+    dc = np.full((P, 1, 3), np.nan, np.float32); rest = np.full((P, M - 1, 3), np.nan, np.float32)
+    rc = lib.gof_sh_grad_expand(P, int(base["sh_degree"]), M, 2, E._p(means), C.c_void_p(base_ptr + 12 * P), vs, C.c_void_p(base_ptr), vs, 0.5,
+                                C.c_void_p(dc.ctypes.data), 3, C.c_void_p(rest.ctypes.data), 3 * (M - 1), None)
+    assert rc == 0, lib.gof_last_error()
+    got = np.concatenate([dc, rest], 1)
+    assert np.array_equal(got, (0.5 * want).astype(np.float32))      # (a power-of-two scale commutes with the rounding)
