@@ -394,6 +394,57 @@ def _worker_emu(rank, world, port, ret):
         ok = ok and np.array_equal(p.grad.numpy(), tot[n])           # two summands: the all-reduce's sum is the same fp32 addition
     ok = ok and np.array_equal(denom.numpy(), den) and np.array_equal(max_r.numpy(), mr) and np.array_equal(accum.numpy(), acc)
     ok = ok and bool(den.max() == world) and all(bool((np.abs(grads_of(v)[0]["means3D"]).max() > 0)) for v in range(world))     # every view sees (and moves) the cloud
+    # ---- the SH gradient in COMPRESSED form through the reducer (dp/reducer.py: all-gather of the 12-byte colour gradients + camera
+    # centres, local expansion of the sum over the views) with the REAL pack / expand kernels behind the reducer's sh_ops interface
+    import ctypes as C
+    lib = E.load()
+
+    class EmuOps:
+        src = None
+        ready = None
+        track = staticmethod(lambda on: None)
+
+        @staticmethod
+        def set_ready(fn):
+            EmuOps.ready = fn
+
+        @staticmethod
+        def take():
+            s_, EmuOps.src = EmuOps.src, None
+            return s_
+
+        @staticmethod
+        def pack(src, out):
+            assert lib.gof_sh_grad_pack(src["P"], C.c_void_p(src["dL_dcolors"].data_ptr()), C.c_void_p(src["geom"].data_ptr()), src["geom"].numel(),
+                                        C.c_void_p(src["radii"].data_ptr()), C.c_void_p(out.data_ptr()), None) == 0
+
+        @staticmethod
+        def expand(src, gathered, scale, outs):
+            Pn, M = src["P"], src["M"]
+            vs = (Pn + 1) * 3
+            if len(outs) == 1:
+                p_dc, p_rest, s_dc, s_rest = outs[0].data_ptr(), outs[0].data_ptr() + 12, 3 * M, 3 * M
+            else:
+                p_dc, p_rest, s_dc, s_rest = outs[0].data_ptr(), outs[1].data_ptr(), 3, 3 * (M - 1)
+            assert lib.gof_sh_grad_expand(Pn, src["degree"], M, int(gathered.shape[0]), C.c_void_p(src["means3D"].data_ptr()), C.c_void_p(gathered.data_ptr() + 12 * Pn), vs,
+                                          C.c_void_p(gathered.data_ptr()), vs, float(scale), C.c_void_p(p_dc), s_dc, C.c_void_p(p_rest), s_rest, None) == 0
+
+    e = E.EmuScene(view(rank))
+    color, radii_r = e.forward()
+    g = e.backward(np.random.default_rng(7 + rank).normal(size=color.shape).astype(np.float32))
+    Pn, M = g["sh"].shape[0], g["sh"].shape[1]
+    xyz = torch.zeros(Pn, 3, requires_grad=True); xyz.grad = torch.from_numpy(g["means3D"].copy())
+    f_dc = torch.zeros(Pn, 1, 3, requires_grad=True); f_rest = torch.zeros(Pn, M - 1, 3, requires_grad=True)
+    f_dc.grad = torch.from_numpy(g["sh"][:, :1].copy()); f_rest.grad = torch.from_numpy(g["sh"][:, 1:].copy())
+    keep = {"geom": torch.from_numpy(e.geom), "radii": torch.from_numpy(radii_r), "col": torch.from_numpy(g["colors"].copy()),
+            "means": torch.from_numpy(np.ascontiguousarray(view(rank)["means3D"], np.float32)), "campos": torch.from_numpy(np.ascontiguousarray(view(rank)["campos"], np.float32))}
+    red = GradientAllReducer([xyz, f_dc, f_rest], sh_params=[f_dc, f_rest], sh_ops=EmuOps)
+    EmuOps.src = {"P": Pn, "M": M, "degree": int(base["sh_degree"]), "dL_dcolors": keep["col"], "geom": keep["geom"], "radii": keep["radii"],
+                  "means3D": keep["means"], "campos": keep["campos"]}
+    red.all_reduce()
+    ok = ok and red.last_exchange == "compressed-sh"
+    got_sh = torch.cat([f_dc.grad, f_rest.grad], 1).numpy()
+    ok = ok and np.array_equal(got_sh, tot["sh"]) and np.array_equal(xyz.grad.numpy(), tot["means3D"])     # same numbers as the dense sum over the views
     # replicas stay identical: every rank holds the same reduced gradients (checked through a gather of checksums)
     chk = torch.tensor([float(np.abs(p.grad.numpy()).sum()) for p in params], dtype=torch.float64)
     gathered = [torch.zeros_like(chk) for _ in range(world)]
