@@ -186,3 +186,47 @@ class EmuScene:
                                    _p(self.radii), _p(self.color), _p(pinned), None)
         self.R = int(capacity)           # the layout size: what fetch() / backward() have to be given on this path
         return rc, int(pinned[0]), bool((raw[nb:] == 0xA5).all())
+
+    def integrate_view(self):
+        """the Gaussian half of the opacity-field query (binning + pixel pass), kept on the object: -> base image [9,H,W]"""
+        lib = self.lib
+        self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
+        self.radii = np.zeros(self.P, np.int32)
+        n = C.c_uint32(0)
+        self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
+        self.R = int(n.value)
+        self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
+        self.base = np.zeros((9, self.H, self.W), np.float32)
+        self._check(lib.gof_integrate_view(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
+                                           _p(self.img), self.img.size, _p(self.base), None))
+        return self.base
+
+    def pack_geom(self):
+        """keep only what the point pass reads of the geometry workspace (the per-view cache of a mesh extraction)"""
+        lib = self.lib
+        self.packed = _aligned(lib.gof_integrate_packed_geom_bytes(self.P), what="packed geom")
+        self._check(lib.gof_integrate_pack_geom(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.packed), self.packed.size, None))
+        return self.packed
+
+    def integrate_points(self, points3D, mode="plain", alpha_min=None, color_min=None):
+        """the point half on the view prepared by integrate_view(): mode 'plain' | 'packed' (reads pack_geom()'s buffer) |
+        'min' / 'min_packed' (min over views fused into the store: alpha_min / color_min updated in place)"""
+        lib = self.lib
+        pts = _f32(points3D); PN = int(pts.shape[0])
+        pws = _aligned(lib.gof_point_bytes(PN), what="point ws")
+        ni = C.c_uint32(0)
+        self._check(lib.gof_integrate_prepare_points(C.byref(self.args), PN, _p(pts), _p(pws), pws.size, C.byref(ni), None))
+        NI = int(ni.value)
+        pbin = _aligned(lib.gof_point_binning_bytes(NI, self.W, self.H), what="point binning")
+        use_packed = mode.endswith("packed")
+        g = self.packed if use_packed else self.geom
+        if mode.startswith("min"):
+            self._check(lib.gof_integrate_points_min(C.byref(self.args), self.R, PN, NI, 1 if use_packed else 0, _p(g), g.size, _p(self.binning), self.binning.size,
+                                                     _p(self.img), self.img.size, _p(pws), pws.size, _p(pbin), pbin.size, _p(self.base), None,
+                                                     _p(alpha_min), None if color_min is None else _p(color_min), None))
+            return alpha_min, color_min
+        out = np.zeros((9, self.H, self.W), np.float32); alpha = np.ones(PN, np.float32); colp = np.zeros((PN, 3), np.float32)
+        fn = lib.gof_integrate_points_packed if use_packed else lib.gof_integrate_points
+        self._check(fn(C.byref(self.args), self.R, PN, NI, _p(g), g.size, _p(self.binning), self.binning.size, _p(self.img), self.img.size,
+                       _p(pws), pws.size, _p(pbin), pbin.size, _p(self.base), _p(out), _p(alpha), _p(colp), None))
+        return out, alpha, colp

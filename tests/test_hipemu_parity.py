@@ -267,3 +267,83 @@ def test_emulated_compressed_sh_gradient_exchange_equals_the_dense_sum():
     assert rc == 0, lib.gof_last_error()
     got = np.concatenate([dc, rest], 1)
     assert np.array_equal(got, (0.5 * want).astype(np.float32))      # (a power-of-two scale commutes with the rounding)
+
+
+def test_emulated_training_loop_fits_a_target_image():
+    """gradient USEFULNESS end to end, without a GPU: a perturbed copy of a small scene is optimised (torch Adam on the host; the
+    rasterizer's forward and backward are the kernels run from source) towards the image the unperturbed scene renders -- the L1
+    loss must fall by more than half in 60 steps.  Wrong signs / scalings / index mix-ups in any gradient make it stall or rise."""
+    import torch
+    rng = np.random.default_rng(3)
+    truth = S.scene_frustum(400, W=96, H=64, focal=80.0, seed=21, kernel_size=0.1, sigma_px=4.0, pose_seed=5)
+    target, _ = E.EmuScene(truth).forward()
+    target = target[:3].copy()
+    P = truth["means3D"].shape[0]
+    start = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in truth.items()}
+    start["means3D"] = (truth["means3D"] + rng.normal(0, 0.02, (P, 3)) * np.abs(truth["means3D"][:, 2:3])).astype(np.float32)
+    start["opacities"] = np.clip(truth["opacities"] * rng.uniform(0.5, 1.0, (P, 1)), 0.01, 0.99).astype(np.float32)
+    start["shs"] = (truth["shs"] + rng.normal(0, 0.15, truth["shs"].shape)).astype(np.float32)
+    start["scales"] = (truth["scales"] * np.exp(rng.normal(0, 0.15, (P, 3)))).astype(np.float32)
+    names = {"means3D": "means3D", "opacities": "opacity", "shs": "sh", "scales": "scales", "rotations": "rotations"}
+    params = {k: torch.from_numpy(start[k].copy()).requires_grad_(True) for k in names}
+    lrs = {"means3D": 2e-3, "opacities": 2e-2, "shs": 1e-2, "scales": 1e-3, "rotations": 1e-3}
+    opt = torch.optim.Adam([{"params": [params[k]], "lr": lrs[k]} for k in names], eps=1e-15)
+    losses = []
+    for it in range(60):
+        sc = dict(start)
+        for k in names:
+            sc[k] = params[k].detach().numpy()
+        sc["opacities"] = np.clip(sc["opacities"], 1e-3, 0.999)
+        e = E.EmuScene(sc)
+        img, _ = e.forward()
+        diff = img[:3] - target
+        losses.append(float(np.abs(diff).mean()))
+        dL = np.zeros_like(img)
+        dL[:3] = np.sign(diff) / diff.size                        # d mean|img - target| / d img
+        g = e.backward(dL)
+        opt.zero_grad()
+        for k, gk in names.items():
+            params[k].grad = torch.from_numpy(g[gk].reshape(params[k].shape).copy())
+        opt.step()
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    assert min(losses[-10:]) < min(losses[:10])
+
+
+def test_emulated_mesh_extraction_paths_min_over_views_and_packed_cache():
+    """SURVEY 8(f)1, the mesh-extraction driver fusion, with the kernels run from source: (a) the point pass reading the PACKED
+    per-view cache (68 B per Gaussian) gives the bits of the plain one; (b) the reduction over views of reference
+    extract_mesh.py:17-34 -- color = where(alpha < alpha_min, color_view, color); alpha_min = min(alpha_min, alpha) -- fused into the
+    point pass's store equals that reduction done on the separate per-view outputs, bit for bit, with and without the colour."""
+    base = S.scene_frustum(3000, W=128, H=96, focal=100.0, seed=17, kernel_size=0.1, pose_seed=3)
+    views = [base, S.other_view(base, 1), S.other_view(base, 2)]
+    pts = np.ascontiguousarray(S.tetra_points(base)[::2], dtype=np.float32)
+    PN = len(pts)
+    want_alpha = np.ones(PN, np.float32); want_color = np.zeros((PN, 3), np.float32)
+    acc_alpha = np.ones(PN, np.float32); acc_color = np.zeros((PN, 3), np.float32)
+    acc_alpha_only = np.ones(PN, np.float32)
+    for k, sc in enumerate(views):
+        e = E.EmuScene(sc)
+        e.integrate_view()
+        out, alpha, colp = e.integrate_points(pts, "plain")
+        e.pack_geom()
+        out_p, alpha_p, colp_p = e.integrate_points(pts, "packed")
+        assert np.array_equal(bits(out), bits(out_p)) and np.array_equal(bits(alpha), bits(alpha_p)) and np.array_equal(bits(colp), bits(colp_p))
+        take = alpha < want_alpha                                       # extract_mesh.py:26-29
+        want_color[take] = colp[take]
+        want_alpha = np.minimum(want_alpha, alpha)
+        e.integrate_points(pts, "min" if k % 2 == 0 else "min_packed", acc_alpha, acc_color)
+        e.integrate_points(pts, "min_packed" if k % 2 == 0 else "min", acc_alpha_only, None)
+    assert (want_alpha < 1).mean() > 0.5
+    assert np.array_equal(bits(acc_alpha), bits(want_alpha)) and np.array_equal(bits(acc_color), bits(want_color))
+    assert np.array_equal(bits(acc_alpha_only), bits(want_alpha))
+
+
+def test_emulated_mark_visible_matches_oracle():
+    lib = E.load()
+    sc = S.scene_frustum(5000, W=160, H=112, focal=120.0, seed=4, pose_seed=6)
+    sc["means3D"][::7, 2] *= -1.0
+    m = np.ascontiguousarray(sc["means3D"], np.float32); V = np.ascontiguousarray(sc["viewmatrix"], np.float32); Pm = np.ascontiguousarray(sc["projmatrix"], np.float32)
+    present = np.zeros(len(m), np.uint8)
+    assert lib.gof_mark_visible(len(m), E._p(m), E._p(V), E._p(Pm), E._p(present), None) == 0
+    want = ob.mark_visible(m, V, Pm)
+    assert np.array_equal(present.astype(bool), np.asarray(want).astype(bool)) and 0 < present.sum() < len(m)
