@@ -303,3 +303,47 @@ def test_emulated_activations_match_oracle(emu_all):
     for a, ref, name in zip((model._scaling.grad, model._opacity.grad, model._rotation.grad), (gs, go, gr), ("g_scaling", "g_opacity", "g_rotation")):
         assert np.isfinite(a.numpy()).all(), name
         _close(a.numpy(), ref.numpy(), 1e-5, name)
+
+
+def test_emulated_densification_selection_and_row_surgery(emu_all, monkeypatch):
+    """gof_densify_select / gof_compact_rows / gof_rows_gather run from source against the reference's masks restated with torch on
+    the host (scene/gaussian_model.py:631-707): grads = accum / denom with NaN -> 0; selected = norm(grads) >= max_grad or
+    norm(grads_abs) >= Q; clone if max(scale) <= size_threshold, else split; the three ordered index lists; rows rebuilt by one
+    gather with new rows taken from `extra` (zeros for the Adam moments)."""
+    D = sys.modules.get("train_epilogue.densify") or __import__("importlib").import_module("train_epilogue.densify")
+    real = D.lib
+    monkeypatch.setattr(D, "lib", emu_all)
+    for name in ("gof_densify_ws_bytes", "gof_densify_select", "gof_compact_rows", "gof_rows_gather"):
+        getattr(emu_all, name).argtypes, getattr(emu_all, name).restype = getattr(real, name).argtypes, getattr(real, name).restype
+    g = torch.Generator().manual_seed(9)
+    P = 20_011
+    accum = torch.rand((P, 1), generator=g) * 3e-4
+    accum_abs = torch.rand((P, 1), generator=g) * 6e-4
+    denom = torch.randint(0, 5, (P, 1), generator=g).float()            # zeros: 0/0 = NaN -> 0
+    scale_max = torch.rand(P, generator=g) * 0.2
+    max_grad, size_threshold = 2e-4, 0.1
+    grads = accum / denom; grads[grads.isnan()] = 0.0
+    grads_abs = accum_abs / denom; grads_abs[grads_abs.isnan()] = 0.0
+    ratio = (torch.norm(grads, dim=-1) >= max_grad).float().mean()
+    Q = torch.quantile(grads_abs.reshape(-1), 1 - ratio)
+    sel = (torch.norm(grads, dim=-1) >= max_grad) | (torch.norm(grads_abs, dim=-1) >= Q)
+    clone = sel & (scale_max <= size_threshold)
+    split = sel & (scale_max > size_threshold)
+    role, keep_idx, clone_idx, split_idx = D.select(accum, accum_abs, denom, scale_max, max_grad, Q, size_threshold)
+    assert torch.equal(role, clone.to(torch.uint8) + 2 * split.to(torch.uint8))
+    assert torch.equal(clone_idx.long(), clone.nonzero().squeeze(1)) and torch.equal(split_idx.long(), split.nonzero().squeeze(1))
+    assert torch.equal(keep_idx.long(), (~split).nonzero().squeeze(1))
+    assert 0 < clone.sum() < P and 0 < split.sum() < P
+    # compact_rows with and without an indirection; rows_gather with new rows
+    keep = torch.rand(P, generator=g) < 0.7
+    assert torch.equal(D.compact_rows(keep).long(), keep.nonzero().squeeze(1))
+    src_rows = torch.randperm(P, generator=g).to(torch.int32)
+    assert torch.equal(D.compact_rows(keep, src_rows), src_rows[keep])
+    src = torch.randn((P, 15, 3), generator=g); extra = torch.randn((7, 15, 3), generator=g)
+    rows = torch.cat([keep_idx[:1000], -(torch.arange(7, dtype=torch.int32) + 1), clone_idx[:50]])
+    got = D.rows_gather(rows, src, extra)
+    want = torch.cat([src[keep_idx[:1000].long()], extra, src[clone_idx[:50].long()]])
+    assert torch.equal(got, want)
+    got0 = D.rows_gather(rows, src, None)                                  # an Adam moment: zeros where new rows go
+    want0 = want.clone(); want0[1000:1007] = 0
+    assert torch.equal(got0, want0)
