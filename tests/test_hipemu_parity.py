@@ -347,3 +347,53 @@ def test_emulated_mark_visible_matches_oracle():
     assert lib.gof_mark_visible(len(m), E._p(m), E._p(V), E._p(Pm), E._p(present), None) == 0
     want = ob.mark_visible(m, V, Pm)
     assert np.array_equal(present.astype(bool), np.asarray(want).astype(bool)) and 0 < present.sum() < len(m)
+
+
+def test_emulated_staged_entry_points_equal_the_one_call_forms():
+    """gof_backward_blend + gof_backward_preprocess (the split the data-parallel reducer uses to start its exchange early) give the
+    bits of gof_backward; gof_integrate_run (the reference's monolithic IntegrateGaussiansToPointsCUDA shape) gives the bits of
+    gof_integrate_view + gof_integrate_points; gof_profile_enable / gof_profile_report name the kernels of a call."""
+    import ctypes as C
+    import json
+    lib = E.load()
+    sc = TP.SCENES["posed_mod2"]()
+    e = E.EmuScene(sc)
+    assert lib.gof_profile_enable(1) == 0
+    img, radii = e.forward()
+    buf = C.create_string_buffer(1 << 16)
+    assert lib.gof_profile_report(buf, len(buf)) == 0
+    rep = json.loads(buf.value.decode())
+    assert {"preprocess_fwd", "blend_forward"} <= set(rep) and all(v["calls"] >= 1 for v in rep.values())
+    assert lib.gof_profile_enable(0) == 0
+    dL = np.random.default_rng(3).normal(size=img.shape).astype(np.float32)
+    one = e.backward(dL)
+    # the same call, staged
+    P, M = e.P, e.M
+    g = {k: np.full_like(v, np.nan) for k, v in one.items()}
+    g["cov3D"].fill(0)
+    nscratch = lib.gof_backward_scratch_bytes(P, e.R)
+    scratch = E._aligned(nscratch, what="backward scratch")
+    call = (C.byref(e.args), e.R, E._p(e.radii), E._p(e.geom), e.geom.size, E._p(e.binning), e.binning.size, E._p(e.img), e.img.size, E._p(dL),
+            E._p(g["means2D"]), E._p(g["colors"]), E._p(g["opacity"]), E._p(g["means3D"]), None, E._p(g["sh"]), None, E._p(g["scales"]), E._p(g["rotations"]),
+            E._p(g["view2gaussian"]), E._p(scratch), nscratch, None)
+    assert lib.gof_backward_blend(*call) == 0
+    assert np.array_equal(bits(g["colors"]), bits(one["colors"])) and np.array_equal(bits(g["view2gaussian"]), bits(one["view2gaussian"]))   # final after stage 1
+    assert lib.gof_backward_preprocess(*call) == 0
+    for k in one:
+        assert np.array_equal(bits(g[k]), bits(one[k])), k
+    # integrate: monolithic vs split
+    pts = np.ascontiguousarray(S.tetra_points(sc)[::3], dtype=np.float32); PN = len(pts)
+    want_img, want_alpha, want_col, _ = E.EmuScene(sc).integrate(pts)
+    f = E.EmuScene(sc)
+    f.geom = E._aligned(lib.gof_geom_bytes(f.P), what="geom"); f.img = E._aligned(lib.gof_image_bytes(f.W, f.H), what="image")
+    f.radii = np.zeros(f.P, np.int32)
+    n = C.c_uint32(0)
+    assert lib.gof_forward_prepare(C.byref(f.args), E._p(f.geom), f.geom.size, E._p(f.img), f.img.size, E._p(f.radii), C.byref(n), None) == 0
+    pws = E._aligned(lib.gof_point_bytes(PN), what="point ws"); ni = C.c_uint32(0)
+    assert lib.gof_integrate_prepare_points(C.byref(f.args), PN, E._p(pts), E._p(pws), pws.size, C.byref(ni), None) == 0
+    binning = E._aligned(lib.gof_binning_bytes(n.value, f.W, f.H), what="binning"); pbin = E._aligned(lib.gof_point_binning_bytes(ni.value, f.W, f.H), what="point binning")
+    out = np.zeros((9, f.H, f.W), np.float32); alpha = np.ones(PN, np.float32); col = np.zeros((PN, 3), np.float32)
+    rc = lib.gof_integrate_run(C.byref(f.args), n.value, E._p(f.radii), PN, ni.value, E._p(f.geom), f.geom.size, E._p(binning), binning.size, E._p(f.img), f.img.size,
+                               E._p(pws), pws.size, E._p(pbin), pbin.size, E._p(out), E._p(alpha), E._p(col), None)
+    assert rc == 0, lib.gof_last_error()
+    assert np.array_equal(bits(out), bits(want_img)) and np.array_equal(bits(alpha), bits(want_alpha)) and np.array_equal(bits(col), bits(want_col))
