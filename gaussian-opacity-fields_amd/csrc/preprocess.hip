@@ -357,6 +357,23 @@ preprocess_fwd(int P, int D, int M,
         fconic_out[2 * (size_t)idx + 1] = fc[1];
         depths[idx] = p_view.z;
         my_radii = (int32_t)my_radius;
+#ifdef GOF_TIGHT_RECTS
+        // developer A/B (not the shipped build, which keeps the reference's tile lists entry for entry): the reference bins a Gaussian
+        // into every tile of the square of its 3-sigma radius (auxiliary.h:64-74); a tile none of whose pixels lies inside the footprint box
+        // (the conservative pixel box of the alpha >= 1/255 region incl. the error allowance, footprint_bbox above) cannot receive a
+        // contribution from it.  Intersecting the two leaves image and gradients unchanged and shortens the lists (R) -- emission, tile
+        // sort, the forward's cull scan and the backward's staging shrink with them; radii (returned to the caller) stay the reference's.
+        if (box.x > -1e29f) {                                           // (unbounded boxes carry -1e30 / 1e30: no statement)
+            // (widened by one pixel: the opacity-field query's corner sub-rays sit half a pixel outside the pixel centres, integrate.hip)
+            const float bx0 = box.x - 1.0f, bx1 = box.y + 1.0f, by0 = box.z - 1.0f, by1 = box.w + 1.0f;
+            const int tx0 = (int)floorf(fmaxf(bx0, 0.0f) * (1.0f / TILE_X)), tx1 = (bx1 < 0.0f) ? 0 : (int)floorf(fminf(bx1, 1e9f) * (1.0f / TILE_X)) + 1;
+            const int ty0 = (int)floorf(fmaxf(by0, 0.0f) * (1.0f / TILE_Y)), ty1 = (by1 < 0.0f) ? 0 : (int)floorf(fminf(by1, 1e9f) * (1.0f / TILE_Y)) + 1;
+            const bool none = (bx0 > bx1) | (by0 > by1);        // (a box between two pixel centres is still reachable by a corner sub-ray)
+            minx = max(minx, (uint32_t)min(tx0, (int)gx)); maxx = min(maxx, (uint32_t)min(max(tx1, 0), (int)gx));
+            miny = max(miny, (uint32_t)min(ty0, (int)gy)); maxy = min(maxy, (uint32_t)min(max(ty1, 0), (int)gy));
+            if (none || maxx <= minx || maxy <= miny) { maxx = minx; maxy = miny; }
+        }
+#endif
         my_tiles = (maxy - miny) * (maxx - minx);
         my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
     } while (0);
