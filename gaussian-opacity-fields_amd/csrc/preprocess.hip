@@ -112,9 +112,10 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
 // roundings (|| |Sigma'| ||_2 <= sqrt(3) lambda_max); BB by <= 24 eps lambda_max |mu| |r| (b = Sigma' mu, 5 roundings, doubled) + <= 10
 // eps lambda_max |mu| |r| from the fp32 rounding of the transformed mean inside b; CC by <= 11 eps lambda_max |mu|^2.  With
 // d(min_value)/dBB = t, d/dAA = t^2 and t |r| ~ |mu| at the ray's closest approach:  |delta min_value| <~ (22.4 + 34 + 11) eps
-// lambda_max |mu|^2 = 4.0e-6 lambda_max |mu|^2.  The level is therefore raised to k = m0 + Delta with
-//     Delta = GOF_BOX_C * lambda_max * |mu|^2 + 0.05,   GOF_BOX_C = 4e-6
-// (that bound: a sum of worst cases, 8x what was ever observed -- see below; rounds 1-2 carried another factor 1.5, which cost 4 % of
+// lambda_max |mu|^2 = 67.4 eps = 4.02e-6 lambda_max |mu|^2 (the opacity-field query forms BB / AA as an fp32 quotient first,
+// forward.cu:936: one more eps of X <= lambda_max |mu|^2, 4.08e-6).  The level is therefore raised to k = m0 + Delta with
+//     Delta = GOF_BOX_C * lambda_max * |mu|^2 + 0.05,   GOF_BOX_C = 4.2e-6
+// (that bound, rounded up: a sum of worst cases, 8x what was ever observed -- see below; rounds 1-2 carried another factor 1.5, which cost 4 % of
 // the forward blend's heavy trips at S1M, 5 % on the clustered scene, for nothing the bound does not already cover; the constant
 // term covers the fp32 rounding of `power`, the <= 1 ulp exp and the threshold compare with a wide
 // margin), which keeps box and conic conservative with respect to the arithmetic the blend actually performs (for sub-pixel,
@@ -162,7 +163,7 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     const double mx = mu.x, my = mu.y, mz = mu.z;
     const double mu2 = mx * mx + my * my + mz * mz;
 #ifndef GOF_BOX_C
-#define GOF_BOX_C 4e-6
+#define GOF_BOX_C 4.2e-6
 #endif
     const double k = m0 + 0.05 + GOF_BOX_C * lmax * mu2;
     // view-space covariance Cov = A diag(1/l) A^T with A = Rt^T (rows of Rt are the Gaussian axes in view space):
