@@ -97,7 +97,10 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
     // unit-normalised conic (sum |M_ij| = 1): 8 fp32 roundings of terms bounded by max(1, |r|^2) -> 3e-6 * that bound
     const float crx = srx[0], cry = sry[0];
     const float two_hx = 2.0f * (0.5f / focal_x), two_hy = 2.0f * (0.5f / focal_y);
-    const float cone_margin = 3e-6f * fmaxf(1.0f, fmaxf((fabsf(crx) + two_hx) * (fabsf(crx) + two_hx), (fabsf(cry) + two_hy) * (fabsf(cry) + two_hy)));
+#ifndef GOF_INT_CONE_MARGIN
+#define GOF_INT_CONE_MARGIN 3e-6f
+#endif
+    const float cone_margin = GOF_INT_CONE_MARGIN * fmaxf(1.0f, fmaxf((fabsf(crx) + two_hx) * (fabsf(crx) + two_hx), (fabsf(cry) + two_hy) * (fabsf(cry) + two_hy)));
     float cT[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
     float C0 = 0, C1 = 0, C2 = 0, Cdepth = 0, Calpha = 0;
     uint32_t contributor = 0, last_contributor = 0, n_local = 0;
@@ -179,6 +182,7 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                 cand &= cand - 1;
                 const int j = w * 32 + bit;
                 contributor = (uint32_t)b * TILE_PIX + (uint32_t)j + 1u;      // 1-based list position
+                ISTAT_ADD(6, 1);
                 const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
                 const float wgt = c4.z;
                 const float log_thr = cull_log_threshold(wgt);
@@ -216,6 +220,7 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                     used = true;
                 }
                 if (used) {
+                    ISTAT_ADD(7, 1);
                     last_contributor = contributor;
                     if (contributor <= 0xFFFFu) {                 // stored exactly: the second pass finds it where it is
                         word |= 1u << bit;
