@@ -22,7 +22,7 @@ SCENES = {"s1m": lambda: S.scene_frustum(1_000_000, seed=0), "s1m_posed": lambda
 
 if __name__ == "__main__":
     rep = {}
-    for name in (sys.argv[1:] or ["s1m"]):
+    for name in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["s1m"]):
         sc = SCENES[name]()
         t = time.time(); o = ob.OracleScene(sc); oc, orad = o.forward(); t_of = time.time() - t
         e = E.EmuScene(sc)
@@ -46,9 +46,21 @@ if __name__ == "__main__":
         r["blend_backward_max_norm_error"] = {k: float(np.abs(gp[k].reshape(go[k].shape) - go[k]).max() / (np.abs(go[k]).max() + 1e-30)) for k in ("means2D", "colors", "opacity", "view2gaussian")}
         iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
         r["K9_on_identical_inputs_max_norm_error"] = {k: float(np.abs(gp[k].reshape(iso[k].shape) - iso[k]).max() / (np.abs(iso[k]).max() + 1e-30)) for k in ("means3D", "sh", "scales", "rotations")}
+        if "--integrate" in sys.argv:      # the opacity-field query: 1M of the scene's 9M tetra points
+            pts = S.tetra_points(sc)
+            pts = np.ascontiguousarray(pts[np.random.default_rng(3).choice(len(pts), 1_000_000, replace=False)], dtype=np.float32)
+            t = time.time(); ic, ia, icol, irad = ob.OracleScene(sc).integrate(pts); t_oi = time.time() - t
+            t = time.time(); c2, a2, col2, rad2 = E.EmuScene(sc).integrate(pts); t_ei = time.time() - t
+            r["integrate_1M_points"] = {"image_bit_equal": bool(np.array_equal(bits(c2), bits(ic))), "alpha_integrated_bit_equal": bool(np.array_equal(bits(a2), bits(ia))),
+                                        "color_integrated_bit_equal": bool(np.array_equal(bits(col2), bits(icol))), "radii_equal": bool(np.array_equal(rad2, irad)),
+                                        "seconds": {"oracle": round(t_oi, 1), "emulated": round(t_ei, 1)}}
         r["guards_intact"] = E.guards_intact() == []
         rep[name] = r
         print(name, json.dumps(r), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    prev = os.path.join(ROOT, "profiles", "r03_hipemu_full_size.json")
+    if os.path.exists(prev):                       # scenes not re-run keep their committed entries
+        old = json.load(open(prev)).get("scenes", {})
+        rep = {**old, **rep}
     with open(os.path.join(ROOT, "gpurun_out", "r03_hipemu_full_size.json"), "w") as f:
         json.dump({"tool": "tests/devtools/dev_hipemu_full_size.py", "what": "csrc/*.hip compiled for the host (tests/hipemu) vs the oracle at BASELINE's full size, no GPU", "scenes": rep}, f, indent=1)
