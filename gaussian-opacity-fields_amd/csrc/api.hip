@@ -7,6 +7,7 @@
 #include "gof_common.h"
 #include "gof_status.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +59,12 @@ __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
                               float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
-                              uint32_t* tile_cost);
+                              uint32_t* tile_cost, uint32_t* redo_list);
+__global__ void blend_forward_exact(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
+                                    float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
+                                    float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
+                                    uint32_t* tile_cost, const uint32_t* redo_list);
+constexpr int FW_REDO_GRID = 1024;      // >= the list length of every scene measured (S1M: ~650 entries): one tile per workgroup, the kernel lasts one tile
 __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
@@ -326,6 +332,30 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
     hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr);
 }
 
+// The forward blend: the fp32 value path with certified decisions over all tiles, then the tiles it was not sure about once more in
+// the reference's own arithmetic (blend_forward.hip).  The redo list lives where order_tiles_for_backward writes afterwards.
+// Verification mode (gof_set_forward_exact(1), or GOF_FW_EXACT=1 in the environment when the library is loaded): every tile in the
+// exact arithmetic -- every output bit the oracle's.
+static std::atomic<int> g_forward_exact{ [] { const char* e = getenv("GOF_FW_EXACT"); return (e && e[0] == '1') ? 1 : 0; }() };
+static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const GeomWs& g, const BinWs& b, const ImageWs& im, float* out_color, hipStream_t stream)
+{
+    if (g_forward_exact.load(std::memory_order_relaxed)) {
+        GOF_PROFILE("blend_forward", stream);
+        hipLaunchKernelGGL(blend_forward_exact, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                           im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                           im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost, nullptr);
+        return;
+    }
+    { GOF_PROFILE("blend_forward", stream);
+    hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost, im.tile_order_bw); }
+    { GOF_PROFILE("blend_forward_redo", stream);
+    hipLaunchKernelGGL(blend_forward_exact, dim3(FW_REDO_GRID), dim3(TILE_PIX), 0, stream,
+                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost, im.tile_order_bw); }
+}
+
 } // namespace gof
 
 using namespace gof;
@@ -333,7 +363,9 @@ using namespace gof;
 extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
-int gof_abi_version(void) { return 7; }   // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
+int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
+int gof_abi_version(void) { return 8; }   // 8: gof_set_forward_exact; the forward blend's fp32 value path (round 4)
+                                          // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
@@ -447,10 +479,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     } else {
         hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr);
     }
-    { GOF_PROFILE("blend_forward", stream);
-    hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost); }
+    launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
     order_tiles_for_backward(d, im, stream);
     GOF_HIP_CHECK(hipEventSynchronize(ev));
@@ -487,10 +516,7 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     const Dims d = dims_of(a);
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
-    { GOF_PROFILE("blend_forward", stream);
-    hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost); }
+    launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, a->debug);
     order_tiles_for_backward(d, im, stream);
     GOF_LAUNCH_CHECK(stream, a->debug);
@@ -903,8 +929,10 @@ __global__ void unpack_rec(int P, const SplatRec* __restrict__ rec, const float4
 // words the backward reads (positions below the tile's last contributor)
 __global__ void __launch_bounds__(256)
 count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ cmask,
-                         int W, int H, uint32_t gx, uint32_t ntiles, uint32_t* __restrict__ out)
+                         int W, int H, uint32_t gx, uint32_t ntiles, uint32_t* __restrict__ out, int hash)
 {
+    // hash != 0: a position-sensitive checksum of the same words instead of their bit count (two forward modes that agree on it agree
+    // on every contributor bit the backward reads)
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     uint32_t lx, ly;
     tile_pixel(tid, lx, ly);
@@ -919,7 +947,11 @@ count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __res
     const uint32_t max_last = min(s_max, range.y - range.x);
     const uint32_t* cm = cmask + cmask_base(range.x, tile) * TILE_PIX;
     uint32_t c = 0;
-    for (uint32_t w = 0; w < (max_last + 31) / 32; w++) c += __popc(cm[(size_t)w * TILE_PIX + tid]);
+    for (uint32_t w = 0; w < (max_last + 31) / 32; w++) {
+        uint32_t word = cm[(size_t)w * TILE_PIX + tid];
+        if (w == max_last / 32 && (max_last & 31u)) word &= (1u << (max_last & 31u)) - 1u;      // (positions the backward never stages)
+        c += hash ? word * (2u * (w * TILE_PIX + tid) + 1u) + (word >> 7) : (uint32_t)__popc(word);
+    }
     atomicAdd(&s_sum, c);
     __syncthreads();
     if (tid == 0) out[tile] = s_sum;
@@ -953,10 +985,10 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
         if (hipGetLastError() != hipSuccess) { set_error("rebuild_keys launch failed"); return GOF_E_DEVICE; }
         return (int64_t)R;
     }
-    else if (n == "contrib_pairs" && binning_ws && image_ws) {
+    else if ((n == "contrib_pairs" || n == "contrib_hash") && binning_ws && image_ws) {
         if (dst_bytes < (size_t)d.ntiles * 4) { set_error("dst too small"); return GOF_E_INVALID; }
         hipLaunchKernelGGL(count_contributing_pairs, dim3(d.ntiles), dim3(256), 0, stream, im.ranges, im.n_contrib, b.cmask, a->W, a->H, d.gx, d.ntiles,
-                           static_cast<uint32_t*>(dst));
+                           static_cast<uint32_t*>(dst), n == "contrib_hash" ? 1 : 0);
         if (hipGetLastError() != hipSuccess) { set_error("count_contributing_pairs launch failed"); return GOF_E_DEVICE; }
         return (int64_t)d.ntiles;
     }

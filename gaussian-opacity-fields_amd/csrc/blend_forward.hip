@@ -48,12 +48,22 @@ namespace gof {
                              // scanning past a pixel's saturation costs less than the lane compaction of a longer candidate run gains)
 #endif
 constexpr int FW_CHUNK = GOF_FW_CHUNK;
+// the fp32 value path's exponential: the shared deterministic gexpf (default; alpha bit-identical to the exact path's whenever the
+// power is) or v_exp_f32 (-DGOF_FW_HWEXP: ~45 cycles per trip less, alpha within pair_fast_alpha_err all the same)
+#ifdef GOF_FW_HWEXP
+constexpr bool FW_HWEXP = true;
+#else
+constexpr bool FW_HWEXP = false;
+#endif
+// redo list of the certified fp32 path: blend_forward appends the tiles it is not sure about, blend_forward_redo renders them again in
+// the exact arithmetic.  Count at tile_queue[FW_REDO_WORD] (cleared by order_tiles together with the queue heads).
 
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] scanned wave-entries, [1] candidate
 // (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active,
 // [6] (GOF_CULL_AUDIT) pairs the exact path accepts that the cull scan had dropped, [7] scanned wave-entries with a candidate in the wave
-__device__ unsigned long long g_fw_stats[8];
+// [8..11] (certified fp32 path) pixels-events that raised `unsure`: t band, alpha band, T > 0.5 band, T < 1e-4 band; [12] tiles on the redo list, [13] their waves
+__device__ unsigned long long g_fw_stats[16];
 #define STAT_ADD(i, v) atomicAdd(&g_fw_stats[i], (unsigned long long)(v))
 #else
 #define STAT_ADD(i, v)
@@ -73,12 +83,26 @@ __device__ unsigned long long g_fw_tile_clock[2][1 << 16];
 #ifndef GOF_FW_WAVES
 #define GOF_FW_WAVES 4       // LDS bounds the occupancy at 5 workgroups per CU; asking for 4 leaves the allocator more room (88 VGPR, measured -1 %)
 #endif
-// one tile: everything below is per tile; called by all 256 threads of the workgroup (persistent loop in blend_forward)
+// one tile: everything below is per tile; called by all 256 threads of the workgroup.
+// EXACT = true: the value path of a pair in the reference's own arithmetic (fp64 quotients: pair_exact_cc) -- every output bit that
+//   of the oracle; the -DGOF_FW_EXACT verification build renders every tile this way, the default build the tiles on the redo list.
+// EXACT = false (default build, round 4): the value path in fp32 (pair_fast_cc, mapped_depth_fast) with CERTIFIED decisions: every
+//   comparison the exact path makes (t <= near plane, alpha < 1/255, T > 0.5, T (1 - alpha) < 1e-4) is made on the fp32 value, and
+//   whenever that value lies within its error bound of the threshold -- or an intermediate is not finite -- the pixel raises
+//   `unsure`; a wave (8x8 pixel quadrant) with an unsure pixel is put on the redo list -- (tile, wave mask) -- and rendered again by
+//   blend_forward_exact.  So n_contrib, the contributor masks and tile_cost are ALWAYS those of the exact arithmetic, and the float
+//   channels differ from it by the fp32 evaluation only (a few 1e-7 of the channel maximum; the distortion channel, a cancelling sum
+//   divided by (1 - T)^2, by its conditioning).  The transmittance carries an absolute error bound E:
+//   E' = E (1 - alpha) + T (alpha e_alpha + 1.8e-7) (alpha's relative bound e_alpha = pair_fast_alpha_err; 1.8e-7 = one ulp each for
+//   the roundings of 1 - alpha and of the product, which may fall differently in the two paths).
+// wave_mask (EXACT only): bit w set = wave w renders its quadrant; the other waves help staging, write nothing and report the
+//   cost the first pass measured.
+template <bool EXACT>
 __device__ __forceinline__ void
-blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_mask)[TILE_PIX], const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                    const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                   uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost)
+                   uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost, uint32_t* __restrict__ redo_count, uint32_t* __restrict__ redo_list)
 {
     TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -86,7 +110,8 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
     uint32_t lx, ly;
     tile_pixel(tid, lx, ly);
     const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
-    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
+    const bool in_image = px < (uint32_t)W && py < (uint32_t)H;
+    const bool inside = in_image && (!EXACT || ((wave_mask >> (tid >> 6)) & 1u));      // pixels this call renders
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
     const float rx = (float)(((double)pixfx - W / 2.) / (double)focal_x);
@@ -121,7 +146,8 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
     const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
 
     bool done = !inside;
-    float T = 1.0f;
+    bool unsure = false;                         // (EXACT = false) a decision of this pixel was too close to its threshold to call
+    float T = 1.0f, E = 0.0f;                    // E: bound on |T - the exact path's T|
     uint32_t last_contributor = 0, max_contributor = (uint32_t)-1;
     // accumulators kept as the register pairs the packed updates work on (every element sees the reference's operation
     // sequence: packed fp32 instructions are element-wise IEEE)
@@ -148,8 +174,10 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
         }
         __syncthreads();
         const int nwords_batch = (min(TILE_PIX, toDo) + 31) >> 5;
+        const bool wave_renders = !EXACT || ((wave_mask >> (tid >> 6)) & 1u);      // (wave-uniform)
         if (__ballot(!done) == 0ull) {             // whole wave saturated: it only helps staging (and reports "no contributors")
-            for (int q = 0; q < nwords_batch; q++) cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = 0u;
+            if (wave_renders)
+                for (int q = 0; q < nwords_batch; q++) cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = 0u;
             continue;
         }
 
@@ -228,31 +256,58 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
             const f2 n01 = (q0.xy * RX + q0.zw * RY) + q1.xy;               // normal[0], normal[1]
             const f2 n2b = (q1.zw * RX + q2.xy * RY) + q2.zw;               // normal[2], BB / 2
             const f2 rn = RXY * n01;
-            PairEval p;
-            p.n0 = n01.x; p.n1 = n01.y; p.n2 = n2b.x;
-            p.AAf = (rn.x + rn.y) + n2b.x;
-            p.BBf = 2 * n2b.y;
-            pair_exact_cc(q3.x, q3.y, p);
-            if (p.skip) continue;
-            STAT_ADD(3, 1);
+            const float n2 = n2b.x;
+            const float AAf = (rn.x + rn.y) + n2b.x;
+            const float BBf = 2 * n2b.y;
+            float alpha, t, test_T, mapped_max_t;
+            if constexpr (EXACT) {
+                PairEval p;
+                p.AAf = AAf; p.BBf = BBf;
+                pair_exact_cc(q3.x, q3.y, p);
+                if (p.skip) continue;
+                STAT_ADD(3, 1);
 #ifdef GOF_CULL_AUDIT
-            if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
+                if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
 #endif
-            const float alpha = p.alpha, t = p.t;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
+                alpha = p.alpha; t = p.t;
+                test_T = T * (1 - alpha);
+                if (test_T < 0.0001f) { done = true; continue; }
+                const float max_t = t;
+                mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
+            } else {
+                PairFast f;
+                pair_fast_cc<FW_HWEXP>(AAf, BBf, q3.x, q3.y, f);
+                alpha = f.alpha; t = f.t;
+                // A pair the fast value puts within its error bound of a threshold makes the pixel unsure; on the far side of the band
+                // the decision is the exact path's.  (Inside the band either branch may be taken: the tile is rendered again.)
+                // The exact path skips at (double)t <= 0.2, i.e. t < 0.2f; t here is within 1 ulp of that t (1.5e-8 at 0.2).
+                if (t < 0.2f + 6e-8f) { unsure |= t > 0.2f - 6e-8f; if (t > 0.2f - 6e-8f) STAT_ADD(8, 1); continue; }
+                const float ea = pair_fast_alpha_err(f.power, f.ph);
+                unsure |= !(fabsf(fmaf(alpha, 255.0f, -1.0f)) > ea);                      // (not-greater: a NaN / inf bound -- degenerate quadric -- is unsure)
+                if (!(fabsf(fmaf(alpha, 255.0f, -1.0f)) > ea)) STAT_ADD(9, 1);
+                if (alpha < 1.0f / 255.0f) continue;
+                STAT_ADD(3, 1);
+#ifdef GOF_CULL_AUDIT
+                if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
+#endif
+                const float oma = 1 - alpha;
+                test_T = T * oma;
+                unsure |= fabsf(T - 0.5f) <= E;                                           // the median-depth decision below
+                if (fabsf(T - 0.5f) <= E) STAT_ADD(10, 1);
+                E = fmaf(E, oma, T * fmaf(alpha, ea, 1.8e-7f));
+                if (test_T < 0.0001f + E) { unsure |= test_T > 0.0001f - E; if (test_T > 0.0001f - E) STAT_ADD(11, 1); done = true; continue; }
+                mapped_max_t = mapped_depth_fast(t);
+            }
             STAT_ADD(4, 1);
 
-            const float max_t = t;
-            const float mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
             // unit normal -n / |n|: the reference takes an fp64 sqrt and three IEEE divisions (forward.cu:548-549);
             // here one v_rsq_f32 (<= 1 ulp).  Only the normal channels depend on it: they agree with the oracle to
             // ~3e-7 instead of bit for bit; every other output is unaffected.
             const f2 sq = n01 * n01;
-            const float inv_len = __builtin_amdgcn_rsqf((sq.x + sq.y) + p.n2 * p.n2 + 1e-7f);
+            const float inv_len = __builtin_amdgcn_rsqf((sq.x + sq.y) + n2 * n2 + 1e-7f);
             const f2 NINV = { -inv_len, -inv_len };
             const f2 nn01 = n01 * NINV;
-            const f2 bn2 = { s_blue[j], p.n2 * NINV.x };                    // colour 2 | unit normal 2
+            const f2 bn2 = { s_blue[j], n2 * NINV.x };                    // colour 2 | unit normal 2
 
             const float A = 1 - T;
             const float mm = mapped_max_t * mapped_max_t;
@@ -274,7 +329,7 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
         for (int q = w + 1; q < nw; q++) s_mask[q][tid] = 0u;       // candidate words this pixel never reached (it saturated)
         words_valid = nw;
         }   // chunk
-        for (int q = 0; q < nwords_batch; q++)
+        for (int q = 0; q < nwords_batch; q++)           // (a wave that does not render has left the loop above: it is saturated from the start)
             cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = (q < words_valid) ? s_mask[q][tid] : 0u;
     }
 
@@ -303,15 +358,24 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
     // what this tile cost: the deepest list position any of its pixels blended = the entries the backward stages and walks
 #ifndef GOF_NO_TILE_COST      // (developer A/B: what the epilogue costs)
     {
-        uint32_t m = inside ? last_contributor : 0u;
+        // (a quadrant this call does not render: the deepest position the first pass blended there, which is the exact arithmetic's too)
+        uint32_t m = inside ? last_contributor : ((EXACT && in_image) ? n_contrib[pix_id] : 0u);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        uint32_t* const s_unsure = s_tile + 1;       // second scratch word (the masks are dead): waves with a pixel that was not sure
+        const bool wave_unsure = !EXACT && __ballot(unsure) != 0ull;
         __syncthreads();                            // every thread has read the popped tile id / its last mask words
-        if (tid == 0) *s_tile = 0u;
+        if (tid == 0) { s_tile[0] = 0u; s_unsure[0] = 0u; }
         __syncthreads();
-        if ((tid & 63u) == 0u) atomicMax(s_tile, m);
+        if ((tid & 63u) == 0u) {
+            atomicMax(s_tile, m);
+            if (wave_unsure) atomicOr(s_unsure, 1u << (tid >> 6));
+        }
         __syncthreads();
-        if (tid == 0) tile_cost[tile] = *s_tile;
+        if (tid == 0) {
+            tile_cost[tile] = *s_tile;
+            if (!EXACT && *s_unsure) { redo_list[atomicAdd(redo_count, 1u)] = tile | (*s_unsure << 28); STAT_ADD(12, 1); STAT_ADD(13, __popc(*s_unsure)); }
+        }
     }
 #endif
     TILE_CLOCK_END(g_fw_tile_clock);
@@ -323,7 +387,7 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
               const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
               uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
-              uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
+              uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost, uint32_t* __restrict__ redo_list)
 {
     // The kernel's LDS must stay at 32 000 B: 25 allocation granules of 1280 B, five workgroups per CU.  One more word -- a
     // separate slot for the popped tile id -- made it 26 granules and FOUR workgroups per CU (blend_forward 0.886 -> 0.93 ms,
@@ -331,7 +395,36 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_mask[0][0]);
     if (tile >= ntiles) return;
-    blend_forward_tile(tile, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
+    blend_forward_tile<false>(tile, 0xFu, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost,
+                              tile_queue + FW_REDO_WORD, redo_list);
+}
+
+// The exact arithmetic.  redo_list != nullptr: the tiles the fp32 path was not sure about, again (a handful per frame: DESIGN.md
+// section 3.1) -- a fixed small grid walks the list, whose length is only known on the device.  redo_list == nullptr: every tile,
+// popped from the queues like blend_forward -- the VERIFICATION mode (gof_set_forward_exact(1) / GOF_FW_EXACT=1), in which every
+// output bit is the oracle's; the bit-exact image tests run on it.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))
+blend_forward_exact(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+                    const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                    uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+                    uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ redo_list)
+{
+    __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
+    if (redo_list == nullptr) {
+        const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_mask[0][0]);
+        if (tile >= ntiles) return;
+        blend_forward_tile<true>(tile, 0xFu, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx,
+                                 tile_cost, nullptr, nullptr);
+        return;
+    }
+    const uint32_t n = min(tile_queue[FW_REDO_WORD], ntiles);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();                                  // the previous tile's epilogue has read its scratch word
+        const uint32_t entry = redo_list[i];
+        blend_forward_tile<true>(entry & 0x0FFFFFFFu, entry >> 28, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx,
+                                 tile_cost, nullptr, nullptr);
+    }
 }
 
 #ifdef GOF_TILE_CLOCK
@@ -348,8 +441,15 @@ extern "C" int gof_debug_fw_tile_clock(unsigned long long* out, int ntiles)     
 extern "C" int gof_debug_fw_stats(unsigned long long* out8, int reset)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), sizeof(g_fw_stats));
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), 8 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fw_stats), z, sizeof(z)); }
+    return 0;
+}
+extern "C" int gof_debug_fw_cert_stats(unsigned long long* out8, int reset)      // [8..15]: the certified fp32 path's `unsure` events
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), 8 * sizeof(unsigned long long), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fw_stats), z, sizeof(z), 8 * sizeof(unsigned long long)); }
     return 0;
 }
 #endif

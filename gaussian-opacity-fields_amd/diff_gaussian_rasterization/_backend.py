@@ -75,6 +75,8 @@ def _load():
     lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.gof_debug_fetch.restype = i64
     lib.gof_debug_fetch.argtypes = [C.c_char_p, A, u32, vp, vp, vp, vp, sz, vp]
+    lib.gof_set_forward_exact.argtypes = [C.c_int]
+    lib.gof_set_forward_exact.restype = C.c_int
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
     for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
@@ -569,7 +571,7 @@ _FETCH = {"depths": (torch.float32, 1), "means2D": (torch.float32, 2), "conic_op
           "view2gaussian": (torch.float32, 10), "tiles_touched": (torch.int32, 1),
           "clamped": (torch.uint8, 3), "point_list": (torch.int32, 0), "point_list_keys": (torch.int64, 0),
           "ranges": (torch.int32, 0), "point_ranges": (torch.int32, 0), "final_T": (torch.float32, 0), "n_contrib": (torch.int32, 0),
-          "contrib_pairs": (torch.int32, 0), "tile_cost": (torch.int32, 0), "tile_order": (torch.int32, 0), "tile_order_bw": (torch.int32, 0), "tile_queue": (torch.int32, 0)}
+          "contrib_pairs": (torch.int32, 0), "contrib_hash": (torch.int32, 0), "tile_cost": (torch.int32, 0), "tile_order": (torch.int32, 0), "tile_order_bw": (torch.int32, 0), "tile_queue": (torch.int32, 0)}
 
 
 def debug_fetch(name, view, num_rendered, geom, binning, img):
@@ -578,13 +580,20 @@ def debug_fetch(name, view, num_rendered, geom, binning, img):
     P, HW = view.P, view.H * view.W
     T = ((view.W + 15) // 16) * ((view.H + 15) // 16)
     count = {"point_list": _layout_count(num_rendered), "point_list_keys": _layout_count(num_rendered), "ranges": 2 * T, "point_ranges": 2 * T,
-             "final_T": 4 * HW, "n_contrib": 2 * HW, "contrib_pairs": T, "tile_cost": T, "tile_order": 8 * ((T + 7) // 8 + 128), "tile_order_bw": 8 * ((T + 7) // 8 + 128), "tile_queue": 64}.get(name, P * per)
+             "final_T": 4 * HW, "n_contrib": 2 * HW, "contrib_pairs": T, "contrib_hash": T, "tile_cost": T, "tile_order": 8 * ((T + 7) // 8 + 128), "tile_order_bw": 8 * ((T + 7) // 8 + 128), "tile_queue": 64}.get(name, P * per)
     out = torch.empty(count, dtype=dtype, device=view.device)
     n = lib.gof_debug_fetch(name.encode(), view.ref(), _layout_count(num_rendered), _ptr(geom), _ptr(binning), _ptr(img),
                             C.c_void_p(out.data_ptr()), out.numel() * out.element_size(), _stream())
     if n < 0:
         _check(int(n))
     return out
+
+
+def set_forward_exact(on):
+    """Verification mode of the forward blend (gof_set_forward_exact, include/gof_hip.h): True = every (pixel, Gaussian) pair in the
+    reference's own arithmetic (every output bit the oracle's); False (default) = fp32 values with certified decisions.  Process-wide;
+    returns the previous setting."""
+    return bool(lib.gof_set_forward_exact(1 if on else 0))
 
 
 def profile_enable(on=True):

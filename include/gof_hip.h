@@ -80,6 +80,15 @@ typedef struct GofRasterArgs {
 const char* gof_last_error(void);
 /* library / ABI version, bumped when a signature or workspace layout changes */
 int gof_abi_version(void);
+/* Verification mode of the forward blend (process-wide; returns the previous setting; initial value: 1 if the environment variable
+ * GOF_FW_EXACT=1 is set when the library is loaded, else 0).
+ *   0 (default): a (pixel, Gaussian) pair's VALUES (t, alpha, mapped depth) are evaluated in fp32; every DECISION of the reference's
+ *      renderCUDA (forward.cu:519-534, 540, 566: t <= near, alpha < 1/255, T (1 - alpha) < 1e-4, T > 0.5) is taken on the fp32
+ *      value only where it lies outside its error bound of the threshold -- a tile with a pixel that cannot tell is rendered again
+ *      in the reference's own arithmetic.  n_contrib, the contributor masks, radii, lists, ranges are those of mode 1; the float
+ *      channels agree with mode 1 to a few 1e-7 of the channel maximum.
+ *   1: every pair in the reference's arithmetic (fp64 where forward.cu widens to double): every output bit is the oracle's. */
+int gof_set_forward_exact(int on);
 
 /* ---- workspace size queries (host only) ------------------------------------------------ */
 /* replaces required<GeometryState>(P)  (rasterizer_impl.cu:277, 188-204) */

@@ -72,6 +72,10 @@ def report(src, kernel, marker, title, extra=()):
     print("\nmost frequent: " + ", ".join("%s x%d" % kv for kv in top) + "\n")
 if __name__ == "__main__":
     print("# Instruction mix of the hot loops (gfx950 assembly of the shipped sources; tests/devtools/dev_isa_hist.py)\n")
-    report("blend_forward.hip", "blend_forward", r"v_rcp_f64", "blend_forward, phase 2: one candidate (pixel, entry) pair per lane and trip")
-    report("blend_forward.hip", "blend_forward", r"v_alignbit", "blend_forward, phase 1: cull scan, 32 entries per trip (one mask word)")
-    report("blend_backward.hip", "blend_backward", r"v_permlane32_swap", "blend_backward: one visited entry per wave and trip (gradient block + wave reduction)")
+    extra = sys.argv[1:]          # e.g. -DGOF_FW_EXACT, -DGOF_FW_HWEXP: the variant builds
+    if extra:
+        print("build flags: `%s`\n" % " ".join(extra))
+    # (marker v_rsq_f32: the unit normal, present in the phase-2 / gradient loop of every variant)
+    report("blend_forward.hip", "blend_forward", r"v_rsq_f32", "blend_forward, phase 2: one candidate (pixel, entry) pair per lane and trip", extra)
+    report("blend_forward.hip", "blend_forward", r"v_alignbit", "blend_forward, phase 1: cull scan, 32 entries per trip (one mask word)", extra)
+    report("blend_backward.hip", "blend_backward", r"v_rsq_f32", "blend_backward: one visited entry per wave and trip (gradient block + wave reduction)", extra)

@@ -29,6 +29,56 @@ def settings_from(sd, debug=False, prefiltered=False):
         sh_degree=sd["sh_degree"], campos=sd["campos"], prefiltered=prefiltered, debug=debug)
 
 
+class forward_exact:
+    """with forward_exact(): ... -- the forward blend's verification mode (gof_set_forward_exact: every pair in the reference's own
+    arithmetic, every output bit the oracle's) for the calls inside; the previous mode is restored."""
+
+    def __init__(self, on=True, lib=None):
+        self.on, self.lib = on, lib
+
+    def __enter__(self):
+        if self.lib is None:
+            from diff_gaussian_rasterization import _backend as B
+            self.lib = B.lib
+        self.prev = self.lib.gof_set_forward_exact(1 if self.on else 0)
+
+    def __exit__(self, *exc):
+        self.lib.gof_set_forward_exact(self.prev)
+
+
+# fp32 value path of the forward blend (the default mode) against the exact arithmetic (measured, profiles/r04_forward_modes.md:
+# <= 5e-7 of the channel maximum on every scene of the table and at full size; asserted at 2e-6).  Channel 8 (distortion) is a
+# cancelling sum divided by (1 - T)^2 + 1e-7 whose values are small (mapped depth squared, <= 1): held to 2e-6 ABSOLUTE.
+FAST_MODE_TOL = 2e-6
+
+
+def assert_fast_mode_matches_exact(fast, exact):
+    """`fast`, `exact`: dicts of numpy arrays from the two forward modes on the same inputs -- color [9,H,W], final_T [4*HW],
+    n_contrib, contrib_hash, tile_cost, radii.  Every DECISION must be the exact arithmetic's (integer arrays equal bit for bit, the
+    contributor masks by a position-sensitive checksum per tile); the float channels within FAST_MODE_TOL."""
+    for k in ("radii", "n_contrib", "contrib_hash", "tile_cost"):
+        assert np.array_equal(fast[k], exact[k]), (k, int((fast[k] != exact[k]).sum()))
+    cf, cx = np.asarray(fast["color"], np.float64), np.asarray(exact["color"], np.float64)
+    assert np.isfinite(cf).all() == np.isfinite(cx).all()
+    ok = np.isfinite(cx)
+    for ch in range(9):
+        d = np.abs(cf[ch] - cx[ch])[ok[ch]]
+        scale = 1.0 if ch == 8 else max(1.0, float(np.abs(cx[ch][ok[ch]]).max()) if ok[ch].any() else 1.0)
+        assert d.size == 0 or d.max() <= FAST_MODE_TOL * scale, ("channel", ch, float(d.max()), scale)
+    HW = cf.shape[1] * cf.shape[2]
+    tf, tx = np.asarray(fast["final_T"], np.float64), np.asarray(exact["final_T"], np.float64)
+    assert np.abs(tf[:HW] - tx[:HW]).max() <= FAST_MODE_TOL                                      # T <= 1
+    for q in (1, 2, 3):                                                                          # dist1, dist2, distortion before normalisation
+        m = max(1.0, float(np.abs(tx[q * HW:(q + 1) * HW]).max()))
+        assert np.abs(tf[q * HW:(q + 1) * HW] - tx[q * HW:(q + 1) * HW]).max() <= FAST_MODE_TOL * m, q
+
+
+def forward_mode_arrays(res):
+    """the arrays assert_fast_mode_matches_exact compares, from a product_forward_raw result"""
+    return dict(color=res["color"].cpu().numpy(), radii=res["radii"].cpu().numpy(), final_T=fetch(res, "final_T"),
+                n_contrib=fetch(res, "n_contrib"), contrib_hash=fetch(res, "contrib_hash"), tile_cost=fetch(res, "tile_cost"))
+
+
 def product_forward_raw(sd, **over):
     """Call the native forward directly; returns dict with outputs + workspaces."""
     from diff_gaussian_rasterization import _backend as B

@@ -68,10 +68,12 @@ _FETCH_DTYPES = None
 class EmuScene:
     """One synthetic scene (synthetic_scenes.py dict) through the emulated library: forward(), backward(dL), fetch(name)."""
 
-    def __init__(self, sc, lib=None, **over):
+    def __init__(self, sc, lib=None, exact=False, **over):
+        """exact: the forward blend's verification mode (gof_set_forward_exact) for this object's forward calls"""
         from diff_gaussian_rasterization import _backend as B
         self.B = B
         self.lib = lib or load()
+        self.exact = bool(exact)
         self.sc = sc
         k = self.keep = {}
         k["bg"] = _f32(sc["bg"]); k["means3D"] = _f32(sc["means3D"]); k["opacity"] = _f32(sc["opacities"])
@@ -99,8 +101,14 @@ class EmuScene:
         if rc != 0:
             raise RuntimeError("libgof_hip_emu: " + self.lib.gof_last_error().decode(errors="replace"))
 
+    def mode_arrays(self):
+        """what gpu_common.assert_fast_mode_matches_exact compares"""
+        return dict(color=self.color, radii=self.radii, final_T=self.fetch("final_T"), n_contrib=self.fetch("n_contrib"),
+                    contrib_hash=self.fetch("contrib_hash"), tile_cost=self.fetch("tile_cost"))
+
     def forward(self):
         lib = self.lib
+        lib.gof_set_forward_exact(1 if self.exact else 0)
         self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
@@ -138,7 +146,7 @@ class EmuScene:
         P, HW = self.P, self.H * self.W
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         count = {"point_list": self.R, "point_list_keys": self.R, "ranges": 2 * T, "point_ranges": 2 * T, "final_T": 4 * HW, "n_contrib": 2 * HW,
-                 "contrib_pairs": T, "tile_cost": T, "tile_order": 8 * ((T + 7) // 8 + 128), "tile_order_bw": 8 * ((T + 7) // 8 + 128),
+                 "contrib_pairs": T, "contrib_hash": T, "tile_cost": T, "tile_order": 8 * ((T + 7) // 8 + 128), "tile_order_bw": 8 * ((T + 7) // 8 + 128),
                  "tile_queue": 64}.get(name, P * per)
         out = np.zeros(count, npdt)
         n = self.lib.gof_debug_fetch(name.encode(), C.byref(self.args), self.R, _p(self.geom), _p(self.binning), _p(self.img), _p(out), out.nbytes, None)
@@ -182,6 +190,7 @@ class EmuScene:
         self.radii = np.zeros(self.P, np.int32)
         self.color = np.zeros((9, self.H, self.W), np.float32)
         pinned = np.zeros(4, np.uint32)
+        lib.gof_set_forward_exact(1 if self.exact else 0)
         rc = lib.gof_forward_fused(C.byref(self.args), int(capacity), _p(self.geom), self.geom.size, _p(self.binning), nb, _p(self.img), self.img.size,
                                    _p(self.radii), _p(self.color), _p(pinned), None)
         self.R = int(capacity)           # the layout size: what fetch() / backward() have to be given on this path

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip
 import oracle_binding as ob  # noqa: E402
 import synthetic_scenes as S  # noqa: E402
 import test_parity_gpu as TP  # noqa: E402
-from gpu_common import bits  # noqa: E402
+from gpu_common import assert_fast_mode_matches_exact, bits  # noqa: E402
 
 build_emu = pytest.importorskip("build_emu")
 if not os.path.exists(build_emu.CXX):
@@ -38,10 +38,18 @@ MEDIUM = ["lego10k", "posed_ragged", "posed_clustered150k"]
 
 
 def _pair(sc, **over):
+    """oracle + the emulated library in BOTH forward modes: `e` = the default mode (fp32 values, certified decisions: what ships; the
+    integer arrays and the backward are checked on it), `e.exact` = the verification mode, whose image `pc` is held to the oracle's
+    bits; the two modes are compared on the way (same decisions, floats within gpu_common.FAST_MODE_TOL)."""
     o = ob.OracleScene(sc, **over)
     oc, orad = o.forward()
+    ex = E.EmuScene(sc, exact=True, **over)
+    pc, prad = ex.forward()
     e = E.EmuScene(sc, **over)
-    pc, prad = e.forward()
+    pf, prf = e.forward()
+    if e.R > 0:
+        assert_fast_mode_matches_exact(e.mode_arrays(), ex.mode_arrays())
+    e.exact_scene = ex
     return o, oc, orad, e, pc, prad
 
 
@@ -57,7 +65,7 @@ def test_emulated_forward_bit_exact(name):
         assert TP._same(a, b), arr
     for arr in TP.INT_ARRAYS:
         assert TP._same(e.fetch(arr), o.fetch(arr)), arr
-    assert np.array_equal(bits(e.fetch("final_T")), bits(o.fetch("final_T")))
+    assert np.array_equal(bits(e.exact_scene.fetch("final_T")), bits(o.fetch("final_T")))
     TP.assert_image_matches(pc, oc)
     # the tile scheduler: every tile in exactly one XCD queue, all queues consumed
     T = ((sc["W"] + 15) // 16) * ((sc["H"] + 15) // 16)
@@ -155,7 +163,7 @@ def test_emulated_fuzz_forward_integrate_backward(seed):
     assert e.R == o.num_rendered() and np.array_equal(prad, orad)
     for arr in TP.INT_ARRAYS:
         assert TP._same(e.fetch(arr), o.fetch(arr)), arr
-    assert np.array_equal(bits(e.fetch("final_T")), bits(o.fetch("final_T")))
+    assert np.array_equal(bits(e.exact_scene.fetch("final_T")), bits(o.fetch("final_T")))
     TP.assert_image_matches(pc, oc)
     dL = np.random.default_rng(seed).normal(size=oc.shape).astype(np.float32)
     go = o.backward(dL); gp = e.backward(dL)
@@ -204,7 +212,7 @@ def test_emulated_cull_audit_counts_no_dropped_pair():
     total = 0
     for sc in scenes:
         lib.gof_debug_fw_stats(out, 1)
-        e = E.EmuScene(sc, lib=lib)
+        e = E.EmuScene(sc, lib=lib, exact=True)              # (the pairs the EXACT arithmetic accepts)
         e.forward()
         lib.gof_debug_fw_stats(out, 1)
         s = list(out)

@@ -26,7 +26,7 @@ import torch
 
 import oracle_binding as ob
 import synthetic_scenes as S
-from gpu_common import bits, fetch, product_forward_raw, settings_from, to_dev
+from gpu_common import assert_fast_mode_matches_exact, bits, fetch, forward_exact, forward_mode_arrays, product_forward_raw, settings_from, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -80,8 +80,19 @@ def _forward_pair(sc, **over):
     o = ob.OracleScene(sc, **{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in over.items()
                               if k in ("colors_precomp", "cov3D_precomp", "view2gaussian_precomp")})
     oc, orad = o.forward()
-    res = product_forward_raw(to_dev(sc), **over)
+    # the product in both forward modes: res = the DEFAULT mode (fp32 values, certified decisions: what ships, what the integer
+    # arrays and the backward are checked on), res["exact"] = the verification mode (what the image's bits are held to the oracle on)
+    sd = to_dev(sc)
+    with forward_exact():
+        res_x = product_forward_raw(sd, **over)
+        torch.cuda.synchronize()
+    res = product_forward_raw(sd, **over)
     torch.cuda.synchronize()
+    if res["R"] > 0:
+        assert_fast_mode_matches_exact(forward_mode_arrays(res), forward_mode_arrays(res_x))
+    else:
+        assert torch.equal(res["color"], res_x["color"])
+    res["exact"] = res_x
     return o, oc, orad, res
 
 
@@ -147,8 +158,8 @@ def test_forward_bit_exact(name):
         assert _same(a.reshape(P, per)[vis], b.reshape(P, per)[vis]), arr
     for arr in INT_ARRAYS:
         assert _same(fetch(res, arr), o.fetch(arr)), arr
-    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_final_T_matches(fetch(res["exact"], "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
 
 
 def _fuzz_scene(seed):
@@ -181,8 +192,8 @@ def test_forward_and_integrate_fuzz_bit_exact(seed):
     assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad)
     for arr in INT_ARRAYS:
         assert _same(fetch(res, arr), o.fetch(arr)), arr
-    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_final_T_matches(fetch(res["exact"], "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
     pts = np.ascontiguousarray(S.tetra_points(sc)[:20000], dtype=np.float32)
     io, ia, icol, _ = o.integrate(pts)
     sd = to_dev(sc)
@@ -217,7 +228,7 @@ def test_forward_lower_sh_degrees(deg):
     sc = S.scene_frustum(2000, W=96, H=64, focal=70.0, seed=6)
     sc["sh_degree"] = deg
     o, oc, orad, res = _forward_pair(sc)
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
 
 
 def test_forward_precomputed_inputs():
@@ -230,7 +241,7 @@ def test_forward_precomputed_inputs():
                 cov3D_precomp=torch.from_numpy(cov).cuda())
     o2, oc2, orad2, res = _forward_pair(sc, **over)
     assert np.array_equal(orad2, orad) and np.array_equal(res["radii"].cpu().numpy(), orad)
-    pc = res["color"].cpu().numpy()
+    pc = res["exact"]["color"].cpu().numpy()
     assert_image_matches(pc, oc2)
     # precomputed inputs reproduce the computed path exactly for visible Gaussians
     assert np.array_equal(bits(oc2), bits(oc)) or np.abs(oc2 - oc).max() == 0.0
@@ -261,7 +272,7 @@ def test_backward_with_precomputed_inputs(which, mod):
         over["view2gaussian_precomp"] = torch.from_numpy(v2g).cuda()
     o, oc, orad, res = _forward_pair(base, **over)
     assert np.array_equal(res["radii"].cpu().numpy(), orad) and res["R"] == o.num_rendered()
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
     dL = np.random.default_rng(4).normal(size=oc.shape).astype(np.float32)
     go = o.backward(dL)
     gp = _product_backward(res, dL)
@@ -296,7 +307,11 @@ def test_backward_with_precomputed_inputs_through_autograd():
     o = ob.OracleScene(sc, colors_precomp=rgb, view2gaussian_precomp=v2g)
     oc, orad = o.forward()
     go = o.backward(dL.numpy())
-    assert_image_matches(color.detach().cpu().numpy(), oc)
+    with forward_exact(), torch.no_grad():      # the image's bits: verification mode (the backward above ran on the default mode's forward)
+        color_x, _ = GaussianRasterizer(settings_from(sd))(means3D=leaf["means3D"], means2D=means2D, colors_precomp=col, opacities=leaf["opacities"],
+                                                             scales=leaf["scales"], rotations=leaf["rotations"], view2gaussian_precomp=vg)
+    assert_image_matches(color_x.cpu().numpy(), oc)
+    assert (color.detach() - color_x).abs().max().item() <= 2e-6 * max(1.0, color_x.abs().max().item())
     for name, t in (("colors", col.grad), ("view2gaussian", vg.grad), ("means2D", means2D.grad), ("opacity", leaf["opacities"].grad)):
         assert_grad_close(t.cpu().numpy(), go[name], name)
 
@@ -313,7 +328,7 @@ def test_empty_and_culled():
     behind = dict(sc); behind["means3D"] = sc["means3D"].copy(); behind["means3D"][:, 2] = -1.0
     o, oc, orad, res = _forward_pair(behind)
     assert res["R"] == 0 and not res["radii"].any().item()
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
     vis = B.mark_visible(to_dev(sc)["means3D"], sd["viewmatrix"], sd["projmatrix"]).cpu().numpy()
     assert np.array_equal(vis, ob.mark_visible(sc["means3D"], sc["viewmatrix"], sc["projmatrix"]))
     vis = B.mark_visible(to_dev(behind)["means3D"], sd["viewmatrix"], sd["projmatrix"]).cpu().numpy()
@@ -385,7 +400,12 @@ def test_autograd_surface_like_render():
     o = ob.OracleScene(sc)
     oc, orad = o.forward()
     go = o.backward(dL.cpu().numpy())
-    assert_image_matches(rendered_image.detach().cpu().numpy(), oc)
+    with forward_exact(), torch.no_grad():      # the image's bits: verification mode (the backward above ran on the default mode's forward)
+        image_x, _ = rasterizer(means3D=leaf["means3D"], means2D=screenspace_points, shs=leaf["shs"], colors_precomp=None,
+                                opacities=leaf["opacities"], scales=leaf["scales"], rotations=leaf["rotations"],
+                                cov3D_precomp=None, view2gaussian_precomp=None)
+    assert_image_matches(image_x.cpu().numpy(), oc)
+    assert (rendered_image.detach() - image_x).abs().max().item() <= 2e-6 * max(1.0, image_x.abs().max().item())
     assert screenspace_points.grad is not None
     for name, t in (("means2D", screenspace_points.grad), ("opacity", leaf["opacities"].grad), ("sh", leaf["shs"].grad)):
         assert_grad_close(t.cpu().numpy(), go[name], name)
@@ -818,8 +838,8 @@ def test_full_size_s1m_against_oracle():
     assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad)
     assert _same(fetch(res, "point_list"), o.fetch("point_list"))
     assert _same(fetch(res, "n_contrib"), o.fetch("n_contrib"))
-    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_final_T_matches(fetch(res["exact"], "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
     dL = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
     go = o.backward(dL)
     gp = _product_backward(res, dL)
@@ -841,8 +861,8 @@ def test_full_size_s1m_posed_against_oracle():
     for arr in K1_ARRAYS:
         a = fetch(res, arr); b = o.fetch(arr)
         assert _same(a.reshape(P, -1)[vis], b.reshape(P, -1)[vis]), arr
-    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_final_T_matches(fetch(res["exact"], "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
     dL = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
     go = o.backward(dL)
     gp = _product_backward(res, dL)
@@ -863,8 +883,8 @@ def test_full_size_s1m_clustered_against_oracle():
     assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad) and res["R"] > 20_000_000
     assert _same(fetch(res, "point_list"), o.fetch("point_list"))
     assert _same(fetch(res, "n_contrib"), o.fetch("n_contrib"))
-    assert_final_T_matches(fetch(res, "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
-    assert_image_matches(res["color"].cpu().numpy(), oc)
+    assert_final_T_matches(fetch(res["exact"], "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
     rg = fetch(res, "ranges").view(np.uint32).reshape(-1, 2)
     L = rg[:, 1].astype(np.int64) - rg[:, 0]
     T = len(L); stride = (T + 7) // 8 + 128
@@ -941,7 +961,7 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
     names = ["s1m", "s1m_ks01", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
              "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01", "clustered150k", "posed_clustered150k"]
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib),
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib, GOF_FW_EXACT="1"),      # (audit: the pairs the EXACT arithmetic accepts)
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
