@@ -53,6 +53,20 @@ constexpr int NGRAD = 16;   // colour 3, mean2D 3, opacity 1, view2gaussian 0..8
 #endif
 constexpr int BATCH = GOF_BW_BATCH;
 static_assert(BATCH == 64 || BATCH == 128, "BATCH must be 64 or 128");
+// How the 16 per-pair values are summed over the wave (GOF_BW_REDUCE):
+//   0  in registers: transposed reduction with v_permlane32/16_swap, DPP quad levels and row rotations (rounds 2-3; ~75 VALU
+//      instructions of which 12 lane-group swaps at ~12 cycles: ~300 of the trip's 749 SIMD-cycles);
+//   1  through the LDS (round 4): every lane stores its 16 values into a [value][lane] panel of its wave (16 ds_write_b32, contiguous
+//      per instruction), then lane (v, p) = (lane / 4, lane % 4) reads back the 16 lanes 16 p .. 16 p + 15 of value v with four
+//      ds_read_b128, adds them and two DPP quad steps finish: 17 VALU instructions; the transposition is done by the LDS crossbar,
+//      which this kernel leaves idle otherwise.  Row stride 68 words: the b128 lane groups then meet 16 distinct 16-byte slots
+//      (MI355X_MICROARCH.md, LDS).  17 KB more LDS (4 x 16 x 68 words): 4 workgroups per CU (40.2 KB) instead of 5-6.
+//   2  the same in two halves of 8 values over an 8-value panel (8.5 KB: 5 workgroups per CU): lane (v, p) = (lane / 8, lane % 8) reads
+//      8 lanes' worth with two ds_read_b128, three DPP steps.
+#ifndef GOF_BW_REDUCE
+#define GOF_BW_REDUCE 1
+#endif
+constexpr int RED_STRIDE = 68;
 
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] wave iterations of the entry loop, [1] (row, iteration) pairs with
@@ -151,8 +165,12 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     __shared__ uint32_t s_inst[BATCH];                 // instance index of the staged (tile, Gaussian) pair
     __shared__ float s_slab[4][NGRAD][BATCH];          // per wave: the wave totals of the entries it visited in this batch
     __shared__ uint32_t s_vis[4][BATCH / 32];           // per wave: which entries those are
-    __shared__ uint32_t s_cm[BATCH / 32][TILE_PIX];
     __shared__ uint32_t s_max_last;
+#if GOF_BW_REDUCE == 1
+    __shared__ __attribute__((aligned(16))) float s_red[4][NGRAD][RED_STRIDE];
+#elif GOF_BW_REDUCE == 2
+    __shared__ __attribute__((aligned(16))) float s_red[4][NGRAD / 2][RED_STRIDE];
+#endif
 
     const float T_final = inside ? final_Ts[pix_id] : 0;
     float T = T_final;
@@ -222,10 +240,14 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 const uint2 rc = rect[id];
                 s_inst[tid] = inst_off[id] + (ty - (rc.x >> 16)) * (rc.y & 0xFFFFu) + (tx - (rc.x & 0xFFFFu));
             }
+        }
+        // the pixel's contributor words of this batch: read by their own thread only -- registers, not LDS
+        uint32_t cmw[BATCH / 32];
+        {
             const int nw = (n + 31) >> 5;
 #pragma unroll
             for (int q = 0; q < BATCH / 32; q++)
-                s_cm[q][tid] = (q < nw) ? cm_tile[((size_t)(p0 >> 5) + q) * TILE_PIX + tid] : 0u;
+                cmw[q] = (q < nw) ? cm_tile[((size_t)(p0 >> 5) + q) * TILE_PIX + tid] : 0u;
         }
         __syncthreads();
         if (tid == 0) BSTAT_ADD(4, n);
@@ -234,8 +256,10 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         // the OR of the 64 mask words, LDS reads of the record are broadcasts).
         const uint32_t wave = tid >> 6;
         const uint32_t slab_row = 8u * ((lane >> 1) & 1u) + 4u * (lane & 1u) + 2u * ((lane >> 4) & 1u) + (lane >> 5);   // value this lane's total belongs to
-        for (int w = ((n + 31) >> 5) - 1; w >= 0; w--) {
-            const uint32_t word = s_cm[w][tid];
+#pragma unroll
+        for (int w = BATCH / 32 - 1; w >= 0; w--) {
+            if (w > ((n + 31) >> 5) - 1) continue;                 // (wave-uniform; the loop is unrolled so that cmw[] stays in registers)
+            const uint32_t word = cmw[w];
             uint32_t todo = wave_or(word);
             uint32_t visited = todo;
 #ifdef GOF_STATS
@@ -380,6 +404,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 // does the same for odd / even rows.  16 -> 8 -> 4 live values; two DPP quad levels with selects 4 -> 2 -> 1; two row
                 // rotations finish.  Lane l ends with the wave total of value 8 b1 + 4 b0 + 2 p + h (b0, b1 = lane bits 0, 1;
                 // p = row parity; h = wave half).
+#if GOF_BW_REDUCE == 0
                 float u[8], v4[4];
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
@@ -404,6 +429,47 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     tot = tot + dpp_get<0x128>(tot);                  // row_ror:8
                 }
                 if ((lane & 12u) == 0u) s_slab[wave][slab_row][j] = tot;
+#elif GOF_BW_REDUCE == 1
+                // The wave's own panel: no other wave touches it, and the LDS serves a wave's instructions in order -- the two
+                // wave barriers only keep the compiler from moving the accesses across (no instruction).
+                {
+                    float* const panel = &s_red[wave][0][0];
+#pragma unroll
+                    for (int k = 0; k < NGRAD; k++) panel[k * RED_STRIDE + lane] = g[k];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const f4* const rp = reinterpret_cast<const f4*>(panel + (lane >> 2) * RED_STRIDE + 16u * (lane & 3u));
+                    const f4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
+                    float tot = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+                    tot = tot + dpp_get<0xB1>(tot);                   // quad_perm [1,0,3,2]
+                    tot = tot + dpp_get<0x4E>(tot);                   // quad_perm [2,3,0,1]
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();                  // (the next visit's stores come after these reads)
+                    if ((lane & 3u) == 0u) s_slab[wave][lane >> 2][j] = tot;
+                }
+#else
+                {
+                    float* const panel = &s_red[wave][0][0];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+#pragma unroll
+                        for (int k = 0; k < NGRAD / 2; k++) panel[k * RED_STRIDE + lane] = g[h * (NGRAD / 2) + k];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const f4* const rp = reinterpret_cast<const f4*>(panel + (lane >> 3) * RED_STRIDE + 8u * (lane & 7u));
+                        const f4 a = rp[0], b = rp[1];
+                        float tot = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+                        tot = tot + dpp_get<0xB1>(tot);               // quad_perm [1,0,3,2]
+                        tot = tot + dpp_get<0x4E>(tot);               // quad_perm [2,3,0,1]
+                        tot = tot + dpp_get<0x141>(tot);              // row_half_mirror: the other quad of the 8 lanes
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if ((lane & 7u) == 0u) s_slab[wave][h * (NGRAD / 2) + (lane >> 3)][j] = tot;
+                    }
+                }
+#endif
             }
             if (lane == 0) s_vis[wave][w] = visited;
         }
@@ -434,7 +500,14 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
 }
 
 // one workgroup per tile, popped as the workgroup starts: deepest walk first (pop_tile, gof_common.h; order by the forward's tile_cost)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+#if GOF_BW_REDUCE == 0
+#define GOF_BW_MIN_WAVES 5
+#elif GOF_BW_REDUCE == 1
+#define GOF_BW_MIN_WAVES 4       // the LDS (40.2 KB) allows 4 workgroups per CU: the register allocator may use 512 / 4
+#else
+#define GOF_BW_MIN_WAVES 5
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_BW_MIN_WAVES, 8)))
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,

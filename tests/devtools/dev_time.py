@@ -5,7 +5,10 @@ import numpy as np, torch
 from gpu_common import *
 import synthetic_scenes as S
 from diff_gaussian_rasterization import _backend as B
-sc = S.scene_frustum(1_000_000, seed=0)
+# usage: dev_time.py [s1m|clustered|posed]   (GOF_HIP_LIB selects a variant library, GOF_FW_EXACT=1 the forward's verification mode)
+which = sys.argv[1] if len(sys.argv) > 1 else "s1m"
+sc = {"s1m": lambda: S.scene_frustum(1_000_000, seed=0), "clustered": lambda: S.scene_clustered(1_000_000, seed=0),
+      "posed": lambda: S.scene_frustum(1_000_000, seed=0, pose_seed=21)}[which]()
 sd = to_dev(sc)
 res = product_forward_raw(sd)
 dL = torch.randn(9, sd["H"], sd["W"], device="cuda")
@@ -20,6 +23,7 @@ def timeit(fn, n=10):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return np.median(ts)
 for _ in range(3): bwd(); product_forward_raw(sd)
+print(which, "redo-list entries", int(fetch(res, "tile_queue")[16]), "of", ((sd["W"] + 15) // 16) * ((sd["H"] + 15) // 16), "tiles")
 print("fwd ms", timeit(lambda: product_forward_raw(sd)), "bwd ms", timeit(bwd))
 B.profile_enable(True)
 for _ in range(10): product_forward_raw(sd); bwd()

@@ -198,6 +198,10 @@ inline unsigned long long hipemu_ballot(int pred, const char* what)
 // build_emu.py inserts this wave barrier into its scratch copy of the source (LOCKSTEP_POINTS there lists every such place).
 inline void hipemu_wave_sync(const char* what) { uint64_t act; (void)hipemu::wave_exchange(0, &act, what); }
 #define HIPEMU_WAVE_SYNC() hipemu_wave_sync(HIPEMU_AT("lock-step point"))
+// a wave exchanging data through its own LDS panel: on the hardware the LDS serves a wave's instructions in order and the builtin
+// is a compiler barrier only; here it is where the wave's fibers meet
+#define __builtin_amdgcn_wave_barrier() hipemu_wave_sync(HIPEMU_AT("wave_barrier"))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 template <class T> inline T hipemu_shfl(T v, int src, int width, const char* what)
 {
     const int lane = (int)hipemu::t_fiber->lane;
