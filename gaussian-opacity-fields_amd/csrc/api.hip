@@ -302,7 +302,10 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
-    // (im.ranges was cleared by gather_rects in stage 1 of this frame: gof_forward_prepare / gof_forward_fused)
+    // im.ranges: gof_forward_fused ran stage 1 (gather_rects clears the ranges) in this very call.  gof_forward_render and
+    // gof_integrate_view are handed an image workspace by the caller: nothing guarantees that stage 1 of THIS frame went through it, and
+    // stale ranges would walk point_list out of bounds -- they clear it themselves (5 us on paths that read a count back anyway).
+    if (!n_dev) GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
         hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev,
@@ -644,6 +647,7 @@ int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
+    if (!rc) rc = take_async_status();       // a tile / point sort of an earlier call on this process that timed out is reported here
     if (rc) return rc;
     if (!num_integrated_host) { set_error("num_integrated_host is NULL"); return GOF_E_INVALID; }
     *num_integrated_host = 0;
@@ -674,6 +678,7 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
+    if (!rc) rc = take_async_status();       // a tile / point sort of an earlier call on this process that timed out is reported here
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
     if (!radii || !out_color) { set_error("an output / radii pointer is NULL"); return GOF_E_INVALID; }
@@ -730,6 +735,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
+    if (!rc) rc = take_async_status();       // a tile / point sort of an earlier call on this process that timed out is reported here
     if (rc) return rc;
     if (a->P == 0 || PN <= 0) return GOF_OK;     // rasterize_points.cu:301
     // the accumulating variants may leave out the image and the colour

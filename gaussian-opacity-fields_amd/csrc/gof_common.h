@@ -10,6 +10,11 @@
 #include <stddef.h>
 #include "../../include/gof_hip.h"
 
+// One target: pop_tile reads HW_REG_XCC_ID, the backward used v_permlane16/32_swap, the LDS budgets assume 160 KB per CU.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgof_hip.so is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace gof {
 
 // ---- compile-time constants of the reference (config.h:15-17, auxiliary.h:21-34) -----------

@@ -88,6 +88,17 @@ def _load():
 lib = _load()
 
 
+_grad_bucket = (0, 0, 0)      # (storage pointer, first byte, one past the last byte) of the latest backward's gradient allocation
+
+
+def is_in_grad_bucket(t):
+    """True if `t` lies in the gradient allocation of the most recent rasterizer backward (the segments of its parameter gradients).
+    train_epilogue/activations.py writes the raw-parameter gradient over an incoming gradient only then: such a tensor is this
+    library's own scratch, not a gradient autograd shares between nodes."""
+    sp, lo, hi = _grad_bucket
+    return sp != 0 and t.untyped_storage().data_ptr() == sp and lo <= t.data_ptr() and t.data_ptr() + t.numel() * t.element_size() <= hi
+
+
 def _check(rc):
     if rc != 0:
         raise RuntimeError("libgof_hip: " + lib.gof_last_error().decode(errors="replace"))
@@ -283,6 +294,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         offs.append(tot)
         tot += (n + 3) & ~3
     bucket = torch.empty(tot, **f)
+    global _grad_bucket
+    _grad_bucket = (bucket.untyped_storage().data_ptr(), bucket.data_ptr(), bucket.data_ptr() + 4 * tot)     # what is_in_grad_bucket() recognises
     g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_opacity = bucket[offs[1]:offs[1] + sizes[1]].view(P, 1)
     g_scales = bucket[offs[2]:offs[2] + sizes[2]].view(P, 3); g_rot = bucket[offs[3]:offs[3] + sizes[3]].view(P, 4)
     if v.split_sh:        # gradients in the layout of the inputs: (dL_dfeatures_dc [P,1,3], dL_dfeatures_rest [P,15,3])

@@ -25,15 +25,21 @@ _vp, _i64 = C.c_void_p, C.c_int64
 # never accumulated into in place: torch/csrc/autograd/input_buffer.cpp); so under this flag the two activations that read _scaling
 # are ONE autograd node (_ScalingOpacity: the property evaluated first computes both, the other takes its result), whose backward
 # adds the opacity path's contribution to the scaling gradient itself, in place.  If a gradient still ends up elsewhere the reducer
-# simply packs that tensor: correctness does not depend on any of this.  Off by default: a caller that keeps a reference to the
-# rasterizer's activated-parameter gradients (retain_grad, hooks) would see them overwritten.
+# simply packs that tensor: correctness does not depend on any of this.  Off by default, and supported in the launcher only: a caller
+# that keeps a reference to the rasterizer's activated-parameter gradients (retain_grad, hooks) would see them overwritten.  An
+# incoming gradient is written over ONLY if it lies in the rasterizer's own gradient allocation of the latest backward
+# (diff_gaussian_rasterization._backend.is_in_grad_bucket): any other tensor -- a gradient autograd shares between nodes (fan-out of
+# an add, a hook's copy) -- gets a fresh output, as the autograd contract demands.
 INPLACE_GRAD = False
 
 
 def _out_like(g, ref):
-    """where the raw-parameter gradient goes: over the incoming gradient under INPLACE_GRAD, else a fresh tensor"""
+    """where the raw-parameter gradient goes: over the incoming gradient under INPLACE_GRAD (if that is the rasterizer's own gradient
+    segment), else a fresh tensor"""
     if INPLACE_GRAD and g.is_contiguous() and g.dtype == torch.float32 and g.device == ref.device and g.numel() == ref.numel():
-        return g.view(ref.shape)
+        from diff_gaussian_rasterization._backend import is_in_grad_bucket
+        if is_in_grad_bucket(g):
+            return g.view(ref.shape)
     return torch.empty_like(ref)
 for _name, _n in (("gof_act_scaling", 3), ("gof_act_scaling_backward", 4), ("gof_act_opacity", 4), ("gof_act_opacity_backward", 6),
                   ("gof_act_rotation", 2), ("gof_act_rotation_backward", 3)):
@@ -117,6 +123,8 @@ class _ScalingOpacity(torch.autograd.Function):
         ro, rs, f = ctx.saved_tensors
         n = int(rs.shape[0])
         gro = grs = None
+        global _backward_epoch
+        _backward_epoch += 1          # a parked output of an older node must not be handed out any more (_fused_take)
         with torch.cuda.device(rs.device):
             if g_sc is not None:
                 g_sc = g_sc.contiguous()
@@ -131,12 +139,16 @@ class _ScalingOpacity(torch.autograd.Function):
         return gro, grs, None
 
 
+_backward_epoch = 0
+
+
 def _fused_take(model, which):
     """`which` (0 = opacity, 1 = scaling) of `model` from a _ScalingOpacity node shared with the OTHER property: whichever is read
     first computes both and parks the other output, which the other property then takes -- once, so that every node is used for
     exactly one (opacity, scaling) pair (render() reads opacity at gaussian_renderer/__init__.py:60 and scaling at :70; a property
-    read twice in a row simply starts a new node)."""
-    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (model._opacity, model._scaling, model.filter_3D)) + (torch.is_grad_enabled(),)
+    read twice in a row simply starts a new node).  The key carries the count of backwards run so far: a parked output whose node has
+    been through a backward (its graph freed) is never handed out."""
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (model._opacity, model._scaling, model.filter_3D)) + (torch.is_grad_enabled(), _backward_epoch)
     parked = getattr(model, "_gof_act_parked", None)
     model._gof_act_parked = None
     if parked is not None and parked[0] == key and parked[1] == which:

@@ -116,7 +116,8 @@ int gof_forward_prepare(const GofRasterArgs* args,
                         void* stream);
 /* Stage 2: duplicateWithKeys + stable radix sort + identifyTileRanges + forward blend
  * (rasterizer_impl.cu:344-402, forward.cu:409-612).  out_color is [9,H,W]; every pixel of
- * every channel is written. */
+ * every channel is written.  geom_ws must be the one gof_forward_prepare of THIS frame filled; image_ws need only be large
+ * enough (the tile ranges are cleared here, as the reference's cudaMemset at rasterizer_impl.cu:365 does). */
 int gof_forward_render(const GofRasterArgs* args,
                        uint32_t num_rendered,
                        const int32_t* radii,          /* [P] as written by gof_forward_prepare */
@@ -214,11 +215,17 @@ int gof_integrate_run(const GofRasterArgs* args,
  * once per bisection step and loops over all views):
  *   gof_integrate_view:   Gaussian binning + the pixel pass (5 sub-rays per pixel, forward.cu:886-1007).  Leaves records,
  *                         sorted list, tile ranges and per-pixel contributor masks in the three workspaces and the base
- *                         image (channels 0-2, 6, 7; zero-filled by the caller beforehand) in out_color.
+ *                         image (channels 0-2, 6, 7; zero-filled by the caller beforehand) in out_color.  As for
+ *                         gof_forward_render: geom_ws from gof_forward_prepare of this view, image_ws any buffer of the
+ *                         stated size (its tile ranges are cleared here).
  *   gof_integrate_points: point binning + the point pass (forward.cu:1138-1217) for one point set, after
  *                         gof_integrate_prepare_points.  Reads the workspaces a previous gof_integrate_view of the SAME
  *                         args filled (they are not modified except image_ws's point ranges); base_color is that call's
- *                         image, out_color [9,H,W] receives it plus channel 8 (points per pixel) and may alias it. */
+ *                         image, out_color [9,H,W] receives it plus channel 8 (points per pixel) and may alias it.
+ * Late errors: a point / tile sort whose bounded look-back poll expires (GPU heavily oversubscribed) leaves its ranges empty -- the
+ * launches behind it then write NOTHING, so out_alpha_integrated / out_color_integrated keep what the caller put there (pre-fill
+ * them: 1 and 0, as the reference's torch.ones / zeros at rasterize_points.cu:285-286) -- and raises a status word that the NEXT
+ * call into the library (forward, backward or integrate entry point) returns as GOF_E_DEVICE. */
 int gof_integrate_view(const GofRasterArgs* args, uint32_t num_rendered, const int32_t* radii,
                        void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes,
                        void* image_ws, size_t image_bytes, float* out_color, void* stream);
