@@ -59,12 +59,11 @@ __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
                               float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
-                              uint32_t* tile_cost, uint32_t* redo_list);
+                              uint32_t* tile_cost);
 __global__ void blend_forward_exact(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                                     float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
                                     float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
-                                    uint32_t* tile_cost, const uint32_t* redo_list);
-constexpr int FW_REDO_GRID = 1024;      // >= the list length of every scene measured (S1M: ~650 entries): one tile per workgroup, the kernel lasts one tile
+                                    uint32_t* tile_cost);
 __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
@@ -335,28 +334,17 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
     hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr);
 }
 
-// The forward blend: the fp32 value path with certified decisions over all tiles, then the tiles it was not sure about once more in
-// the reference's own arithmetic (blend_forward.hip).  The redo list lives where order_tiles_for_backward writes afterwards.
-// Verification mode (gof_set_forward_exact(1), or GOF_FW_EXACT=1 in the environment when the library is loaded): every tile in the
-// exact arithmetic -- every output bit the oracle's.
+// The forward blend.  Default: the reference's arithmetic without its two fp64 divisions per pair (blend_forward.hip: pair_nodiv_cc).
+// Verification mode (gof_set_forward_exact(1), or GOF_FW_EXACT=1 in the environment when the library is loaded): every pair with the
+// divisions -- every output bit the oracle's.
 static std::atomic<int> g_forward_exact{ [] { const char* e = getenv("GOF_FW_EXACT"); return (e && e[0] == '1') ? 1 : 0; }() };
 static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const GeomWs& g, const BinWs& b, const ImageWs& im, float* out_color, hipStream_t stream)
 {
-    if (g_forward_exact.load(std::memory_order_relaxed)) {
-        GOF_PROFILE("blend_forward", stream);
-        hipLaunchKernelGGL(blend_forward_exact, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                           im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                           im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost, nullptr);
-        return;
-    }
-    { GOF_PROFILE("blend_forward", stream);
-    hipLaunchKernelGGL(blend_forward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+    GOF_PROFILE("blend_forward", stream);
+    auto* kernel = g_forward_exact.load(std::memory_order_relaxed) ? blend_forward_exact : blend_forward;
+    hipLaunchKernelGGL(kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost, im.tile_order_bw); }
-    { GOF_PROFILE("blend_forward_redo", stream);
-    hipLaunchKernelGGL(blend_forward_exact, dim3(FW_REDO_GRID), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost, im.tile_order_bw); }
+                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
 }
 
 } // namespace gof
@@ -367,7 +355,7 @@ extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
 int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
-int gof_abi_version(void) { return 8; }   // 8: gof_set_forward_exact; the forward blend's fp32 value path (round 4)
+int gof_abi_version(void) { return 8; }   // 8: gof_set_forward_exact (round 4: the forward blend's division-free default mode)
                                           // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 

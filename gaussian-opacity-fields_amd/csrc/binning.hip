@@ -284,7 +284,6 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
         const uint32_t before = (b >= 64u) ? s_carry[x] : 0u;
         s_off[x][b] = before + inc - share;
         if (b == 127u && queue) { queue[x] = 0u; queue[NXCD + x] = before + inc; }  // head, length
-        if (tid == 0u && queue) queue[FW_REDO_WORD] = 0u;                           // blend_forward's redo list is empty
     }
     __syncthreads();
     auto place = [&](uint32_t i, bool live, uint32_t bkt, uint32_t rank, uint32_t lead_cnt) {

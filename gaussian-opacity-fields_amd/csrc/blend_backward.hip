@@ -255,7 +255,9 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         // The wave walks the union of its pixels' contributors back to front (wave-uniform entry index: scalar bit walk over
         // the OR of the 64 mask words, LDS reads of the record are broadcasts).
         const uint32_t wave = tid >> 6;
+#if GOF_BW_REDUCE == 0
         const uint32_t slab_row = 8u * ((lane >> 1) & 1u) + 4u * (lane & 1u) + 2u * ((lane >> 4) & 1u) + (lane >> 5);   // value this lane's total belongs to
+#endif
 #pragma unroll
         for (int w = BATCH / 32 - 1; w >= 0; w--) {
             if (w > ((n + 31) >> 5) - 1) continue;                 // (wave-uniform; the loop is unrolled so that cmw[] stays in registers)

@@ -48,22 +48,11 @@ namespace gof {
                              // scanning past a pixel's saturation costs less than the lane compaction of a longer candidate run gains)
 #endif
 constexpr int FW_CHUNK = GOF_FW_CHUNK;
-// the fp32 value path's exponential: the shared deterministic gexpf (default; alpha bit-identical to the exact path's whenever the
-// power is) or v_exp_f32 (-DGOF_FW_HWEXP: ~45 cycles per trip less, alpha within pair_fast_alpha_err all the same)
-#ifdef GOF_FW_HWEXP
-constexpr bool FW_HWEXP = true;
-#else
-constexpr bool FW_HWEXP = false;
-#endif
-// redo list of the certified fp32 path: blend_forward appends the tiles it is not sure about, blend_forward_redo renders them again in
-// the exact arithmetic.  Count at tile_queue[FW_REDO_WORD] (cleared by order_tiles together with the queue heads).
-
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] scanned wave-entries, [1] candidate
 // (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active,
 // [6] (GOF_CULL_AUDIT) pairs the exact path accepts that the cull scan had dropped, [7] scanned wave-entries with a candidate in the wave
-// [8..11] (certified fp32 path) pixels-events that raised `unsure`: t band, alpha band, T > 0.5 band, T < 1e-4 band; [12] tiles on the redo list, [13] their waves
-__device__ unsigned long long g_fw_stats[16];
+__device__ unsigned long long g_fw_stats[8];
 #define STAT_ADD(i, v) atomicAdd(&g_fw_stats[i], (unsigned long long)(v))
 #else
 #define STAT_ADD(i, v)
@@ -84,25 +73,23 @@ __device__ unsigned long long g_fw_tile_clock[2][1 << 16];
 #define GOF_FW_WAVES 4       // LDS bounds the occupancy at 5 workgroups per CU; asking for 4 leaves the allocator more room (88 VGPR, measured -1 %)
 #endif
 // one tile: everything below is per tile; called by all 256 threads of the workgroup.
-// EXACT = true: the value path of a pair in the reference's own arithmetic (fp64 quotients: pair_exact_cc) -- every output bit that
-//   of the oracle; the -DGOF_FW_EXACT verification build renders every tile this way, the default build the tiles on the redo list.
-// EXACT = false (default build, round 4): the value path in fp32 (pair_fast_cc, mapped_depth_fast) with CERTIFIED decisions: every
-//   comparison the exact path makes (t <= near plane, alpha < 1/255, T > 0.5, T (1 - alpha) < 1e-4) is made on the fp32 value, and
-//   whenever that value lies within its error bound of the threshold -- or an intermediate is not finite -- the pixel raises
-//   `unsure`; a wave (8x8 pixel quadrant) with an unsure pixel is put on the redo list -- (tile, wave mask) -- and rendered again by
-//   blend_forward_exact.  So n_contrib, the contributor masks and tile_cost are ALWAYS those of the exact arithmetic, and the float
-//   channels differ from it by the fp32 evaluation only (a few 1e-7 of the channel maximum; the distortion channel, a cancelling sum
-//   divided by (1 - T)^2, by its conditioning).  The transmittance carries an absolute error bound E:
-//   E' = E (1 - alpha) + T (alpha e_alpha + 1.8e-7) (alpha's relative bound e_alpha = pair_fast_alpha_err; 1.8e-7 = one ulp each for
-//   the roundings of 1 - alpha and of the product, which may fall differently in the two paths).
-// wave_mask (EXACT only): bit w set = wave w renders its quadrant; the other waves help staging, write nothing and report the
-//   cost the first pass measured.
+// EXACT = true: a pair's value path in the reference's own arithmetic, fp64 divisions included (pair_exact_cc; the mapped depth's
+//   quotient) -- every output bit that of the oracle: the VERIFICATION mode (gof_set_forward_exact(1) / GOF_FW_EXACT=1), on which
+//   the image's bit-exactness tests run.
+// EXACT = false (default, round 4): the same arithmetic without the two fp64 DIVISIONS per pair (pair_nodiv_cc: the quotient BB / AA
+//   by two fp64 corrections of the fp32 reciprocal -- faithfully rounded; the mapped depth in fp32, mapped_depth_fast).  t, alpha, T
+//   and with them every decision (t <= near, alpha < 1/255, T (1 - alpha) < 1e-4, T > 0.5), n_contrib, the contributor masks and
+//   the colour / depth / alpha channels are those of the exact path -- identical on every scene tested, see pair_nodiv_cc for when
+//   a last bit may differ --; the distortion channel and dist1 / dist2 carry the fp32 mapped depth's 1-2 ulp (a few 1e-7).
+//   (Measured first and dropped: an fp32-only value path with error-bounded decisions and a redo list for the waves that could
+//   not tell -- kernel -9 %, but 2.5 % of the waves had to be rendered again and that launch, one wave per tile, cost 0.13 ms:
+//   profiles/r04_ab_call1_*.txt, profiles/HISTORY.md.)
 template <bool EXACT>
 __device__ __forceinline__ void
-blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_mask)[TILE_PIX], const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                    const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                   uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost, uint32_t* __restrict__ redo_count, uint32_t* __restrict__ redo_list)
+                   uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost)
 {
     TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -110,8 +97,7 @@ blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_m
     uint32_t lx, ly;
     tile_pixel(tid, lx, ly);
     const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
-    const bool in_image = px < (uint32_t)W && py < (uint32_t)H;
-    const bool inside = in_image && (!EXACT || ((wave_mask >> (tid >> 6)) & 1u));      // pixels this call renders
+    const bool inside = px < (uint32_t)W && py < (uint32_t)H;
     const uint32_t pix_id = (uint32_t)W * py + px;
     const float pixfx = (float)px + 0.5f, pixfy = (float)py + 0.5f;
     const float rx = (float)(((double)pixfx - W / 2.) / (double)focal_x);
@@ -146,8 +132,7 @@ blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_m
     const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
 
     bool done = !inside;
-    bool unsure = false;                         // (EXACT = false) a decision of this pixel was too close to its threshold to call
-    float T = 1.0f, E = 0.0f;                    // E: bound on |T - the exact path's T|
+    float T = 1.0f;
     uint32_t last_contributor = 0, max_contributor = (uint32_t)-1;
     // accumulators kept as the register pairs the packed updates work on (every element sees the reference's operation
     // sequence: packed fp32 instructions are element-wise IEEE)
@@ -174,10 +159,8 @@ blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_m
         }
         __syncthreads();
         const int nwords_batch = (min(TILE_PIX, toDo) + 31) >> 5;
-        const bool wave_renders = !EXACT || ((wave_mask >> (tid >> 6)) & 1u);      // (wave-uniform)
         if (__ballot(!done) == 0ull) {             // whole wave saturated: it only helps staging (and reports "no contributors")
-            if (wave_renders)
-                for (int q = 0; q < nwords_batch; q++) cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = 0u;
+            for (int q = 0; q < nwords_batch; q++) cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = 0u;
             continue;
         }
 
@@ -259,43 +242,23 @@ blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_m
             const float n2 = n2b.x;
             const float AAf = (rn.x + rn.y) + n2b.x;
             const float BBf = 2 * n2b.y;
-            float alpha, t, test_T, mapped_max_t;
-            if constexpr (EXACT) {
-                PairEval p;
-                p.AAf = AAf; p.BBf = BBf;
-                pair_exact_cc(q3.x, q3.y, p);
-                if (p.skip) continue;
-                STAT_ADD(3, 1);
+            PairEval p;
+            p.AAf = AAf; p.BBf = BBf;
+            if constexpr (EXACT) pair_exact_cc(q3.x, q3.y, p);
+            else pair_nodiv_cc(q3.x, q3.y, p);
+            if (p.skip) continue;
+            STAT_ADD(3, 1);
 #ifdef GOF_CULL_AUDIT
-                if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
+            if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
 #endif
-                alpha = p.alpha; t = p.t;
-                test_T = T * (1 - alpha);
-                if (test_T < 0.0001f) { done = true; continue; }
+            const float alpha = p.alpha, t = p.t;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            float mapped_max_t;
+            if constexpr (EXACT) {
                 const float max_t = t;
                 mapped_max_t = (float)((GOF_FAR_PLANE * max_t - GOF_FAR_PLANE * GOF_NEAR_PLANE) / ((GOF_FAR_PLANE - GOF_NEAR_PLANE) * max_t));
             } else {
-                PairFast f;
-                pair_fast_cc<FW_HWEXP>(AAf, BBf, q3.x, q3.y, f);
-                alpha = f.alpha; t = f.t;
-                // A pair the fast value puts within its error bound of a threshold makes the pixel unsure; on the far side of the band
-                // the decision is the exact path's.  (Inside the band either branch may be taken: the tile is rendered again.)
-                // The exact path skips at (double)t <= 0.2, i.e. t < 0.2f; t here is within 1 ulp of that t (1.5e-8 at 0.2).
-                if (t < 0.2f + 6e-8f) { unsure |= t > 0.2f - 6e-8f; if (t > 0.2f - 6e-8f) STAT_ADD(8, 1); continue; }
-                const float ea = pair_fast_alpha_err(f.power, f.ph);
-                unsure |= !(fabsf(fmaf(alpha, 255.0f, -1.0f)) > ea);                      // (not-greater: a NaN / inf bound -- degenerate quadric -- is unsure)
-                if (!(fabsf(fmaf(alpha, 255.0f, -1.0f)) > ea)) STAT_ADD(9, 1);
-                if (alpha < 1.0f / 255.0f) continue;
-                STAT_ADD(3, 1);
-#ifdef GOF_CULL_AUDIT
-                if (!((s_cand[w][tid] >> b) & 1u)) STAT_ADD(6, 1);
-#endif
-                const float oma = 1 - alpha;
-                test_T = T * oma;
-                unsure |= fabsf(T - 0.5f) <= E;                                           // the median-depth decision below
-                if (fabsf(T - 0.5f) <= E) STAT_ADD(10, 1);
-                E = fmaf(E, oma, T * fmaf(alpha, ea, 1.8e-7f));
-                if (test_T < 0.0001f + E) { unsure |= test_T > 0.0001f - E; if (test_T > 0.0001f - E) STAT_ADD(11, 1); done = true; continue; }
                 mapped_max_t = mapped_depth_fast(t);
             }
             STAT_ADD(4, 1);
@@ -329,7 +292,7 @@ blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_m
         for (int q = w + 1; q < nw; q++) s_mask[q][tid] = 0u;       // candidate words this pixel never reached (it saturated)
         words_valid = nw;
         }   // chunk
-        for (int q = 0; q < nwords_batch; q++)           // (a wave that does not render has left the loop above: it is saturated from the start)
+        for (int q = 0; q < nwords_batch; q++)
             cm_tile[((size_t)i * (TILE_PIX / 32) + q) * TILE_PIX + tid] = (q < words_valid) ? s_mask[q][tid] : 0u;
     }
 
@@ -358,36 +321,28 @@ blend_forward_tile(const uint32_t tile, const uint32_t wave_mask, uint32_t (*s_m
     // what this tile cost: the deepest list position any of its pixels blended = the entries the backward stages and walks
 #ifndef GOF_NO_TILE_COST      // (developer A/B: what the epilogue costs)
     {
-        // (a quadrant this call does not render: the deepest position the first pass blended there, which is the exact arithmetic's too)
-        uint32_t m = inside ? last_contributor : ((EXACT && in_image) ? n_contrib[pix_id] : 0u);
+        uint32_t m = inside ? last_contributor : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-        uint32_t* const s_unsure = s_tile + 1;       // second scratch word (the masks are dead): waves with a pixel that was not sure
-        const bool wave_unsure = !EXACT && __ballot(unsure) != 0ull;
         __syncthreads();                            // every thread has read the popped tile id / its last mask words
-        if (tid == 0) { s_tile[0] = 0u; s_unsure[0] = 0u; }
+        if (tid == 0) *s_tile = 0u;
         __syncthreads();
-        if ((tid & 63u) == 0u) {
-            atomicMax(s_tile, m);
-            if (wave_unsure) atomicOr(s_unsure, 1u << (tid >> 6));
-        }
+        if ((tid & 63u) == 0u) atomicMax(s_tile, m);
         __syncthreads();
-        if (tid == 0) {
-            tile_cost[tile] = *s_tile;
-            if (!EXACT && *s_unsure) { redo_list[atomicAdd(redo_count, 1u)] = tile | (*s_unsure << 28); STAT_ADD(12, 1); STAT_ADD(13, __popc(*s_unsure)); }
-        }
+        if (tid == 0) tile_cost[tile] = *s_tile;
     }
 #endif
     TILE_CLOCK_END(g_fw_tile_clock);
 }
 
 // one workgroup per tile; WHICH tile is decided as the workgroup starts (pop_tile, gof_common.h): heaviest first, XCD queues of equal cost
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
-blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-              const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
-              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-              uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
-              uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost, uint32_t* __restrict__ redo_list)
+template <bool EXACT>
+__device__ __forceinline__ void
+blend_forward_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+                   const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                   uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+                   uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
     // The kernel's LDS must stay at 32 000 B: 25 allocation granules of 1280 B, five workgroups per CU.  One more word -- a
     // separate slot for the popped tile id -- made it 26 granules and FOUR workgroups per CU (blend_forward 0.886 -> 0.93 ms,
@@ -395,36 +350,26 @@ blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ poi
     __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_mask[0][0]);
     if (tile >= ntiles) return;
-    blend_forward_tile<false>(tile, 0xFu, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost,
-                              tile_queue + FW_REDO_WORD, redo_list);
+    blend_forward_tile<EXACT>(tile, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
 }
-
-// The exact arithmetic.  redo_list != nullptr: the tiles the fp32 path was not sure about, again (a handful per frame: DESIGN.md
-// section 3.1) -- a fixed small grid walks the list, whose length is only known on the device.  redo_list == nullptr: every tile,
-// popped from the queues like blend_forward -- the VERIFICATION mode (gof_set_forward_exact(1) / GOF_FW_EXACT=1), in which every
-// output bit is the oracle's; the bit-exact image tests run on it.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
+blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
+              const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
+              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+              uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+              uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
+{
+    blend_forward_body<false>(ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, ntiles, tile_order, tile_queue, tile_cost);
+}
+// the verification mode (gof_set_forward_exact(1) / GOF_FW_EXACT=1): every pair in the reference's own arithmetic
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))
 blend_forward_exact(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                     const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                     uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
-                    uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost, const uint32_t* __restrict__ redo_list)
+                    uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
-    __shared__ uint32_t s_mask[TILE_PIX / 32][TILE_PIX];
-    if (redo_list == nullptr) {
-        const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_mask[0][0]);
-        if (tile >= ntiles) return;
-        blend_forward_tile<true>(tile, 0xFu, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx,
-                                 tile_cost, nullptr, nullptr);
-        return;
-    }
-    const uint32_t n = min(tile_queue[FW_REDO_WORD], ntiles);
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        __syncthreads();                                  // the previous tile's epilogue has read its scratch word
-        const uint32_t entry = redo_list[i];
-        blend_forward_tile<true>(entry & 0x0FFFFFFFu, entry >> 28, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx,
-                                 tile_cost, nullptr, nullptr);
-    }
+    blend_forward_body<true>(ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, ntiles, tile_order, tile_queue, tile_cost);
 }
 
 #ifdef GOF_TILE_CLOCK
@@ -441,15 +386,8 @@ extern "C" int gof_debug_fw_tile_clock(unsigned long long* out, int ntiles)     
 extern "C" int gof_debug_fw_stats(unsigned long long* out8, int reset)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), 8 * sizeof(unsigned long long));
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), sizeof(g_fw_stats));
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fw_stats), z, sizeof(z)); }
-    return 0;
-}
-extern "C" int gof_debug_fw_cert_stats(unsigned long long* out8, int reset)      // [8..15]: the certified fp32 path's `unsure` events
-{
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_stats), 8 * sizeof(unsigned long long), 8 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fw_stats), z, sizeof(z), 8 * sizeof(unsigned long long)); }
     return 0;
 }
 #endif

@@ -68,11 +68,9 @@ struct ImageWs {
     uint32_t* tile_queue;   // [TILE_QUEUE_WORDS] [0..7] heads / [8..15] lengths of the forward-side queues, [32..47] the backward's lengths (its heads: scratch)
     uint32_t* tile_cost;    // [T] what blend_forward measured per tile (entries walked): the backward's cost
     uint32_t* tile_order_bw;// [8][tile_queue_stride(T)] dispatch order of blend_backward: by tile_cost (deepest walk first), written after the forward blend
-                            // (until then its first T words hold blend_forward's redo list: tiles to render again in the exact arithmetic)
 };
 constexpr int NXCD = 8;
 constexpr int TILE_QUEUE_WORDS = 64;
-constexpr int FW_REDO_WORD = 16;       // tile_queue[16]: number of tiles on blend_forward's redo list (cleared by order_tiles with the heads)
 // Binning workspace (replaces BinningState, rasterizer_impl.h:69-79)
 struct BinWs {
     uint32_t* vals;  uint32_t* vals_alt;          // [R]  vals = sorted point_list (Gaussian ids, per tile, front to back)
@@ -432,46 +430,42 @@ __device__ __forceinline__ void pair_exact_backward_cc(float CC, float w, PairEv
     p.alpha = fminf(0.99f, w * p.G);
     p.skip = false;
 }
-// The FORWARD's value path in fp32 only (round 4; blend_forward's default build, the fp64 form above stays as the verification build
-// -DGOF_FW_EXACT and as the re-render of the tiles this form is not sure about).  Same hi + lo evaluation as the backward's, plus
-// what a forward needs on top: every quantity a DECISION hangs on comes with a bound on its distance from the exact path's value, so
-// the caller can tell "same decision as the exact path, certainly" from "too close to call" (the tile is then rendered again by the
-// exact kernel).
-//   t      = -0.5 fl(qh + ql), qh + ql = BB/AA to ~2^-44 (v_rcp_f32 + one FMA remainder): FAITHFUL, i.e. <= 1 ulp from the exact
-//            path's correctly rounded value (the fp64 quotient rounded to fp32 IS the correctly rounded fp32 quotient, 53 >= 2 * 24 + 2)
-//   power  = -0.5 ((CC - ph) - pl), (ph, pl) = (qh + ql) * BB/4 as an fp32 pair: |power - exact| <= 1.5 ulp(power) + 2^-43 |ph|
-//            (the exact path's own fp64 roundings, 2^-52 |ph|, are inside that)
-//   alpha  = min(0.99, w G(power)), relative distance from the exact path's alpha <= pair_fast_alpha_err(power, ph):
-//            |d power| <= 1.8e-7 |power| + 2^-43 |ph| (two half-ulp roundings of min_value in each path where CC - ph does not
-//            cancel exactly, the pair product's 2^-43 |ph|), the exponential's 1 ulp in each path and the product w G's rounding in
-//            each path (3.6e-7 together; v_exp_f32 under -DGOF_FW_HWEXP: 1 ulp + the rounding of power log2(e), inside the first
-//            term's slack); G by the shared deterministic gexpf (default: alpha is then BIT-identical to the exact path's whenever
-//            power is) or by v_exp_f32
-// A degenerate quadric (AA = 0, denormal, NaN) shows up as a non-finite ph: pair_fast_alpha_err is then inf / NaN and the caller's
-// alpha test, written as !(distance > bound), calls the pair unsure.
-struct PairFast {
-    float t, alpha, ph, power;
-};
-template <bool HW_EXP>
-__device__ __forceinline__ void pair_fast_cc(float AAf, float BBf, float CC, float w, PairFast& o)
+// The FORWARD's default value path (round 4): the exact path's own fp64 arithmetic with the one expensive instruction sequence taken
+// out -- the fp64 DIVISION BB / AA (v_rcp_f64 at quarter rate + two Newton steps on the reciprocal + the scaling / fix-up
+// instructions: ~14 of the ~37 fp64 instructions of a pair, and a second one for the mapped depth).  The quotient is formed from
+// the fp32 reciprocal instead: q0 = fl32(BB * rcp(AA)) (2^-22), then two corrections q <- q + (BB - q AA) y in fp64 with
+// y = (double)rcp(AA): the error contracts by |AA y - 1| <= 2^-23 each time, 2^-45 then 2^-68, i.e. q is the FAITHFULLY rounded
+// fp64 quotient -- the correctly rounded one except where the true quotient lies within 2^-68 |q| of a rounding boundary (a fraction
+// 2^-14 of the pairs), and then its neighbour.  Everything behind it is the exact path's code.  What that last bit of q can change:
+// power = fl32(-min_value / 2) moves by one fp32 ulp only if min_value also lies within 2^-52 |BB^2 / 4 AA| of an fp32 rounding
+// boundary -- 2^-14 x ~1e-3 at S1M's conditioning, a handful of pairs per 1.2e8; measured: 0 differing n_contrib / contributor
+// masks / colour bits on every scene of the test table and at full size (tests/: both modes are run side by side).
+// A quotient the fp32 reciprocal cannot start (AA zero / denormal, an overflowing quotient, NaN) takes the true division: the
+// degenerate cases keep the reference's IEEE semantics.
+__device__ __forceinline__ void pair_nodiv_cc(float CC, float w, PairEval& p)
 {
-    const float ra = __builtin_amdgcn_rcpf(AAf);
-    const float qh = BBf * ra;                                    // within 1.5 ulp
-    const float ql = fmaf(-qh, AAf, BBf) * ra;                    // its remainder: qh + ql = BB/AA to ~2^-44
-    const float b4 = BBf * 0.25f;
-    const float ph = qh * b4;
-    const float pl = fmaf(ql, b4, fmaf(qh, b4, -ph));             // (qh + ql) * b4 = ph + pl
-    const float mv = (CC - ph) - pl;                              // CC - ph exact (Sterbenz) where it cancels
-    o.t = -0.5f * (qh + ql);
-    o.ph = ph;
-    float power = -0.5f * mv;
+    const float ra = __builtin_amdgcn_rcpf(p.AAf);
+    const float qh = p.BBf * ra;
+    const double AA = (double)p.AAf, BB = (double)p.BBf;
+    double q;
+    if (fabsf(qh) < 3e38f && fabsf(ra) < 3e38f) {        // (false for inf / NaN too)
+        const double y = (double)ra;
+        q = (double)qh;
+        q = fma(fma(-q, AA, BB), y, q);
+        q = fma(fma(-q, AA, BB), y, q);
+    } else {
+        q = BB / AA;
+    }
+    p.q = q;
+    p.t = -0.5f * (float)q;                               // == (float)(-q * 0.5): the scaling is exact
+    p.skip = p.t < 0.2f;                                  // (double)t <= 0.2  <=>  t < 0.2f  (0.2f is the fp32 above 0.2; NaN: neither)
+    const double min_value = (-q) * (BB * 0.25) + (double)CC;
+    float power = (float)(-0.5 * min_value);
     if (power > 0.0f) power = 0.0f;
-    o.power = power;
-    const float G = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gexpf(power);
-    o.alpha = fminf(0.99f, w * G);
+    p.G = gexpf(power);
+    p.alpha = fminf(0.99f, w * p.G);
+    if (p.alpha < 1.0f / 255.0f) p.skip = true;
 }
-// relative bound on |alpha_fast - alpha_exact| (see above; 2^-43 = 1.14e-13)
-__device__ __forceinline__ float pair_fast_alpha_err(float power, float ph) { return fmaf(fabsf(ph), 1.2e-13f, fmaf(fabsf(power), 1.8e-7f, 3.7e-7f)); }
 // mapped depth (forward.cu:545) m = (FAR t - FAR NEAR) / ((FAR - NEAR) t) = c1 - c2 / t in fp32 (v_rcp_f32, one FMA): within
 // 1.2e-7 c2 / t + 1 ulp of the exact path's fp64 quotient, i.e. <= 2 ulp at the near plane, 1 ulp from t ~ 1 on (no decision
 // depends on it; the backward evaluates the same form)

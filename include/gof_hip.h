@@ -82,12 +82,12 @@ const char* gof_last_error(void);
 int gof_abi_version(void);
 /* Verification mode of the forward blend (process-wide; returns the previous setting; initial value: 1 if the environment variable
  * GOF_FW_EXACT=1 is set when the library is loaded, else 0).
- *   0 (default): a (pixel, Gaussian) pair's VALUES (t, alpha, mapped depth) are evaluated in fp32; every DECISION of the reference's
- *      renderCUDA (forward.cu:519-534, 540, 566: t <= near, alpha < 1/255, T (1 - alpha) < 1e-4, T > 0.5) is taken on the fp32
- *      value only where it lies outside its error bound of the threshold -- a tile with a pixel that cannot tell is rendered again
- *      in the reference's own arithmetic.  n_contrib, the contributor masks, radii, lists, ranges are those of mode 1; the float
- *      channels agree with mode 1 to a few 1e-7 of the channel maximum.
- *   1: every pair in the reference's arithmetic (fp64 where forward.cu widens to double): every output bit is the oracle's. */
+ *   0 (default): the arithmetic of the reference's renderCUDA (forward.cu:504-557) WITHOUT its two fp64 divisions per (pixel,
+ *      Gaussian) pair: the quotient BB / AA comes from the fp32 reciprocal corrected twice in fp64 (faithfully rounded; everything
+ *      behind it -- t, min_value, alpha, T, every threshold decision -- is evaluated as in mode 1), the mapped depth in fp32.
+ *      n_contrib, contributor masks, colour / depth / alpha channels: those of mode 1 on every scene tested (a last bit of one pair
+ *      in ~1e7 may differ: csrc/gof_common.h, pair_nodiv_cc); distortion channel within a few 1e-7.
+ *   1: every pair in the reference's arithmetic as written (fp64 where forward.cu widens to double): every output bit is the oracle's. */
 int gof_set_forward_exact(int on);
 
 /* ---- workspace size queries (host only) ------------------------------------------------ */

@@ -46,31 +46,39 @@ class forward_exact:
         self.lib.gof_set_forward_exact(self.prev)
 
 
-# fp32 value path of the forward blend (the default mode) against the exact arithmetic (measured, profiles/r04_forward_modes.md:
-# <= 5e-7 of the channel maximum on every scene of the table and at full size; asserted at 2e-6).  Channel 8 (distortion) is a
-# cancelling sum divided by (1 - T)^2 + 1e-7 whose values are small (mapped depth squared, <= 1): held to 2e-6 ABSOLUTE.
+# The forward blend's default mode (the reference's arithmetic without its two fp64 divisions per pair: csrc/gof_common.h,
+# pair_nodiv_cc) against the verification mode.  t, alpha and T are the exact arithmetic's up to a last bit of one pair in ~1e7, so:
+# every decision identical; colour / normal / depth / alpha channels and final_T bit-identical on all but a vanishing number of pixels
+# (measured: none anywhere, profiles/r04_forward_modes.md); the distortion channel, dist1 and dist2 carry the fp32 mapped depth's
+# 1-2 ulp: measured <= 2.5e-7 absolute, asserted at 2e-6 (mapped depth <= 1).
 FAST_MODE_TOL = 2e-6
 
 
 def assert_fast_mode_matches_exact(fast, exact):
     """`fast`, `exact`: dicts of numpy arrays from the two forward modes on the same inputs -- color [9,H,W], final_T [4*HW],
     n_contrib, contrib_hash, tile_cost, radii.  Every DECISION must be the exact arithmetic's (integer arrays equal bit for bit, the
-    contributor masks by a position-sensitive checksum per tile); the float channels within FAST_MODE_TOL."""
+    contributor masks by a position-sensitive checksum per tile); channels 0-7 and T bit-identical on all but <= max(2, 1e-6 HW)
+    pixels and within FAST_MODE_TOL there; the distortion quantities within FAST_MODE_TOL."""
     for k in ("radii", "n_contrib", "contrib_hash", "tile_cost"):
         assert np.array_equal(fast[k], exact[k]), (k, int((fast[k] != exact[k]).sum()))
-    cf, cx = np.asarray(fast["color"], np.float64), np.asarray(exact["color"], np.float64)
-    assert np.isfinite(cf).all() == np.isfinite(cx).all()
-    ok = np.isfinite(cx)
-    for ch in range(9):
-        d = np.abs(cf[ch] - cx[ch])[ok[ch]]
-        scale = 1.0 if ch == 8 else max(1.0, float(np.abs(cx[ch][ok[ch]]).max()) if ok[ch].any() else 1.0)
-        assert d.size == 0 or d.max() <= FAST_MODE_TOL * scale, ("channel", ch, float(d.max()), scale)
+    cf, cx = np.asarray(fast["color"], np.float32), np.asarray(exact["color"], np.float32)
     HW = cf.shape[1] * cf.shape[2]
-    tf, tx = np.asarray(fast["final_T"], np.float64), np.asarray(exact["final_T"], np.float64)
-    assert np.abs(tf[:HW] - tx[:HW]).max() <= FAST_MODE_TOL                                      # T <= 1
+    allowed = max(2, int(1e-6 * HW))
+    for ch in range(9):
+        a, b = cf[ch].ravel(), cx[ch].ravel()
+        differ = bits(a) != bits(b)
+        if ch != 8:
+            assert int(differ.sum()) <= allowed, ("channel", ch, "pixels with different bits", int(differ.sum()))
+        if differ.any():
+            assert np.isfinite(a[differ]).all() and np.isfinite(b[differ]).all(), ("channel", ch, "a non-finite value differs")
+            d = np.abs(a[differ].astype(np.float64) - b[differ])
+            scale = 1.0 if ch == 8 else max(1.0, float(np.abs(b[np.isfinite(b)]).max()))
+            assert d.max() <= FAST_MODE_TOL * scale, ("channel", ch, float(d.max()), scale)
+    tf, tx = np.asarray(fast["final_T"], np.float32), np.asarray(exact["final_T"], np.float32)
+    assert int((bits(tf[:HW]) != bits(tx[:HW])).sum()) <= allowed and np.abs(tf[:HW].astype(np.float64) - tx[:HW]).max() <= FAST_MODE_TOL
     for q in (1, 2, 3):                                                                          # dist1, dist2, distortion before normalisation
         m = max(1.0, float(np.abs(tx[q * HW:(q + 1) * HW]).max()))
-        assert np.abs(tf[q * HW:(q + 1) * HW] - tx[q * HW:(q + 1) * HW]).max() <= FAST_MODE_TOL * m, q
+        assert np.abs(tf[q * HW:(q + 1) * HW].astype(np.float64) - tx[q * HW:(q + 1) * HW]).max() <= FAST_MODE_TOL * m, q
 
 
 def forward_mode_arrays(res):
