@@ -337,6 +337,9 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
 // The forward blend.  Default: the reference's arithmetic without its two fp64 divisions per pair (blend_forward.hip: pair_nodiv_cc).
 // Verification mode (gof_set_forward_exact(1), or GOF_FW_EXACT=1 in the environment when the library is loaded): every pair with the
 // divisions -- every output bit the oracle's.
+// tile rectangle of a Gaussian intersected with its footprint box (opt-in: gof_set_tight_tile_rects / GOF_TIGHT_RECTS=1; preprocess.hip)
+static std::atomic<int> g_tight_rects{ [] { const char* e = getenv("GOF_TIGHT_RECTS"); return (e && e[0] == '1') ? 1 : 0; }() };
+
 static std::atomic<int> g_forward_exact{ [] { const char* e = getenv("GOF_FW_EXACT"); return (e && e[0] == '1') ? 1 : 0; }() };
 static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const GeomWs& g, const BinWs& b, const ImageWs& im, float* out_color, hipStream_t stream)
 {
@@ -355,6 +358,7 @@ extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
 int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
+int gof_set_tight_tile_rects(int on) { return g_tight_rects.exchange(on ? 1 : 0); }
 int gof_abi_version(void) { return 8; }   // 8: gof_set_forward_exact (round 4: the forward blend's division-free default mode)
                                           // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
@@ -375,7 +379,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
-                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, a->prefiltered, radii, g.depths, g.rec, g.conic, g.bbox, g.fconic,
+                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, (a->prefiltered ? 1 : 0) | (g_tight_rects.load(std::memory_order_relaxed) ? 2 : 0), radii, g.depths, g.rec, g.conic, g.bbox, g.fconic,
                        g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)

@@ -75,8 +75,8 @@ def _load():
     lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.gof_debug_fetch.restype = i64
     lib.gof_debug_fetch.argtypes = [C.c_char_p, A, u32, vp, vp, vp, vp, sz, vp]
-    lib.gof_set_forward_exact.argtypes = [C.c_int]
-    lib.gof_set_forward_exact.restype = C.c_int
+    lib.gof_set_forward_exact.argtypes = lib.gof_set_tight_tile_rects.argtypes = [C.c_int]
+    lib.gof_set_forward_exact.restype = lib.gof_set_tight_tile_rects.restype = C.c_int
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
     for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
@@ -607,6 +607,13 @@ def set_forward_exact(on):
     reference's own arithmetic (every output bit the oracle's); False (default) = fp32 values with certified decisions.  Process-wide;
     returns the previous setting."""
     return bool(lib.gof_set_forward_exact(1 if on else 0))
+
+
+def set_tight_tile_rects(on):
+    """Opt-in tile lists (gof_set_tight_tile_rects, include/gof_hip.h): a Gaussian's tile rectangle intersected with its footprint
+    box -- same image and gradients from shorter lists, which are then no longer the reference's entry for entry.  Process-wide;
+    returns the previous setting."""
+    return bool(lib.gof_set_tight_tile_rects(1 if on else 0))
 
 
 def profile_enable(on=True):

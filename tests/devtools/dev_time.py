@@ -23,7 +23,7 @@ def timeit(fn, n=10):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return np.median(ts)
 for _ in range(3): bwd(); product_forward_raw(sd)
-print(which, "redo-list entries", int(fetch(res, "tile_queue")[16]), "of", ((sd["W"] + 15) // 16) * ((sd["H"] + 15) // 16), "tiles")
+print(which, "instances", int(res["R"]))
 print("fwd ms", timeit(lambda: product_forward_raw(sd)), "bwd ms", timeit(bwd))
 B.profile_enable(True)
 for _ in range(10): product_forward_raw(sd); bwd()

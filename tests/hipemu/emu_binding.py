@@ -68,12 +68,14 @@ _FETCH_DTYPES = None
 class EmuScene:
     """One synthetic scene (synthetic_scenes.py dict) through the emulated library: forward(), backward(dL), fetch(name)."""
 
-    def __init__(self, sc, lib=None, exact=False, **over):
-        """exact: the forward blend's verification mode (gof_set_forward_exact) for this object's forward calls"""
+    def __init__(self, sc, lib=None, exact=False, tight=False, **over):
+        """exact: the forward blend's verification mode (gof_set_forward_exact) for this object's forward calls;
+        tight: the opt-in tile lists (gof_set_tight_tile_rects)"""
         from diff_gaussian_rasterization import _backend as B
         self.B = B
         self.lib = lib or load()
         self.exact = bool(exact)
+        self.tight = bool(tight)
         self.sc = sc
         k = self.keep = {}
         k["bg"] = _f32(sc["bg"]); k["means3D"] = _f32(sc["means3D"]); k["opacity"] = _f32(sc["opacities"])
@@ -109,9 +111,11 @@ class EmuScene:
     def forward(self):
         lib = self.lib
         lib.gof_set_forward_exact(1 if self.exact else 0)
+        lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
+        lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
         self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
@@ -161,6 +165,7 @@ class EmuScene:
         self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
+        lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
         self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
@@ -191,6 +196,7 @@ class EmuScene:
         self.color = np.zeros((9, self.H, self.W), np.float32)
         pinned = np.zeros(4, np.uint32)
         lib.gof_set_forward_exact(1 if self.exact else 0)
+        lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         rc = lib.gof_forward_fused(C.byref(self.args), int(capacity), _p(self.geom), self.geom.size, _p(self.binning), nb, _p(self.img), self.img.size,
                                    _p(self.radii), _p(self.color), _p(pinned), None)
         self.R = int(capacity)           # the layout size: what fetch() / backward() have to be given on this path
@@ -202,6 +208,7 @@ class EmuScene:
         self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
+        lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
         self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")

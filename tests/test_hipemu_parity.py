@@ -408,16 +408,15 @@ def test_emulated_staged_entry_points_equal_the_one_call_forms():
 
 
 def test_emulated_tight_tile_rectangles_variant_changes_no_output():
-    """-DGOF_TIGHT_RECTS (developer A/B, not the shipped build, which keeps the reference's tile lists entry for entry): a Gaussian is
+    """gof_set_tight_tile_rects(1) (opt-in; the default keeps the reference's tile lists entry for entry): a Gaussian is
     binned only into the tiles of its 3-sigma square (auxiliary.h:64-74) that its footprint box -- widened by the pixel the opacity
     query's corner sub-rays need -- can reach.  Lists shrink (S1M: 8.84 M -> 6.99 M instances, 505 -> 439 entries scanned per pixel);
     image, state, radii and the opacity query stay bit-identical, gradients equal up to the summation order of the per-Gaussian gather."""
-    tight = E.load(extra_flags=("-DGOF_TIGHT_RECTS",), tag="tight")
     scenes = [TP.SCENES[k]() for k in ("small_ks01", "posed_mod2", "posed_stress_box", "posed_long_lists", "posed_ragged")] + [TP._fuzz_scene(s) for s in (0, 9, 11, 13, 17, 21, 26, 29, 31, 38)]
     shrunk = 0
     for sc in scenes:
         e0 = E.EmuScene(sc); c0, r0 = e0.forward()
-        e1 = E.EmuScene(sc, lib=tight); c1, r1 = e1.forward()
+        e1 = E.EmuScene(sc, tight=True); c1, r1 = e1.forward()
         assert np.array_equal(bits(c0), bits(c1)) and np.array_equal(r0, r1) and np.array_equal(bits(e0.fetch("final_T")), bits(e1.fetch("final_T")))
         assert e1.R <= e0.R
         shrunk += e1.R < e0.R
@@ -426,6 +425,6 @@ def test_emulated_tight_tile_rectangles_variant_changes_no_output():
         for k in ("means2D", "colors", "opacity", "view2gaussian", "sh"):
             assert np.abs(g0[k] - g1[k]).max() <= 2e-6 * max(np.abs(g0[k]).max(), 1e-30), k
         pts = np.ascontiguousarray(S.tetra_points(sc)[:20000], dtype=np.float32)
-        for a, b in zip(E.EmuScene(sc).integrate(pts)[:3], E.EmuScene(sc, lib=tight).integrate(pts)[:3]):
+        for a, b in zip(E.EmuScene(sc).integrate(pts)[:3], E.EmuScene(sc, tight=True).integrate(pts)[:3]):
             assert np.array_equal(bits(a), bits(b))
     assert shrunk >= len(scenes) - 1

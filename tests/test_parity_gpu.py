@@ -946,6 +946,44 @@ def test_full_size_properties_s1m():
     assert torch.equal(res["color"], res2["color"])
 
 
+@pytest.mark.parametrize("name", ["small_ks01", "posed_ragged", "posed_stress_box", "clustered150k", "posed_mod2", "s1m"])
+def test_tight_tile_rectangles_change_no_output(name):
+    """gof_set_tight_tile_rects(1) (opt-in; the default keeps the reference's lists entry for entry): a Gaussian is binned only into
+    the tiles of its 3-sigma square (auxiliary.h:64-74) that its footprint box can reach.  The lists shrink (S1M: 8.84 M -> 6.99 M
+    instances); image, final_T, radii, n_contrib per pixel's contributors' identity and the opacity query stay bit-identical, the
+    gradients equal up to the summation order of the per-Gaussian gather."""
+    from diff_gaussian_rasterization import _backend as B
+    sc = S.scene_frustum(1_000_000, seed=0) if name == "s1m" else SCENES[name]()
+    sd = to_dev(sc)
+    base = product_forward_raw(sd)
+    prev = B.set_tight_tile_rects(True)
+    try:
+        tight = product_forward_raw(sd)
+        torch.cuda.synchronize()
+    finally:
+        B.set_tight_tile_rects(prev)
+    assert tight["R"] <= base["R"] and (name in ("small_ks01",) or tight["R"] < base["R"])
+    assert torch.equal(tight["color"], base["color"]) and torch.equal(tight["radii"], base["radii"])
+    assert _same(fetch(tight, "final_T"), fetch(base, "final_T"))
+    assert np.array_equal(fetch(tight, "contrib_pairs"), fetch(base, "contrib_pairs"))        # the same number of contributing pairs per tile
+    dL = np.random.default_rng(5).normal(size=(9, sd["H"], sd["W"])).astype(np.float32)
+    g0, g1 = _product_backward(base, dL), _product_backward(tight, dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian", "sh"):
+        assert np.abs(g0[k] - g1[k]).max() <= 2e-6 * max(np.abs(g0[k]).max(), 1e-30), k
+    if name != "s1m":
+        from diff_gaussian_rasterization import GaussianRasterizer
+        pts = torch.from_numpy(np.ascontiguousarray(S.tetra_points(sc)[:200_000], dtype=np.float32)).cuda()
+        kw = dict(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+        want = GaussianRasterizer(settings_from(sd)).integrate(**kw)
+        prev = B.set_tight_tile_rects(True)
+        try:
+            got = GaussianRasterizer(settings_from(sd)).integrate(**kw)
+        finally:
+            B.set_tight_tile_rects(prev)
+        for a, b in zip(got[:3], want[:3]):
+            assert torch.equal(a, b)
+
+
 def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     """The forward's footprint-conic scan is a prefilter with an error allowance (csrc/preprocess.hip: footprint_bbox); bit-exactness
     of the image already implies that it drops no CONTRIBUTING pair, this audit counts it directly and also covers pairs behind a
