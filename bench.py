@@ -23,28 +23,41 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 
-PMC_FILE = "r03_pmc_traffic_s1m.json"
+PMC_FILE = "r04_pmc_traffic_s1m.json"
 FLOP_PER_PAIR_FWD = 85       # forward.cu:504-575 per contributing pair
 FLOP_PER_PAIR_BWD = 190      # backward.cu:771-952 per contributing pair, incl. its 19 accumulating adds
 
+# which translation unit a profiled kernel (its GOF_PROFILE scope / its name in a rocprofv3 trace) is compiled from: a committed
+# counter pass is quoted for a kernel only while the hash of THAT file + the shared headers is the one the pass was collected on
+KERNEL_SOURCES = {
+    "blend_forward": "blend_forward.hip", "blend_forward_exact": "blend_forward.hip",
+    "blend_backward": "blend_backward.hip", "gather_tile_partials": "blend_backward.hip",
+    "preprocess_fwd": "preprocess.hip", "preprocess_bwd": "preprocess.hip", "preprocess_points": "preprocess.hip",
+    "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_rects": "binning.hip",
+    "point_keys": "binning.hip", "gather_sorted_points": "binning.hip",
+    "os_hist": "radix.hip", "os_pass": "radix.hip", "rs_hist": "radix.hip", "rs_scatter": "radix.hip", "scan_block": "radix.hip",
+    "integrate_pixels": "integrate.hip", "integrate_points": "integrate.hip",
+}
+SHARED_HEADERS = ("gof_common.h", "gof_status.h")
+
 
 def kernel_sha16(kernel=None):
-    """Hash of the sources of the two blend kernels (+ the shared header) -- or, with `kernel`, of that kernel's file + the header:
-    identifies what a committed PMC pass was collected on."""
+    """Hash of the source a kernel is compiled from (its .hip file + the shared headers) -- or, without `kernel`, of the two blend
+    kernels' files: identifies what a committed PMC pass was collected on."""
     import hashlib
     h = hashlib.sha256()
-    files = ("blend_forward.hip", "blend_backward.hip", "gof_common.h") if kernel is None else (kernel + ".hip", "gof_common.h")
-    for f in files:
-        h.update(open(os.path.join(ROOT, "gaussian-opacity-fields_amd", "csrc", f), "rb").read())
+    files = ("blend_forward.hip", "blend_backward.hip") if kernel is None else (KERNEL_SOURCES.get(kernel, kernel + ".hip"),)
+    for f in tuple(files) + SHARED_HEADERS:
+        path = os.path.join(ROOT, "gaussian-opacity-fields_amd", "csrc", f)
+        if os.path.exists(path):
+            h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 
 def pmc_pass_is_current(pmc_all, kernel):
-    """Was the committed counter pass collected on the code `kernel` has now?  Either the recorded source hash of that kernel's file
-    (+ header) is the current one, or the current one is listed as a later source state with the SAME default-build gfx950 code
-    (edits under developer-only #ifdefs; established by tests/devtools/dev_same_isa.py)."""
-    if kernel_sha16() in [pmc_all.get("_kernel_sha16")] + list(pmc_all.get("_same_isa_sha16", [])):
-        return True
+    """Was the committed counter pass collected on the code `kernel` has now?  The recorded source hash of that kernel's translation
+    unit (+ shared headers) is the current one, or the current one is listed as a later source state with the SAME default-build
+    gfx950 code (edits under developer-only #ifdefs; established by tests/devtools/dev_same_isa.py)."""
     cur = kernel_sha16(kernel)
     return cur in [pmc_all.get("_sha16_by_kernel", {}).get(kernel)] + list(pmc_all.get("_same_isa_sha16_by_kernel", {}).get(kernel, []))
 
@@ -63,6 +76,8 @@ def parse():
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=1_000_000, help="Gaussians of the cpu_baseline sample (default: the whole workload)")
     ap.add_argument("--no-integrate", action="store_true", help="skip the opacity-field query leg (BASELINE config 5 shape)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the heavy-tailed scene leg (S1M-clustered: what the tile scheduler is for)")
+    ap.add_argument("--no-views", action="store_true", help="skip the leg that cycles 8 posed cameras inside its timed region")
+    ap.add_argument("--no-reference", action="store_true", help="skip the leg that times the reference's own kernels (oracle/_ref) on this GPU")
     return ap.parse_args()
 
 
@@ -228,6 +243,10 @@ def main():
             out["full_loop"] = full_loop(sd, dev, W, H)
         if world == 1 and not args.no_clustered and P == 1_000_000:
             out["clustered"] = clustered_leg(dev, P, W, H, focal, args.kernel_size, out["ms_per_step"])
+        if world == 1 and not args.no_views and P == 1_000_000:
+            out["views"] = views_leg(dev, sc, out["ms_per_step"])
+        if world == 1 and not args.no_reference:
+            out["reference_same_gpu"] = reference_leg(sd, dL, out["ms_per_step"])
         if world == 1 and not args.no_integrate:
             out["integrate"] = integrate_leg(dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -296,9 +315,18 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     pmc_file = os.path.join(ROOT, "profiles", PMC_FILE)
     if P == 1_000_000 and (W, H) == (1600, 1063) and os.path.exists(pmc_file):
         pmc_all = json.load(open(pmc_file))
-        pmc_source = {"file": "profiles/" + PMC_FILE, "kernel_sha16": pmc_all.get("_kernel_sha16"), "current_kernel_sha16": kernel_sha16(),
+        pmc_source = {"file": "profiles/" + PMC_FILE, "sha16_by_kernel_at_collection": pmc_all.get("_sha16_by_kernel"),
                       "collected_by": "rocprofv3 --pmc passes of tests/devtools/dev_pmc.py (separate FETCH_SIZE / WRITE_SIZE / SQ passes)"}
         pmc_source["current_sha16_of_the_dominant_kernel"] = kernel_sha16(dom)
+        stale = []
+        for name, ent in kernels.items():               # every kernel's counter traffic, but only from a pass on ITS current source
+            if name in pmc_all and isinstance(pmc_all[name], dict) and "hbm_bytes_corrected" in pmc_all[name]:
+                if pmc_pass_is_current(pmc_all, name):
+                    ent["traffic_MB"] = round(pmc_all[name]["hbm_bytes_corrected"] / 1e6, 1)
+                else:
+                    ent["traffic_MB"] = None
+                    stale.append(name)
+        pmc_source["kernels_whose_source_changed_since_the_pass"] = stale
         if pmc_pass_is_current(pmc_all, dom):
             traffic = pmc_all.get(dom, {}).get("hbm_bytes_corrected")
             valu_issue_frac = pmc_all.get(dom, {}).get("valu_issue_frac")
@@ -389,6 +417,79 @@ def clustered_leg(dev, P, W, H, focal, kernel_size, s1m_ms, steps=20, warmup=3):
             "tile_list_length_pct_0_50_90_99_100": pct(lens), "entries_walked_per_tile_pct_0_50_90_99_100": pct(walked),
             "vs_s1m_ms_per_step": round(ms / s1m_ms, 3),
             "kernels_ms": {k: round(v["total_ms"] / max(1, v["calls"]), 4) for k, v in rep.items()}}
+
+
+def views_leg(dev, sc, s1m_ms, n_views=8, steps=40, warmup=8):
+    """A training run renders a DIFFERENT camera every iteration (train.py:100-104): instance count (the sync-free forward's learnt
+    capacity), tile costs and their order, L2 / MALL contents all change from step to step, where the headline renders one view over
+    and over.  This leg cycles `n_views` posed cameras (synthetic_scenes.other_view: the same cloud seen from rigidly moved cameras)
+    inside its timed region: ms per step over the cycle, the per-view spread, and how often the fused forward had to redo a frame
+    because the instance count outgrew the capacity learnt from the previous views.  Reported beside the headline, not as it."""
+    import synthetic_scenes as S
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    views = [to_dev(sc if v == 0 else S.other_view(sc, v), dev) for v in range(n_views)]
+    base = views[0]
+    params = {k: base[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    rasts = [GaussianRasterizer(settings_from(v)) for v in views]
+    H, W = base["H"], base["W"]
+    dL = torch.randn((9, H, W), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+    counts = []
+
+    def step(i):
+        for p in params.values():
+            p.grad = None
+        means2D.grad = None
+        color, _ = rasts[i % n_views](means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                                      scales=params["scales"], rotations=params["rotations"])
+        color.backward(dL)
+    redo0 = B._stats["fused_redone_frames"]
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    redo = B._stats["fused_redone_frames"] - redo0
+    per_view = []
+    for v in range(n_views):                       # each view on its own (the headline's pattern), for the spread
+        for _ in range(2):
+            step(v)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step(v)
+        torch.cuda.synchronize()
+        per_view.append(1e3 * (time.perf_counter() - t0) / 5)
+        counts.append(int(B._stats["last_num_rendered"]))
+    return {"workload": "S1M seen from %d posed cameras, one per step, cycled inside the timed region, fwd+bwd" % n_views,
+            "ms_per_step": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps, "vs_s1m_ms_per_step": round(ms / s1m_ms, 3),
+            "per_view_alone_ms": [round(x, 4) for x in per_view], "num_rendered_per_view": counts,
+            "mean_of_the_views_alone_ms": round(float(np.mean(per_view)), 4),
+            "fused_forward_redone_frames": redo}
+
+
+def reference_leg(sd, dL, product_ms):
+    """The reference's OWN kernels on this GPU: submodules/diff-gaussian-rasterization/cuda_rasterizer/*.cu compiled for gfx950 where
+    they lie by oracle/build_ref.sh (default FMA contraction, as a user's build would be) -- oracle/_ref/libgof_cudaref.so, TEST
+    INFRASTRUCTURE, timed here OUTSIDE the timed region of the headline, on the same scene, everything resident on the device.
+    BASELINE.md holds no published number for this metric (vs_baseline stays null); this is the same-GPU yardstick."""
+    try:
+        import reference_binding as rb
+        if not rb.available(""):
+            return {"available": False, "why": "oracle/_ref/libgof_cudaref.so is not in this checkout (built where /root/reference exists)"}
+        ref = rb.Reference(sd, "")
+        fwd_ms, bwd_ms = ref.time_forward_backward(dL.contiguous())
+        ms = fwd_ms + bwd_ms
+        return {"available": True, "kind": "the reference's CUDA sources compiled for gfx950 (oracle/build_ref.sh), default FMA contraction",
+                "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3), "ms_per_step": round(ms, 3), "iters_per_s": round(1e3 / ms, 2),
+                "num_rendered": int(ref.R), "product_speedup": round(ms / product_ms, 2),
+                "note": "3 iterations after 1 warm-up, medians; host-side wall clock around the two synchronising wrapper calls"}
+    except Exception as e:      # the yardstick must never take the headline down
+        return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
 def full_loop(sd, dev, W, H, steps=10, warmup=3):

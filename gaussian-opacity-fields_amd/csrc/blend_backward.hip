@@ -56,18 +56,22 @@ static_assert(BATCH == 64 || BATCH == 128, "BATCH must be 64 or 128");
 // How the 16 per-pair values are summed over the wave (GOF_BW_REDUCE):
 //   0  in registers: transposed reduction with v_permlane32/16_swap, DPP quad levels and row rotations (rounds 2-3; ~75 VALU
 //      instructions of which 12 lane-group swaps at ~12 cycles: ~300 of the trip's 749 SIMD-cycles);
-//   1  through the LDS (round 4): every lane stores its 16 values into a [value][lane] panel of its wave (16 ds_write_b32, contiguous
-//      per instruction), then lane (v, p) = (lane / 4, lane % 4) reads back the 16 lanes 16 p .. 16 p + 15 of value v with four
-//      ds_read_b128, adds them and two DPP quad steps finish: 17 VALU instructions; the transposition is done by the LDS crossbar,
-//      which this kernel leaves idle otherwise.  Row stride 68 words: the b128 lane groups then meet 16 distinct 16-byte slots
-//      (MI355X_MICROARCH.md, LDS).  17 KB more LDS (4 x 16 x 68 words): 4 workgroups per CU (40.2 KB) instead of 5-6.
-//   3  as 1, software-pipelined over the visits: the panel of visit k is read back at the START of visit k + 1 (the loads are in
-//      flight while visit k + 1's gradient block runs), summed and stored after it, and only then overwritten with visit k + 1's
-//      values -- the wave never waits for its own LDS round trip.  16 more live registers.
-//   2  the same in two halves of 8 values over an 8-value panel (8.5 KB: 5 workgroups per CU): lane (v, p) = (lane / 8, lane % 8) reads
-//      8 lanes' worth with two ds_read_b128, three DPP steps.
+//   2  through the LDS (round 4, shipped), in two halves of 8 values: every lane stores 8 values into a [value][lane] panel of its
+//      wave (ds_write2_b32, contiguous per instruction), then lane (v, p) = (lane / 8, lane % 8) reads back the 8 lanes 8 p .. 8 p + 7
+//      of value v with two ds_read_b128, adds them, and three DPP steps finish: 18 VALU instructions per half; the transposition is
+//      done by the LDS crossbar, which this kernel leaves idle otherwise.  Row stride 68 words (b128 lane groups on distinct 16-byte
+//      slots: MI355X_MICROARCH.md, LDS).  8.5 KB more LDS: 31.5 KB, 5 workgroups per CU.
+// Measured (profiles/r04_ab_call2_*.txt, S1M / S1M-clustered): 0: 1.162 / 1.543 ms; 2: 1.070 / 1.373 ms (-8 % / -11 %).  The ISA count
+// promised more (746 -> 598 SIMD-cycles per trip): an LDS store moves its source registers through the SIMD's register read ports
+// (~2 cycles per dword), so the 16 stored values cost about what the 12 swaps did.  Also measured, not kept: all 16 values through
+// one 17 KB panel (1.091 / 1.396, 4 workgroups per CU); that software-pipelined over the visits -- panel of visit k read back during
+// visit k + 1's arithmetic (1.082 / 1.393: the round trip was not what limited it); lanes without a contribution storing a zero
+// register instead of every lane clearing 16 registers first (1.174 / 1.521: eight more store instructions cost more than 16 v_mov).
 #ifndef GOF_BW_REDUCE
-#define GOF_BW_REDUCE 3
+#define GOF_BW_REDUCE 2
+#endif
+#if GOF_BW_REDUCE != 0 && GOF_BW_REDUCE != 2
+#error "GOF_BW_REDUCE: 0 (register swaps) or 2 (LDS panel, two halves)"
 #endif
 constexpr int RED_STRIDE = 68;
 
@@ -169,9 +173,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     __shared__ float s_slab[4][NGRAD][BATCH];          // per wave: the wave totals of the entries it visited in this batch
     __shared__ uint32_t s_vis[4][BATCH / 32];           // per wave: which entries those are
     __shared__ uint32_t s_max_last;
-#if GOF_BW_REDUCE == 1 || GOF_BW_REDUCE == 3
-    __shared__ __attribute__((aligned(16))) float s_red[4][NGRAD][RED_STRIDE];
-#elif GOF_BW_REDUCE == 2
+#if GOF_BW_REDUCE == 2
     __shared__ __attribute__((aligned(16))) float s_red[4][NGRAD / 2][RED_STRIDE];
 #endif
 
@@ -261,17 +263,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
 #if GOF_BW_REDUCE == 0
         const uint32_t slab_row = 8u * ((lane >> 1) & 1u) + 4u * (lane & 1u) + 2u * ((lane >> 4) & 1u) + (lane >> 5);   // value this lane's total belongs to
 #endif
-#if GOF_BW_REDUCE == 3
-        int pj = -1;                                               // the visit whose values lie in the panel, not yet summed (wave-uniform)
-        float* const panel = &s_red[wave][0][0];
-        const f4* const rp = reinterpret_cast<const f4*>(panel + (lane >> 2) * RED_STRIDE + 16u * (lane & 3u));
-        auto finish_visit = [&](const f4& a, const f4& b, const f4& c, const f4& d, int jdone) {
-            float tot = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
-            tot = tot + dpp_get<0xB1>(tot);                        // quad_perm [1,0,3,2]
-            tot = tot + dpp_get<0x4E>(tot);                        // quad_perm [2,3,0,1]
-            if ((lane & 3u) == 0u) s_slab[wave][lane >> 2][jdone] = tot;
-        };
-#endif
 #pragma unroll
         for (int w = BATCH / 32 - 1; w >= 0; w--) {
             if (w > ((n + 31) >> 5) - 1) continue;                 // (wave-uniform; the loop is unrolled so that cmw[] stays in registers)
@@ -306,18 +297,9 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 }
 #endif
 
-#if GOF_BW_REDUCE == 3
-                const int pjs = __builtin_amdgcn_readfirstlane(pj);                    // (uniform by construction: keep it in a scalar register)
-                // the previous visit's panel: in flight during this visit's arithmetic (read unconditionally -- before a batch's first
-                // visit it holds stale values that are never used: no zero-filled registers, no branch)
-                const f4 pa = rp[0], pb = rp[1], pc = rp[2], pd = rp[3];
-                __builtin_amdgcn_wave_barrier();                                       // (every lane has issued its loads before any lane stores below)
-#endif
                 float g[NGRAD];
-#if !(GOF_BW_REDUCE == 3 && defined(GOF_BW_ZSTORE))
 #pragma unroll
                 for (int k = 0; k < NGRAD; k++) g[k] = 0.f;
-#endif
                 if (contrib) {
                     BSTAT_ADD(2, 1);
                     const f4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j], q5 = s_rec[5][j];
@@ -422,18 +404,8 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     // dL_dv2g[9] = dL_dmin_value = -0.5 wgt (G dL_dalpha) = -0.5 wgt g[6] with wgt a constant of the Gaussian: its total is
                     // formed from the total of g[6] at the flush, not reduced here
                     }
-#if GOF_BW_REDUCE == 3 && defined(GOF_BW_ZSTORE)
-                    // (the previous visit's panel values are in registers -- the loads were issued first and the LDS serves a wave in
-                    // order --, so the panel can be overwritten here, inside the branch: the lanes without a contribution store a zero
-                    // register in the other branch instead of every lane clearing 16 registers first)
-#pragma unroll
-                    for (int k = 0; k < NGRAD; k++) panel[k * RED_STRIDE + lane] = g[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NGRAD; k++) panel[k * RED_STRIDE + lane] = 0.f;
-#endif
                 }
-                // wave total of the 16 values by a transposed reduction whose first two levels use gfx950's lane-group
+                // GOF_BW_REDUCE == 0: wave total of the 16 values by a transposed reduction whose first two levels use gfx950's lane-group
                 // swaps (no selects): v_permlane32_swap exchanges the upper half of one register with the lower half of another, so
                 // x + y afterwards holds value A summed over the halves in lanes 0-31 and value B in lanes 32-63; v_permlane16_swap
                 // does the same for odd / even rows.  16 -> 8 -> 4 live values; two DPP quad levels with selects 4 -> 2 -> 1; two row
@@ -464,38 +436,9 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     tot = tot + dpp_get<0x128>(tot);                  // row_ror:8
                 }
                 if ((lane & 12u) == 0u) s_slab[wave][slab_row][j] = tot;
-#elif GOF_BW_REDUCE == 1
-                // The wave's own panel: no other wave touches it, and the LDS serves a wave's instructions in order -- the two
-                // wave barriers only keep the compiler from moving the accesses across (no instruction).
-                {
-                    float* const panel = &s_red[wave][0][0];
-#pragma unroll
-                    for (int k = 0; k < NGRAD; k++) panel[k * RED_STRIDE + lane] = g[k];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const f4* const rp = reinterpret_cast<const f4*>(panel + (lane >> 2) * RED_STRIDE + 16u * (lane & 3u));
-                    const f4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
-                    float tot = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
-                    tot = tot + dpp_get<0xB1>(tot);                   // quad_perm [1,0,3,2]
-                    tot = tot + dpp_get<0x4E>(tot);                   // quad_perm [2,3,0,1]
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();                  // (the next visit's stores come after these reads)
-                    if ((lane & 3u) == 0u) s_slab[wave][lane >> 2][j] = tot;
-                }
-#elif GOF_BW_REDUCE == 3
-                if (pjs >= 0) finish_visit(pa, pb, pc, pd, pjs);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();                      // (the panel has been read: it may be overwritten)
-#ifndef GOF_BW_ZSTORE
-#pragma unroll
-                for (int k = 0; k < NGRAD; k++) panel[k * RED_STRIDE + lane] = g[k];
-#endif
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                pj = __builtin_amdgcn_readfirstlane(j);
 #else
+                // The wave's own panel: no other wave touches it, and the LDS serves a wave's instructions in order -- the wave
+                // barriers only keep the compiler from moving the accesses across (no instruction).
                 {
                     float* const panel = &s_red[wave][0][0];
 #pragma unroll
@@ -520,11 +463,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
             }
             if (lane == 0) s_vis[wave][w] = visited;
         }
-#if GOF_BW_REDUCE == 3
-        if (__builtin_amdgcn_readfirstlane(pj) >= 0) finish_visit(rp[0], rp[1], rp[2], rp[3], __builtin_amdgcn_readfirstlane(pj));      // drain: the batch's last visit
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#endif
         __syncthreads();
         // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, stored as the partial
         // gradient record of this (tile, Gaussian) instance
@@ -554,8 +492,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
 // one workgroup per tile, popped as the workgroup starts: deepest walk first (pop_tile, gof_common.h; order by the forward's tile_cost)
 #if GOF_BW_REDUCE == 0
 #define GOF_BW_MIN_WAVES 5
-#elif GOF_BW_REDUCE == 1 || GOF_BW_REDUCE == 3
-#define GOF_BW_MIN_WAVES 4       // the LDS (40.2 KB) allows 4 workgroups per CU: the register allocator may use 512 / 4
 #else
 #define GOF_BW_MIN_WAVES 5
 #endif

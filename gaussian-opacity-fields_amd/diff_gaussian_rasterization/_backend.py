@@ -201,6 +201,7 @@ def _prepare_and_bin(v):
 GOF_E_CAPACITY = -5
 FUSED_FORWARD = os.environ.get("GOF_FUSED_FORWARD", "1") != "0"
 _capacity = {}          # (device, P, W, H) -> instance capacity learnt from earlier frames
+_stats = {"fused_redone_frames": 0, "last_num_rendered": 0}      # bench.py's `views` leg reads these (no effect on the path)
 _pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
 
 
@@ -259,15 +260,18 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 true_r = int(pin[0].item()) & 0xFFFFFFFF
                 if _round_capacity(true_r) > cap:
                     _capacity[shape_key] = _round_capacity(true_r)        # growing scene: stay ahead of it
+                _stats["last_num_rendered"] = true_r
                 return NumRendered(true_r, cap), out_color, radii, geom, binning, img
             if rc != GOF_E_CAPACITY:
                 _check(rc)
+            _stats["fused_redone_frames"] += 1
             del geom, img, binning, radii                                     # too small: redo the frame below with the exact count
         geom, img, binning, radii, rendered = _prepare_and_bin(v)
         _check(lib.gof_forward_render(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                       _ptr(img), img.numel(), _ptr(out_color), _stream()))
         if use_fused and not prefiltered and not debug:
             _capacity[shape_key] = max(_capacity.get(shape_key, 0), _round_capacity(rendered))
+        _stats["last_num_rendered"] = int(rendered)
     return NumRendered(rendered), out_color, radii, geom, binning, img
 
 

@@ -48,7 +48,7 @@ def pmc(sub):
 passes = {s: pmc(s) for s in ("fetch", "write", "sq1", "sq2", "sq3", "sq4")}
 kernels = sorted(set().union(*[set(p) for p in passes.values()]))
 import bench as bench_mod
-data = {"_kernel_sha16": bench_mod.kernel_sha16(), "_sha16_by_kernel": {k: bench_mod.kernel_sha16(k) for k in ("blend_forward", "blend_backward")},
+data = {"_kernel_sha16": bench_mod.kernel_sha16(), "_sha16_by_kernel": {k: bench_mod.kernel_sha16(k) for k in kernels if k in bench_mod.KERNEL_SOURCES},
         "_note": "per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md); "
                  "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over all waves / SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs"}
 for k in kernels:

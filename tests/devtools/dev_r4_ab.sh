@@ -7,7 +7,7 @@
 #   fw5                -DGOF_FW_WAVES=5
 #   gpurun --timeout 900 -- 'bash tests/devtools/dev_r4_ab.sh'
 PKG=gaussian-opacity-fields_amd
-declare -A FLAGS=( [bw0]="-DGOF_BW_REDUCE=0" [bw1]="-DGOF_BW_REDUCE=1" [bw2]="-DGOF_BW_REDUCE=2" [bw3z]="-DGOF_BW_REDUCE=3 -DGOF_BW_ZSTORE" [fw5]="-DGOF_FW_WAVES=5" )
+declare -A FLAGS=( [bw0]="-DGOF_BW_REDUCE=0" )     # (call 2 also timed -DGOF_BW_REDUCE=1|3 (+ -DGOF_BW_ZSTORE) and -DGOF_FW_WAVES=5: profiles/r04_ab_call2_*.txt; those variants were removed)
 if [ "$1" = build ]; then
   cd "$(dirname "$0")/../.."
   for v in "${!FLAGS[@]}"; do GOF_BUILD_TAG=$v GOF_EXTRA_FLAGS="${FLAGS[$v]}" python $PKG/build.py & done; wait
@@ -17,7 +17,7 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r4_ab; mkdir -p $O
 SCENES=${SCENES:-"s1m clustered"}
 for scene in $SCENES; do
-  for v in ${VARIANTS:-shipped exact tight bw0 bw1 bw2 bw3z fw5}; do
+  for v in ${VARIANTS:-shipped exact tight bw0}; do
     lib=$GRAFT_REPO_ROOT/$PKG/lib/libgof_hip.so; ex=0; tr=0
     case $v in shipped) ;; exact) ex=1 ;; tight) tr=1 ;; *) lib=$GRAFT_REPO_ROOT/$PKG/lib/libgof_hip_$v.so ;; esac
     [ -f $lib ] || { echo "== $scene $v: $lib missing"; continue; }

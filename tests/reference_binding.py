@@ -85,6 +85,28 @@ class Reference:
         self.R = self.L.cudaref_forward(self.h, C.byref(self.args), C.c_void_p(self.out.data_ptr()), C.c_void_p(self.radii.data_ptr()))
         return self.out.cpu().numpy(), self.radii.cpu().numpy()
 
+    def time_forward_backward(self, dL_dev, iters=3):
+        """fwd + bwd of the reference's own kernels with everything resident on the device (no host copies inside the timed part;
+        the C wrapper synchronises after each of the two calls, as torch's binding would not -- the reference is timed generously):
+        -> (fwd_ms, bwd_ms) medians.  bench.py's `reference_same_gpu` leg."""
+        import time
+        dev = self.sd["means3D"].device
+        P, M = self.P, self.M
+        z = lambda *s: torch.zeros(s, device=dev)   # noqa: E731
+        out = z(9, self.H, self.W); radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        g = [z(P, 3), z(P, 3), z(P, 1), z(P, 3), z(P, 6), z(P, M, 3), z(P, 3), z(P, 4), z(P, 10), z(P, 4)]
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        tf, tb = [], []
+        for _ in range(iters + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.R = self.L.cudaref_forward(self.h, C.byref(self.args), p(out), p(radii))
+            t1 = time.perf_counter()
+            self.L.cudaref_backward(self.h, C.byref(self.args), p(radii), p(dL_dev), *[p(t) for t in g])
+            t2 = time.perf_counter()
+            tf.append(1e3 * (t1 - t0)); tb.append(1e3 * (t2 - t1))
+        return float(np.median(tf[1:])), float(np.median(tb[1:]))
+
     def fetch(self, name):
         n = C.c_longlong(0)
         ptr = self.L.cudaref_fetch(self.h, name.encode(), C.byref(n))
