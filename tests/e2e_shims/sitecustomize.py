@@ -16,3 +16,20 @@ try:
     _Image.fromarray = fromarray
 except Exception:      # pragma: no cover  (never break interpreter start-up)
     pass
+
+# GOF_E2E_SEED=<n> (tests/test_trajectory_gpu.py): the reference's train.py leaves `safe_state(args.quiet)` commented out (train.py:365),
+# so Python's `random` -- the camera order, train.py:103 -- starts from OS entropy; two runs that are to be COMPARED step by step
+# need the same sequence.  Seeds `random` and numpy's global generator at interpreter start (torch's default generators start from
+# a fixed seed on their own).
+try:
+    import os as _os
+    if _os.environ.get("GOF_E2E_SEED"):
+        import random as _random
+        _random.seed(int(_os.environ["GOF_E2E_SEED"]))
+        try:
+            import numpy as _np2
+            _np2.random.seed(int(_os.environ["GOF_E2E_SEED"]))
+        except Exception:
+            pass
+except Exception:      # pragma: no cover
+    pass
