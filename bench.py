@@ -120,6 +120,18 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         dist.all_reduce(torch.zeros(1, device=dev))      # the communicator exists before a collective is issued from the autograd thread
+        # one rank per GPU, or fail loudly: two ranks on one device would report a "scaling" that is time-slicing (and RCCL would hang or
+        # crawl).  GOF_BENCH_SHARE_GPU=1 is the development override (gloo, fewer GPUs than ranks).
+        ids = [None] * world
+        try:
+            me = str(torch.cuda.get_device_properties(dev).uuid)
+        except Exception:
+            me = "%s#%d" % (os.uname().nodename, dev_index)
+        dist.all_gather_object(ids, me)
+        if len(set(ids)) != world and not share:
+            raise SystemExit("bench.py: %d ranks but only %d distinct GPUs (%s): one rank per GPU, or GOF_BENCH_SHARE_GPU=1 for a development run" % (world, len(set(ids)), ids))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     import synthetic_scenes as S
     from gpu_common import to_dev, settings_from

@@ -473,3 +473,129 @@ def test_world2_gloo_step_with_the_kernels_run_from_source_on_the_host():
         p.join(300)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _worker_delay(rank, world, port, ret):
+    """see test_the_early_gather_is_waited_for_only_where_the_design_says"""
+    import time
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-opacity-fields_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dp import GradientAllReducer
+    P, M = 300, 16
+    log = []                                              # (what, time) in program order on this rank
+
+    class DelayedWork:
+        """the collective's handle: completes DELAY seconds after its issue; wait() records when it was called and when it returned"""
+        def __init__(self, work, name, delay):
+            self.work, self.name, self.t_done = work, name, time.perf_counter() + delay
+
+        def wait(self):
+            log.append(("wait_begin:" + self.name, time.perf_counter()))
+            self.work.wait()
+            left = self.t_done - time.perf_counter()
+            if left > 0:
+                time.sleep(left)
+            log.append(("wait_end:" + self.name, time.perf_counter()))
+            return True
+
+    DELAY = 0.4
+    real_all_gather, real_all_reduce = dist.all_gather, dist.all_reduce
+
+    def all_gather(out, inp, group=None, async_op=False):
+        log.append(("issue:gather", time.perf_counter()))
+        w = real_all_gather(out, inp, group=group, async_op=True)
+        return DelayedWork(w, "gather", DELAY) if async_op else w.wait()
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        log.append(("issue:reduce", time.perf_counter()))
+        w = real_all_reduce(t, op=op, group=group, async_op=True)
+        return DelayedWork(w, "reduce", DELAY) if async_op else w.wait()
+    dist.all_gather, dist.all_reduce = all_gather, all_reduce
+
+    class Ops:                                            # a stand-in rasterizer: pack = copy of the colour gradient, expand = basis 1 for every coefficient
+        src, ready = None, None
+        track = staticmethod(lambda on: None)
+        set_ready = staticmethod(lambda fn: setattr(Ops, "ready", fn))
+
+        @staticmethod
+        def take():
+            s_, Ops.src = Ops.src, None
+            return s_
+
+        @staticmethod
+        def pack(src, out):
+            out[:src["P"]].copy_(src["dL_dcolors"])
+
+        @staticmethod
+        def expand(src, gathered, scale, grads):
+            log.append(("expand", time.perf_counter()))
+            tot = gathered[:, :src["P"]].sum(0) * scale
+            grads[0].copy_(tot[:, None, :].expand(-1, src["M"], -1))
+
+    g = torch.Generator().manual_seed(5)
+    params = [torch.randn((P, 3), generator=g).requires_grad_(True), torch.randn((P, M, 3), generator=g).requires_grad_(True)]
+    red = GradientAllReducer(params, sh_params=[params[1]], sh_ops=Ops)
+    gr = torch.Generator().manual_seed(50 + rank)
+    col = torch.randn((P, 3), generator=gr)
+    # (warm-up: gloo opens its connections on the first collective of each kind; then both ranks start together)
+    warm = torch.zeros(4)
+    real_all_gather([torch.zeros(4), torch.zeros(4)], warm)
+    real_all_reduce(warm)
+    dist.barrier()
+    # ---- "the backward": blend stage done -> the rasterizer announces its colour gradient (the early gather starts) -> the per-Gaussian
+    # stage and the rest of autograd run (0.15 s of "compute" here) -> the backward returns
+    t0 = time.perf_counter()
+    src = {"P": P, "M": M, "dL_dcolors": col, "campos": torch.zeros(3)}
+    Ops.src = src
+    Ops.ready(src)                                        # = _on_colour_gradient, from inside the backward
+    log.append(("callback_returned", time.perf_counter()))
+    time.sleep(0.15)                                      # preprocess_bwd + the remaining autograd nodes
+    params[0].grad = torch.randn((P, 3), generator=gr)
+    params[1].grad = col[:, None, :].expand(-1, M, -1).contiguous()
+    log.append(("backward_returned", time.perf_counter()))
+    red.all_reduce()
+    log.append(("exchange_returned", time.perf_counter()))
+    T = {k: v - t0 for k, v in log}
+    order = [k for k, _ in log]
+    ok = red.last_exchange == "compressed-sh"
+    # (1) the callback only ISSUES the gather: it returns at once, and nothing waits before the backward has returned
+    ok = ok and order.index("issue:gather") < order.index("callback_returned") < order.index("backward_returned")
+    ok = ok and T["callback_returned"] < 0.1 and all(not k.startswith("wait_begin") or order.index(k) > order.index("backward_returned") for k in order)
+    # (2) inside the exchange: the dense all-reduce is ISSUED before the gather is waited for (it runs behind it on the communication
+    # side), the expansion follows the gather's completion, and the all-reduce is waited for last
+    ok = ok and order.index("issue:reduce") < order.index("wait_begin:gather") < order.index("wait_end:gather") < order.index("expand") \
+        < order.index("wait_begin:reduce") < order.index("wait_end:reduce") < order.index("exchange_returned")
+    # (3) the delay is paid ONCE and only for what is still outstanding: the gather was issued 0.15 s before the exchange began, so its
+    # wait is shorter than the delay by that compute, and the reduce -- issued at the start of the exchange -- is (nearly) done by then
+    gather_wait = T["wait_end:gather"] - T["wait_begin:gather"]
+    reduce_wait = T["wait_end:reduce"] - T["wait_begin:reduce"]
+    ok = ok and DELAY - 0.15 - 0.08 < gather_wait < DELAY - 0.15 + 0.08 and reduce_wait < 0.25
+    # and the numbers are right
+    cols = [torch.randn((P, 3), generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
+    ok = ok and torch.allclose(params[1].grad, sum(cols)[:, None, :].expand(-1, M, -1), atol=1e-6)
+    ret[rank] = (bool(ok), order, {k: round(v, 3) for k, v in T.items()})
+    dist.all_gather, dist.all_reduce = real_all_gather, real_all_reduce
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_early_gather_is_waited_for_only_where_the_design_says():
+    """the all-gather of the colour gradient is STARTED from inside the rasterizer's backward (after its blend
+    stage) and waited for in GradientAllReducer.all_reduce() -- behind the issue of the dense all-reduce, in front of the SH
+    expansion.  World 2 on gloo with every collective completing 0.4 s after its issue (a deliberately slow interconnect): the
+    backward must not wait at all, and the exchange must wait only for what is still outstanding.  No 8-GPU node was available in any
+    round; this pins the protocol's overlap structure so that the first real run measures bandwidth, not a serialisation bug."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_delay, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+        got = dict(ret)
+    assert set(got) == {0, 1} and all(v[0] for v in got.values()), got

@@ -77,12 +77,20 @@ def _err(a, b):
     return np.abs(a - b) / scale
 
 
-def test_product_vs_reference_default_build_within_the_references_own_fma_band():
-    """The ray-Gaussian evaluation is ill-conditioned in fp32: the reference's OWN output
+BAND_SCENES = ["base20k", "posed_ragged", "posed_mod2", "posed_mod05_ks01", "clustered150k", "posed_clustered150k", "posed_mid100k"]
+BAND_REPORT = {}          # scene -> measured figures (written to gpurun_out/reference_default_build_band.json by the last parametrisation)
+
+
+@pytest.mark.parametrize("name", BAND_SCENES)
+def test_product_vs_reference_default_build_within_the_references_own_fma_band(name):
+    """What a user who switches backends sees: the product against the reference's DEFAULT (FMA-contracting) build.
+    The ray-Gaussian evaluation is ill-conditioned in fp32: the reference's OWN output
     moves by up to 1e-1 relative at single pixels when the compiler contracts multiply-adds differently.
     So the product (no contraction, = the nofma build bit for bit up to exp) is held to the band spanned by
-    the reference's two builds, and to the north_star tolerance (1e-4) at the median."""
-    sc = scene()
+    the reference's two builds, and to the north_star tolerance (1e-4) at the median -- on posed cameras, scale_modifier != 1 and
+    heavy-tailed scenes as well (round 4; round 3 asserted it on one 20 k-Gaussian scene)."""
+    from test_parity_gpu import SCENES
+    sc = scene() if name == "base20k" else SCENES[name]()
     sd = to_dev(sc)
     ref = rb.Reference(sd, "")
     rc, rrad = ref.forward()
@@ -118,6 +126,40 @@ def test_product_vs_reference_default_build_within_the_references_own_fma_band()
         assert mine_l2 <= 2.0 * band_l2 + 1e-5, (k, mine_l2, band_l2)
         nofma_l2 = np.linalg.norm(gp[k].reshape(b.shape) - gr2[k]) / (np.linalg.norm(gr2[k]) + 1e-30)
         assert nofma_l2 < 1e-4, (k, nofma_l2)
+        BAND_REPORT.setdefault(name, {}).setdefault("gradients_rel_l2", {})[k] = {"product_vs_default": float(mine_l2), "reference_band": float(band_l2), "product_vs_nofma": float(nofma_l2)}
+    BAND_REPORT[name].update(image_percentiles_50_99_99p9={"product_vs_default": [float(x) for x in pm], "reference_band": [float(x) for x in pb]},
+                             worst_ratio_product_over_band=float(np.max(pm / np.maximum(pb, 1e-12))),
+                             radii_differing_fraction=float((prad != rrad).mean()), R_product=int(res["R"]), R_reference_default=int(ref.R))
+    if name == BAND_SCENES[-1]:
+        import json, os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump(BAND_REPORT, open(os.path.join(out, "reference_default_build_band.json"), "w"), indent=1)
+
+
+def test_s1m_forward_vs_reference_default_build():
+    """BASELINE's full-size configuration, forward: the product against the reference's default (FMA-contracting) build -- radii
+    and instance count up to ceil() flips, the image inside the band the reference's two builds span (99.9th percentile; the
+    reference against itself moves single pixels by 1e-1)."""
+    sc = S.scene_frustum(1_000_000, seed=0)
+    sd = to_dev(sc)
+    ref = rb.Reference(sd, "")
+    rc, rrad = ref.forward()
+    R_default = ref.R
+    ref2 = rb.Reference(sd, "_nofma")
+    rc2, rrad2 = ref2.forward()
+    del ref, ref2
+    res = product_forward_raw(sd)
+    torch.cuda.synchronize()
+    prad = res["radii"].cpu().numpy()
+    assert np.array_equal(prad, rrad2)
+    assert (prad != rrad).mean() < 1e-3 and abs(res["R"] - R_default) <= 1e-3 * R_default
+    pc = res["color"].cpu().numpy()
+    band, mine = _err(rc2, rc), _err(pc, rc)
+    qs = [50, 99, 99.9]
+    pb, pm = np.percentile(band, qs), np.percentile(mine, qs)
+    assert pm[0] < 1e-4 and (pm <= 2.0 * pb + 1e-5).all(), (pm, pb)
+    assert np.abs(pc - rc2).max() <= 2e-5 * max(1.0, np.abs(rc2).max())
 
 
 def test_integrate_matches_reference():
