@@ -26,6 +26,16 @@ _L.cudaref_forward.argtypes = [C.c_void_p, C.POINTER(GofRasterArgs), C.c_void_p,
 _L.cudaref_backward.argtypes = [C.c_void_p, C.POINTER(GofRasterArgs)] + [C.c_void_p] * 12
 IS_REFERENCE_BACKEND = True
 
+# The launcher's simple_knn._C (distCUDA2 on HIP: scene initialisation, identical on both sides of the comparison) finds the shared
+# library through `diff_gaussian_rasterization._backend`: the product's ctypes loader, imported here by file path under that name.
+# The RASTERIZER of this module stays the reference's kernels (_Rasterize below never touches it).
+import importlib.util as _ilu      # noqa: E402
+_spec = _ilu.spec_from_file_location("diff_gaussian_rasterization._backend",
+                                     os.path.join(ROOT, "gaussian-opacity-fields_amd", "diff_gaussian_rasterization", "_backend.py"))
+_backend = _ilu.module_from_spec(_spec)
+sys.modules["diff_gaussian_rasterization._backend"] = _backend
+_spec.loader.exec_module(_backend)
+
 
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
