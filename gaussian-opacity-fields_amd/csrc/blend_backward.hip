@@ -629,9 +629,9 @@ extern "C" int gof_debug_bw_tile_clock(unsigned long long* out, int ntiles)     
 #ifdef GOF_STATS
 extern "C" int gof_debug_bw_stats(unsigned long long* out8, int reset)
 {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bw_stats), sizeof(g_bw_stats));
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stats), z, sizeof(z)); }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bw_stats), sizeof(g_bw_stats));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stats), z, sizeof(z)); }
     return 0;
 }
 #endif

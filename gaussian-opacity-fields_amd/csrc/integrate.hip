@@ -102,15 +102,6 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
 #endif
     const float cone_margin = GOF_INT_CONE_MARGIN * fmaxf(1.0f, fmaxf((fabsf(crx) + two_hx) * (fabsf(crx) + two_hx), (fabsf(cry) + two_hy) * (fabsf(cry) + two_hy)));
     float cT[5] = { 1.0f, 1.0f, 1.0f, 1.0f, 1.0f };
-    // Certain-reject bound of a sub-ray (round 4): an entry is used by sub-ray c only if cT[c] (1 - alpha) >= 1e-4, i.e.
-    // alpha <= 1 - 1e-4 / cT[c].  lmax[c] = ln of that bound (+inf while it is >= 0.99, the cap of alpha): a candidate whose fp32
-    // ESTIMATE of ln(alpha / w) exceeds lmax[c] - ln w by more than the estimate's error bound cannot be used by that sub-ray,
-    // whatever the exact arithmetic gives, and skips it (IEEE division, the fp64 min_value, the exponential).  The reference walks on
-    // at test_T < 1e-4 (`continue`, forward.cu:951-956), so a pixel whose sub-rays sit just above 1e-4 evaluates five sub-rays per
-    // candidate to the end of its list waiting for an alpha below ~0.02: 35 % of the popped candidates (profiles/r03_structure_counts.md).
-    float lmax[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) lmax[c] = __builtin_huge_valf();
     float C0 = 0, C1 = 0, C2 = 0, Cdepth = 0, Calpha = 0;
     uint32_t contributor = 0, last_contributor = 0, n_local = 0;
     uint32_t last_matched = 0;      // uint16 emulation (forward.cu:983, 1145): list position of the second pass's last match,
@@ -181,6 +172,11 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
         }
         // ---- phase A2: per-lane ordered consumption of the candidates: the 5-sub-ray state machine of forward.cu:886-993;
         // s_used is rewritten in place with the entries that contributed ----
+        // (round 4, built and removed: a per-sub-ray certain-reject pre-test -- fp32 estimate of the power with its error bound against
+        // ln(1/255 w) and against ln of what the sub-ray can still take, 1 - 1e-4 / T -- in front of the IEEE division / fp64 / exp.
+        // On the host it rejects 48 % of the sub-ray evaluations and 98 % of the rest are used; on the GPU the kernel's time did not
+        // move (14.49 ms at the config-5 shape): the lanes of a wave sit at different candidates, one lane on the exact path keeps
+        // the wave on it, and 51 % of the evaluations take it.  profiles/HISTORY.md, round 4.)
         // (word by word, the wave moving on together: letting every lane advance over the 8 mask words on its own -- the forward
         // blend's scheme -- was measured SLOWER here, 8.17 -> 8.57 ms at S1M and 15.3 -> 16.6 ms at S5M, as in integrate_points)
         for (int w = 0; w < 8; w++) {
@@ -195,7 +191,6 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                 const float4 a4 = s_rec[0][j], b4 = s_rec[1][j], c4 = s_rec[2][j];
                 const float wgt = c4.z;
                 const float log_thr = cull_log_threshold(wgt);
-                const float log_w = (wgt > 0.0f) ? __logf(wgt) : -__builtin_huge_valf();      // (wgt <= 0 / NaN: never rejected on this side)
                 bool used = false;
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
@@ -206,16 +201,6 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                     const float AA = rx * n0 + ry * n1 + n2;
                     const float BB = 2 * (b4.z * rx + b4.w * ry + c4.x);
                     const float CC = c4.y;
-                    // fp32 estimate of the power with its error bound (the rounding of BB^2 / 4 AA and of the difference from CC: a few
-                    // ulp of the larger operand, with a wide safety factor -- as pair_certainly_transparent): certainly below 1/255, or
-                    // certainly above what this sub-ray can still take -> the exact path would `continue` (forward.cu:944, 951-956)
-                    if (AA > 0.0f) {
-                        const float X = (BB * __builtin_amdgcn_rcpf(AA)) * (BB * 0.25f);
-                        const float est = -0.5f * (CC - X);
-                        const float E = 4e-7f * fmaxf(fabsf(CC), fabsf(X)) + 1e-4f;
-                        if (est + E < log_thr) continue;
-                        if (fminf(est, 0.0f) - E > lmax[c] - log_w) continue;
-                    }
                     // one IEEE division: -BB/(2*AA) == -(BB/AA)/2 and BB/4 are exact power-of-two scalings (forward.cu:927-931)
                     const float q = BB / AA;
                     const float t = -q * 0.5f;
@@ -237,9 +222,6 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                     if (t > Cdepth) Cdepth = t;
                     if (c == 0) Calpha += alpha * cT[c];
                     cT[c] = test_T;
-                    // what this sub-ray can still take: alpha <= 1 - 1e-4 / T (2e-6 above it for the reciprocal's and the
-                    // subtraction's rounding; no statement while the bound is at or above the cap 0.99, i.e. T >= 0.01)
-                    lmax[c] = (test_T < 0.0099f) ? __logf(fmaxf(1.0f - 0.0001f * __builtin_amdgcn_rcpf(test_T) + 2e-6f, 1e-30f)) : __builtin_huge_valf();
                     used = true;
                 }
                 if (used) {
@@ -497,9 +479,9 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
 #ifdef GOF_STATS
 extern "C" int gof_debug_int_stats(unsigned long long* out8, int reset)
 {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_int_stats), sizeof(g_int_stats));
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_int_stats), z, sizeof(z)); }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_int_stats), sizeof(g_int_stats));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_int_stats), z, sizeof(z)); }
     return 0;
 }
 #endif
