@@ -91,7 +91,7 @@ json.dump(data, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_s1m.json" % 
 md = os.path.join(ROOT, "profiles", "%s_bench_s1m_kernel_stats_%s.md" % (rnd, tag))
 with open(md, "w") as o:
     o.write("# rocprofv3 summaries, round %s, kernels of commit-state '%s' (blend kernel sources sha16 %s)\n\n" % (rnd[1:], tag, data["_kernel_sha16"]))
-    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop`\n"
+    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop --no-clustered --no-views --no-reference`\n"
             "(S1M: 1M Gaussians, 1600x1063, R = 8 837 593)\n\n")
     o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/prof4
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop --no-clustered > $O/stats_bench.json 2> $O/stats.err ) || tail -3 $O/stats.err
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop --no-clustered --no-views --no-reference > $O/stats_bench.json 2> $O/stats.err ) || tail -3 $O/stats.err
 run() { tag=$1; shift; ( cd /tmp && timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc/$tag -- python $GRAFT_REPO_ROOT/tests/devtools/dev_pmc.py > /tmp/pmc_$tag.log 2>&1 ) || tail -5 /tmp/pmc_$tag.log; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE

@@ -809,12 +809,14 @@ def test_integrate_full_size_properties_config5():
 
 
 def test_integrate_config5_gaussian_count_against_oracle():
-    """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 18M instances, tile lists of ~2700 entries) with a 5M-point subsample
-    of its 45M query points, against the oracle on the GPU box's host cores: every output bit-identical."""
+    """BASELINE config 5's splat size at HALF its Gaussian count (2.5M, sigma_px 1.5, 9M instances, tile lists of ~1350 entries --
+    the full 5M / 45M shape is covered by size-independent properties in test_integrate_full_size_properties_config5; round 3 ran
+    the oracle on all 5M here: 51 s of the suite's 356) with a 2.5M-point subsample of its query points, against the oracle on the
+    GPU box's host cores: every output bit-identical."""
     from diff_gaussian_rasterization import GaussianRasterizer
-    sc = S.scene_frustum(5_000_000, seed=0, sigma_px=1.5)
+    sc = S.scene_frustum(2_500_000, seed=0, sigma_px=1.5)
     pts = np.ascontiguousarray(S.tetra_points(sc)[::9], dtype=np.float32)
-    assert pts.shape[0] == 5_000_000
+    assert pts.shape[0] == 2_500_000
     o = ob.OracleScene(sc)
     oc, oal, ocol, orad = o.integrate(pts)
     sd = to_dev(sc)
@@ -822,7 +824,7 @@ def test_integrate_config5_gaussian_count_against_oracle():
     color, alpha, colp, radii = r.integrate(points3D=torch.from_numpy(pts).cuda(), means3D=sd["means3D"], means2D=None,
                                             opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
     torch.cuda.synchronize()
-    assert np.array_equal(radii.cpu().numpy(), orad) and o.num_rendered() > 15_000_000
+    assert np.array_equal(radii.cpu().numpy(), orad) and o.num_rendered() > 7_500_000
     c = color.cpu().numpy()
     assert np.array_equal(bits(c), bits(oc)), [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)]
     a = alpha.cpu().numpy()
@@ -997,7 +999,7 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "gaussian-opacity-fields_amd", "lib", "libgof_hip_audit.so")
     assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
-    names = ["s1m", "s1m_ks01", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
+    names = ["s1m", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
              "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01", "clustered150k", "posed_clustered150k"]
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib, GOF_FW_EXACT="1"),      # (audit: the pairs the EXACT arithmetic accepts)
                        capture_output=True, text=True, timeout=1500)

@@ -139,8 +139,9 @@ def test_product_vs_reference_default_build_within_the_references_own_fma_band(n
 
 def test_s1m_forward_vs_reference_default_build():
     """BASELINE's full-size configuration, forward: the product against the reference's default (FMA-contracting) build -- radii
-    and instance count up to ceil() flips, the image inside the band the reference's two builds span (99.9th percentile; the
-    reference against itself moves single pixels by 1e-1)."""
+    and instance count up to ceil() flips, the image inside the band the reference's two builds span at the median, the 99th and the
+    99.9th percentile (at this scene's conditioning -- distance / scale ~ 480 -- the reference's own two builds differ by 2e-4 at the
+    MEDIAN pixel and 3e-2 at the 99.9th percentile: the 1e-4 median bar of the smaller scenes does not exist here)."""
     sc = S.scene_frustum(1_000_000, seed=0)
     sd = to_dev(sc)
     ref = rb.Reference(sd, "")
@@ -158,7 +159,7 @@ def test_s1m_forward_vs_reference_default_build():
     band, mine = _err(rc2, rc), _err(pc, rc)
     qs = [50, 99, 99.9]
     pb, pm = np.percentile(band, qs), np.percentile(mine, qs)
-    assert pm[0] < 1e-4 and (pm <= 2.0 * pb + 1e-5).all(), (pm, pb)
+    assert (pm <= 1.05 * pb + 1e-6).all(), (pm, pb)                            # measured: equal to the band to four digits
     assert np.abs(pc - rc2).max() <= 2e-5 * max(1.0, np.abs(rc2).max())
 
 

@@ -40,13 +40,17 @@ def _env(**extra):
     return env
 
 
-def _run(launcher, scene, model):
+def _start(launcher, scene, model):
     cmd = [sys.executable, launcher, os.path.join(REFPY, "train.py"), "-s", scene, "-m", model] + TRAIN_ARGS
-    t0 = time.time()
-    r = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, "command failed: %s\n--- stdout\n%s\n--- stderr\n%s" % (" ".join(cmd), r.stdout[-3000:], r.stderr[-5000:])
+    return cmd, time.time(), subprocess.Popen(cmd, env=_env(), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _finish(started, model):
+    cmd, t0, proc = started
+    stdout, stderr = proc.communicate(timeout=900)
+    assert proc.returncode == 0, "command failed: %s\n--- stdout\n%s\n--- stderr\n%s" % (" ".join(cmd), stdout[-3000:], stderr[-5000:])
     curve = {}
-    for m in re.finditer(r"\[ITER (\d+)\] Evaluating test: L1 (\S+) PSNR (\S+)", r.stdout):
+    for m in re.finditer(r"\[ITER (\d+)\] Evaluating test: L1 (\S+) PSNR (\S+)", stdout):
         curve[int(m.group(1))] = {"l1": float(m.group(2)), "psnr": float(m.group(3))}
     for it in MARKS[1:]:
         ply = os.path.join(model, "point_cloud", "iteration_%d" % it, "point_cloud.ply")
@@ -60,11 +64,15 @@ def test_training_trajectory_matches_the_references_own_kernels(tmp_path_factory
     assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libgof_cudaref.so")), "oracle/_ref/libgof_cudaref.so is missing"
     scene = str(tmp_path_factory.mktemp("blender_scene"))
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "fixtures", "make_blender_scene.py"), scene], env=_env())
-    runs, secs = {}, {}
+    runs, secs, started = {}, {}, {}
+    # the three runs side by side on the one GPU (a 160x120 scene is launch-latency bound: they overlap almost perfectly)
     for name, launcher in (("product", os.path.join(PKG, "launch", "run_reference_script.py")),
                            ("reference", os.path.join(ROOT, "tests", "reference_backend", "run_with_reference_rasterizer.py")),
                            ("reference2", os.path.join(ROOT, "tests", "reference_backend", "run_with_reference_rasterizer.py"))):
-        runs[name], secs[name] = _run(launcher, scene, str(tmp_path_factory.mktemp("model_" + name)))
+        model = str(tmp_path_factory.mktemp("model_" + name))
+        started[name] = (_start(launcher, scene, model), model)
+    for name, (st, model) in started.items():
+        runs[name], secs[name] = _finish(st, model)
         assert sorted(runs[name]) == MARKS, (name, sorted(runs[name]))
     out = {"what": "unchanged train.py, %d iterations on the synthetic Blender fixture (24 views of 160x120), same seeds, the reference's own torch "
                    "epilogue on every side; only the rasterizer differs" % ITERS,
