@@ -298,12 +298,12 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         "blend_forward": 72 * r_visited_fwd + 60 * N,                # 8(d): 60 B state + 12 B colour per visited entry, 60 B per pixel
         "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,   # 8(d): 72 B per staged entry, 60 + 36 B per pixel, accumulators once
         "preprocess_bwd": p_visible * (316 + 232),
-        "gather_tile_partials": 68 * r_staged_bwd + R + 8 * P + 68 * P,   # partial records + validity bytes + counts/offsets read, 17 floats per Gaussian written
-        "backward_memsets": 4 * P * 6 + R,                                 # dL_dcov3D (dead output) + the validity bytes
+        "gather_tile_partials": 68 * r_staged_bwd + 4 * R + 8 * P + 68 * P,   # partial records + slot words + counts/offsets read, 17 floats per Gaussian written
+        "backward_memsets": 4 * R,                                         # the slot words (a record pool instead of a record per instance, round 4)
     }
     # bytes this design moves on top of 8(d)'s list: the contributor masks (1 bit per pixel and visited entry = 32 B per entry),
     # written by the forward, read by the backward, and the 32 B footprint conic per entry the forward's cull scan reads
-    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": (32 + 69) * r_staged_bwd}   # masks read; partial record + validity byte written
+    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": (32 + 72) * r_staged_bwd}   # masks read; partial record + slot word written
     kernels = {}
     for name, rec in kernel_times.items():
         avg_ms = rec["total_ms"] / max(1, rec["calls"])
@@ -361,21 +361,25 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
             "kernels": kernels,
             "workload": {"R": R, "P_visible": p_visible, "R_visited_fwd": r_visited_fwd, "R_staged_bwd": r_staged_bwd, "contributing_pairs": pairs,
                          "mean_tile_list": round(float(lens.mean()), 1), "mean_last_contributor": round(float(last[:H, :W].mean()), 1)},
-            "workspace": workspace_report(B, P, W, H, R)}
+            "workspace": workspace_report(B, P, W, H, R, r_staged_bwd)}
     return {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "R": R, "roofline": roof}
 
 
-def workspace_report(B, P, W, H, R):
+def workspace_report(B, P, W, H, R, staged):
     """Bytes of the caller-owned workspaces of one forward + backward, and what an INSTANCE (one (tile, Gaussian) pair of the sorted
-    list) costs: sort state 16 B + contributor masks 32 B (binning workspace) + partial gradient record 69 B (backward scratch) = 117 B,
-    where the reference's BinningState holds 24 B (rasterizer_impl.h:60-70) -- a stated deviation: the masks
-    and records buy the backward without re-derived decisions and without atomics; they scale with R."""
+    list) costs.  Binning workspace: sort state 16 B + contributor masks 32 B.  Backward scratch (round 4): a slot word per instance
+    + a 68-byte partial gradient record per STAGED instance (the pool is sized from gof_backward_query: `staged` of R) -- rounds 2-3
+    held a record per instance, 69 B.  The reference's BinningState holds 24 B (rasterizer_impl.h:60-70): a stated deviation
+    (DESIGN.md section 7): masks and records buy the backward without re-derived decisions and without atomics."""
     lib = B.lib
     geom, image = int(lib.gof_geom_bytes(P)), int(lib.gof_image_bytes(W, H))
-    binning, scratch = int(lib.gof_binning_bytes(R, W, H)), int(lib.gof_backward_scratch_bytes(P, R))
+    binning = int(lib.gof_binning_bytes(R, W, H))
+    scratch_full, scratch = int(lib.gof_backward_scratch_bytes(P, R)), int(lib.gof_backward_scratch_bytes_for(P, R, staged))
     d_bin = (int(lib.gof_binning_bytes(2 * R, W, H)) - binning) / max(R, 1)
-    d_scr = (int(lib.gof_backward_scratch_bytes(P, 2 * R)) - scratch) / max(R, 1)
+    fixed = int(lib.gof_backward_scratch_bytes_for(P, 0, 0))
+    d_scr = (scratch - fixed) / max(R, 1)
     return {"geometry_bytes": geom, "image_bytes": image, "binning_bytes": binning, "backward_scratch_bytes": scratch,
+            "backward_scratch_bytes_worst_case": scratch_full, "staged_fraction_of_instances": round(staged / max(R, 1), 4),
             "per_gaussian_geometry_bytes": round(geom / max(P, 1), 1), "per_instance_binning_bytes": round(d_bin, 1),
             "per_instance_backward_scratch_bytes": round(d_scr, 1), "per_instance_total_bytes": round(d_bin + d_scr, 1),
             "reference_per_instance_bytes": 24, "reference_per_gaussian_bytes": 119}

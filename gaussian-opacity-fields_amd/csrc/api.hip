@@ -68,10 +68,11 @@ __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
-                               float4* part16, float* part17, uint8_t* part_valid, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
+                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_next, uint32_t rec_cap, uint32_t* async_status,
+                               uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                uint32_t* tile_queue, const uint32_t* tile_lens);
 __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
-                                     const uint8_t* part_valid, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors, float* dL_dv2g);
+                                     const uint32_t* slot_of, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors, float* dL_dv2g);
 __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
                                  uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
@@ -126,8 +127,10 @@ static int take_async_status()
 {
     std::lock_guard<std::mutex> lk(g_status_mutex);
     if (g_status_host && *g_status_host) {
+        const uint32_t code = *g_status_host;
         *g_status_host = 0;
-        set_error("an EARLIER call's tile sort timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
+        if (code == 2u) set_error("an EARLIER backward was given a scratch whose record pool was smaller than what its frame staged (size it with gof_backward_scratch_bytes, or with gof_backward_query + gof_backward_scratch_bytes_for): its gradients are incomplete");
+        else set_error("an EARLIER call's tile sort timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
         return GOF_E_DEVICE;
     }
     return GOF_OK;
@@ -359,7 +362,7 @@ extern "C" {
 const char* gof_last_error(void) { return g_error.c_str(); }
 int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
 int gof_set_tight_tile_rects(int on) { return g_tight_rects.exchange(on ? 1 : 0); }
-int gof_abi_version(void) { return 8; }   // 8: gof_set_forward_exact (round 4: the forward blend's division-free default mode)
+int gof_abi_version(void) { return 9; }   // 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query (round 4)
                                           // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
@@ -518,27 +521,43 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     return GOF_OK;
 }
 
-// backward scratch: first instance of every Gaussian in GAUSSIAN-ID order ([P] u32: exclusive scan of tiles_touched -- the partial
-// records of consecutive Gaussians are consecutive in memory, so the gather streams), scan scratch, then per tile instance (R of
-// them) a validity byte, the 17th partial gradient [R] f32 and the 64-byte record of the other 16 [R][16] f32
-struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint32_t* queue; uint8_t* valid; float* part17; float4* part16; };
-constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads sit right in front of the validity bytes: one memset clears both
-static size_t bwd_scratch_layout(int32_t P, uint32_t R, void* base, BwdScratch* o)
+// backward scratch: first instance of every Gaussian in GAUSSIAN-ID order ([P] u32: exclusive scan of tiles_touched), scan scratch,
+// the backward's queue heads + the record pool's cursor, then per tile instance (R of them) a slot word (slot + 1 of the instance's
+// partial gradient record, 0 = none), and the record POOL: per record the 17th partial gradient f32 and the 64-byte line of the other
+// 16.  The pool holds `records` records: R for the worst case (every instance staged), or the number the forward actually staged
+// (gof_backward_query: ~30 % of R at S1M) -- 4 + 68 x 0.3 B per instance instead of 69.
+struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint32_t* queue; uint32_t* slot_of; float* part17; float4* part16; };
+constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads ([0..7]) and the record cursor ([BWD_REC_NEXT]) sit right in front of the slot words: one memset clears both
+constexpr int BWD_REC_NEXT = 16;
+static size_t bwd_scratch_layout(int32_t P, uint32_t R, uint32_t records, void* base, BwdScratch* o)
 {
     char* p = static_cast<char*>(base);
     const size_t p0 = reinterpret_cast<size_t>(p);
     BwdScratch t;
     carve(p, t.inst_off, (size_t)(P < 1 ? 1 : P));
     carve(p, t.scan_tmp, scan_tmp_words((size_t)(P < 1 ? 1 : P)));
-    carve(p, t.valid, (size_t)R + 1 + BWD_QUEUE_BYTES);
-    t.queue = reinterpret_cast<uint32_t*>(t.valid);
-    t.valid += BWD_QUEUE_BYTES;
-    carve(p, t.part17, (size_t)R + 1);
-    carve(p, t.part16, 4 * ((size_t)R + 1));
+    carve(p, t.queue, BWD_QUEUE_BYTES / 4 + (size_t)R + 1);
+    t.slot_of = t.queue + BWD_QUEUE_BYTES / 4;
+    carve(p, t.part17, (size_t)records + 1);
+    carve(p, t.part16, 4 * ((size_t)records + 1));
     if (o) *o = t;
     return reinterpret_cast<size_t>(p) - p0;
 }
-size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered) { return bwd_scratch_layout(P, num_rendered, nullptr, nullptr) + ALIGN; }
+size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered) { return bwd_scratch_layout(P, num_rendered, num_rendered, nullptr, nullptr) + ALIGN; }
+size_t gof_backward_scratch_bytes_for(int32_t P, uint32_t num_rendered, uint32_t staged_entries)
+{
+    return bwd_scratch_layout(P, num_rendered, staged_entries < num_rendered ? staged_entries : num_rendered, nullptr, nullptr) + ALIGN;
+}
+// records a scratch of `bytes` bytes can hold (the inverse of gof_backward_scratch_bytes_for)
+static uint32_t bwd_scratch_records(int32_t P, uint32_t R, size_t bytes)
+{
+    const size_t fixed = bwd_scratch_layout(P, R, 0, nullptr, nullptr) + ALIGN;
+    if (bytes < fixed) return 0;
+    size_t n = (bytes - fixed) / 68 + 16;                   // (the pool arrays of the zero-record layout already hold one record and their alignment padding)
+    if (n > R) n = R;
+    while (n > 0 && bwd_scratch_layout(P, R, (uint32_t)n, nullptr, nullptr) + ALIGN > bytes) n--;      // (the two pool arrays are 256-byte aligned each)
+    return (uint32_t)n;
+}
 
 // stages: 1 = zero-fill + blend_backward (K8), 2 = preprocess_bwd (K9), 3 = both
 static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const int32_t* radii, const void* geom_ws, size_t geom_bytes,
@@ -552,9 +571,13 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
     if (!rc && (stages & 1)) rc = take_async_status();
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
-    if (!scratch || scratch_bytes < gof_backward_scratch_bytes(a->P, R)) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
+    if (!scratch || scratch_bytes < gof_backward_scratch_bytes_for(a->P, R, 0)) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
+    // the record pool is as large as the caller's buffer allows: R records (gof_backward_scratch_bytes: always enough) or the
+    // forward's staged count (gof_backward_query + gof_backward_scratch_bytes_for).  A pool that turns out too small raises the late
+    // status word (the next library call returns GOF_E_DEVICE) -- it cannot happen with either of the two sizes.
+    const uint32_t rec_cap = bwd_scratch_records(a->P, R, scratch_bytes);
     BwdScratch ws;
-    bwd_scratch_layout(a->P, R, aligned_base(scratch), &ws);
+    bwd_scratch_layout(a->P, R, rec_cap, aligned_base(scratch), &ws);
     if (!dL_dout || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !dL_dview2gaussian ||
         (a->M > 0 && a->shs && !dL_dsh) || !radii) { set_error("a gradient / radii pointer is NULL"); return GOF_E_INVALID; }
     const bool split_sh = a->shs_rest != nullptr;
@@ -588,21 +611,21 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
           GOF_HIP_CHECK(hipMemsetAsync(p0, 0, n, stream));
           i = j;
       }
-      if (R > 0) GOF_HIP_CHECK(hipMemsetAsync(ws.queue, 0, BWD_QUEUE_BYTES + (size_t)R, stream)); }
+      if (R > 0) GOF_HIP_CHECK(hipMemsetAsync(ws.queue, 0, BWD_QUEUE_BYTES + 4 * (size_t)R, stream)); }
 
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.valid, d.gx, d.ntiles,
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_NEXT, rec_cap, async_status_word(), d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);
       // R == 0: tiles_touched is 0 everywhere, the kernel writes zeros
       hipLaunchKernelGGL(gather_tile_partials, dim3((unsigned)(((size_t)a->P * 4 + 255) / 256)), dim3(256), 0, stream, a->P, ws.inst_off, g.tiles_touched, ws.part16, ws.part17,
-                         ws.valid, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian);
+                         ws.slot_of, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian);
       GOF_LAUNCH_CHECK(stream, a->debug); }
     }
     if (!(stages & 2)) return GOF_OK;
@@ -633,6 +656,28 @@ GOF_BACKWARD_ENTRY(gof_backward, 3)
 GOF_BACKWARD_ENTRY(gof_backward_blend, 1)
 GOF_BACKWARD_ENTRY(gof_backward_preprocess, 2)
 #undef GOF_BACKWARD_ENTRY
+
+// What the backward of the frame in `image_ws` will need: the number of tile-list entries it stages = records its scratch must hold
+// (sum over the tiles of the deepest blended list position, left by the forward's order_tiles_for_backward).  SYNCHRONISES `stream`
+// (one 4-byte read-back) -- by the time a training step calls its backward the forward has finished anyway.
+int gof_backward_query(const GofRasterArgs* a, uint32_t R, const void* image_ws, size_t image_bytes, uint32_t* staged_entries_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!staged_entries_host) { set_error("staged_entries_host is NULL"); return GOF_E_INVALID; }
+    *staged_entries_host = R;
+    if (a->P == 0 || R == 0) { *staged_entries_host = 0; return GOF_OK; }
+    if (!image_ws || image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace missing or too small"); return GOF_E_WORKSPACE; }
+    if (bw_order_by_length()) return GOF_OK;               // (developer toggle: the forward left no backward order, hence no sum)
+    ImageWs im;
+    image_layout(a->W, a->H, aligned_base(const_cast<void*>(image_ws)), &im);
+    uint32_t n = 0;
+    GOF_HIP_CHECK(hipMemcpyAsync(&n, im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipStreamSynchronize(stream));
+    *staged_entries_host = n < R ? n : R;
+    return GOF_OK;
+}
 
 int gof_integrate_prepare_points(const GofRasterArgs* a, int32_t PN, const float* points3D, void* point_ws, size_t point_bytes,
                                  uint32_t* num_integrated_host, void* stream_)

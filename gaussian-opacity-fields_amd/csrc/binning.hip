@@ -198,7 +198,21 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t stride = tile_queue_stride(ntiles);
     for (uint32_t k = tid; k < NW * NB; k += 1024) (&s_wc[0][0])[k] = 0u;
+    __shared__ uint32_t s_staged;
+    if (tid == 0) s_staged = 0u;
     __syncthreads();
+    {   // sum over the tiles of min(cost, list length) -> queue[BW_STAGED_WORD]: what a kernel that walks `cost` entries of every tile stages
+        uint32_t mine_sum = 0;
+        for (uint32_t t = tid; t < ntiles; t += 1024) {
+            const uint32_t len = ranges[t].y - ranges[t].x;
+            mine_sum += cost_in ? min(cost_in[t], len) : len;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine_sum += (uint32_t)__shfl_xor((int)mine_sum, o);
+        if (lane == 0) atomicAdd(&s_staged, mine_sum);
+    }
+    __syncthreads();
+    if (tid == 0 && queue) queue[BW_STAGED_WORD] = s_staged;
     auto bucket = [&](uint32_t t) -> uint32_t {
         uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);
         if (times_ranges) {            // the point pass of the opacity-field query: #points of the tile x (entries its pixels walked + a fixed per-point share)

@@ -17,8 +17,9 @@
 //         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
 //         entry and wave kept the LDS busy ~70 % of the time);
 //      4. after the batch, thread j adds the slabs of the waves that visited entry j (in wave order) and STORES the 16 sums (and the 17th value derived from the opacity sum) as
-//         the partial gradient of that (tile, Gaussian) instance -- plain stores into a record indexed by an instance number e
-//         in which the instances of one Gaussian, and of consecutive Gaussians, are consecutive -- plus a validity byte.  No
+//         the partial gradient of that (tile, Gaussian) instance -- plain stores into a 68-byte record of a POOL (one record per
+//         staged instance; a wave takes its batch's slots with one atomic on the pool's cursor), whose slot + 1 goes into a word
+//         indexed by an instance number e in which the instances of one Gaussian, and of consecutive Gaussians, are consecutive.  No
 //         global atomic at all: gather_tile_partials (below) then adds the records of every Gaussian in ascending e.  The reference's 17
 //         atomicAdd per contributing pair (and round 1's 45 M memory-side float atomics per frame, 795 MB of "writes" for
 //         67 MB of accumulators) are gone, and the gradients are bit-reproducible from run to run.
@@ -144,7 +145,8 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                     const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-                    float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx)
+                    float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_next,
+                    uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx)
 {
     TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -465,24 +467,39 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         }
         __syncthreads();
         // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, stored as the partial
-        // gradient record of this (tile, Gaussian) instance
-        if ((int)tid < n) {
+        // gradient record of this (tile, Gaussian) instance.  Records live in a POOL (round 4: the scratch holds a record per STAGED
+        // instance -- ~30 % of R at S1M -- not per instance): a wave takes as many consecutive slots as it has visited entries with
+        // one atomic on the pool's cursor, and leaves slot + 1 in slot_of[instance] (0 = no record), which gather_tile_partials reads
+        // where it read a validity byte before.  The values a Gaussian receives do not depend on WHICH slot held them: bit-reproducible.
+        if (tid < (uint32_t)BATCH) {                                   // (whole waves: BATCH is a multiple of 64)
             const uint32_t qw = tid >> 5, qb = 1u << (tid & 31u);
-            const bool v0 = (s_vis[0][qw] & qb) != 0u, v1 = (s_vis[1][qw] & qb) != 0u, v2 = (s_vis[2][qw] & qb) != 0u, v3 = (s_vis[3][qw] & qb) != 0u;
-            if (v0 | v1 | v2 | v3) {
-                const size_t e = s_inst[tid];
-                auto total = [&](int k) {
-                    float x = v0 ? s_slab[0][k][tid] : 0.f;
-                    x += v1 ? s_slab[1][k][tid] : 0.f;
-                    x += v2 ? s_slab[2][k][tid] : 0.f;
-                    x += v3 ? s_slab[3][k][tid] : 0.f;
-                    return x;
-                };
-                float4* dst = part16 + e * 4;
+            bool v0 = false, v1 = false, v2 = false, v3 = false;
+            if ((int)tid < n) { v0 = (s_vis[0][qw] & qb) != 0u; v1 = (s_vis[1][qw] & qb) != 0u; v2 = (s_vis[2][qw] & qb) != 0u; v3 = (s_vis[3][qw] & qb) != 0u; }
+            const bool live = v0 | v1 | v2 | v3;
+            const unsigned long long m = __ballot(live);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(rec_next, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+                if (live) {
+                    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (slot < rec_cap) {
+                        auto total = [&](int k) {
+                            float x = v0 ? s_slab[0][k][tid] : 0.f;
+                            x += v1 ? s_slab[1][k][tid] : 0.f;
+                            x += v2 ? s_slab[2][k][tid] : 0.f;
+                            x += v3 ? s_slab[3][k][tid] : 0.f;
+                            return x;
+                        };
+                        float4* dst = part16 + (size_t)slot * 4;
 #pragma unroll
-                for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
-                part17[e] = -0.5f * s_rec[3][tid].y * total(6);      // dL_dv2g[9], see the gradient block
-                part_valid[e] = 1;
+                        for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
+                        part17[slot] = -0.5f * s_rec[3][tid].y * total(6);      // dL_dv2g[9], see the gradient block
+                        slot_of[s_inst[tid]] = slot + 1u;
+                    } else {
+                        *async_status = 2u;      // the caller sized the scratch for fewer records than the forward staged (gof_backward_query)
+                    }
+                }
             }
         }
     }
@@ -500,27 +517,29 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-               float4* __restrict__ part16, float* __restrict__ part17, uint8_t* __restrict__ part_valid, uint32_t gx, uint32_t ntiles,
+               float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_next,
+               uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx, uint32_t ntiles,
                const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, const uint32_t* __restrict__ tile_lens)
 {
     __shared__ uint32_t s_tile;
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_backward_tile(tile, ranges, point_list, rec, conic, cmask, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
-                        inst_off, part16, part17, part_valid, gx);
+                        inst_off, part16, part17, slot_of, rec_next, rec_cap, async_status, gx);
 }
 
 // Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):
 // writes dL_dcolors [P,3], dL_dmean2D [P,3], dL_dopacity [P], dL_dview2gaussian [P,10] completely (zeros for Gaussians no pixel
 // blended), so none of them needs a memset.  A QUAD of lanes per Gaussian; instances are numbered in Gaussian-id order, so
-// validity bytes, records, counts, offsets and outputs are all visited in ascending address order: lane q of the quad owns values
+// slot words, counts, offsets and outputs are all visited in ascending address order (the records themselves lie where the backward's
+// waves happened to allocate them: one 64-byte line each); lane q of the quad owns values
 // 4q .. 4q+3 of the record, so a record is ONE 64-byte line read by four adjacent lanes (a thread per Gaussian issued four fully
 // address-divergent 16-byte loads per record and a divergent byte load per instance: 0.245 ms, bound by the address units, not by
-// bytes); the validity bytes are read by the quad together (lane q takes instances k0 + q and k0 + 4 + q) and handed round by DPP.
+// bytes); the slot words are read by the quad together (lane q takes instances k0 + q and k0 + 4 + q) and handed round by DPP.
 // (Adding 0.0f for an absent record leaves every bit of the sum unchanged, so the result is that of the plain ordered loop.)
 __global__ void __launch_bounds__(256)
 gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_t* __restrict__ tiles_touched,
-                     const float4* __restrict__ part16, const float* __restrict__ part17, const uint8_t* __restrict__ part_valid,
+                     const float4* __restrict__ part16, const float* __restrict__ part17, const uint32_t* __restrict__ slot_of,
                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dv2g)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -538,8 +557,8 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
 #define GOF_GATHER_TRIP(E0, N, K0)                                                                                   \
     {                                                                                                                  \
         const uint32_t ka = (K0) + q, kb = (K0) + 4u + q;                                                              \
-        const int va = (ka < (N)) ? (int)part_valid[(E0) + ka] : 0;                                                    \
-        const int vb = (kb < (N)) ? (int)part_valid[(E0) + kb] : 0;                                                    \
+        const int va = (ka < (N)) ? (int)slot_of[(E0) + ka] : 0;                                                       \
+        const int vb = (kb < (N)) ? (int)slot_of[(E0) + kb] : 0;                                                       \
         GOF_GATHER_TRIP_V(E0, K0, va, vb)                                                                              \
     }
 #define GOF_GATHER_TRIP_V(E0, K0, va, vb)                                                                            \
@@ -552,20 +571,21 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
     }
 #define GOF_GATHER_LOAD(E0, K0, J, V, CTRL)                                                                          \
         {                                                                                                              \
-            const bool ok = __builtin_amdgcn_update_dpp(0, V, CTRL, 0xf, 0xf, false) != 0;   /* quad_perm [j,j,j,j] */   \
-            const size_t e = (E0) + (K0) + J;                                                                          \
+            const uint32_t sl = (uint32_t)__builtin_amdgcn_update_dpp(0, V, CTRL, 0xf, 0xf, false);   /* quad_perm [j,j,j,j]: slot + 1 of instance (E0) + (K0) + J, 0 = no record */ \
+            const bool ok = sl != 0u;                                                                                  \
+            const size_t e = (size_t)(sl - 1u);                                                                        \
             r[J] = ok ? part16[e * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);                                           \
             r17[J] = (ok && q == 0u) ? part17[e] : 0.f;                                                                \
         }
     if (n && n <= BIG) {
-        // the validity bytes of the NEXT trip are requested before this trip's records: a trip then waits for one memory round trip,
+        // the slot words of the NEXT trip are requested before this trip's records: a trip then waits for one memory round trip,
         // not two (0.095 -> 0.086 ms; pipelining over several Gaussians per quad as well was measured slower, 0.097 ms)
-        int va = (q < n) ? (int)part_valid[e0 + q] : 0;
-        int vb = (4u + q < n) ? (int)part_valid[e0 + 4u + q] : 0;
+        int va = (q < n) ? (int)slot_of[e0 + q] : 0;
+        int vb = (4u + q < n) ? (int)slot_of[e0 + 4u + q] : 0;
         for (uint32_t k0 = 0; k0 < n; k0 += 8) {
             const uint32_t na = k0 + 8u + q, nb = k0 + 12u + q;
-            const int va_next = (na < n) ? (int)part_valid[e0 + na] : 0;
-            const int vb_next = (nb < n) ? (int)part_valid[e0 + nb] : 0;
+            const int va_next = (na < n) ? (int)slot_of[e0 + na] : 0;
+            const int vb_next = (nb < n) ? (int)slot_of[e0 + nb] : 0;
             GOF_GATHER_TRIP_V(e0, k0, va, vb)
             va = va_next; vb = vb_next;
         }

@@ -71,6 +71,8 @@ struct ImageWs {
 };
 constexpr int NXCD = 8;
 constexpr int TILE_QUEUE_WORDS = 64;
+constexpr int BW_STAGED_WORD = 16;      // queue[16] of an order_tiles call = sum over the tiles of min(cost, list length): for the backward's
+                                        // order (tile_queue[32 + 16]) the entries the backward stages = partial records it writes (gof_backward_query)
 // Binning workspace (replaces BinningState, rasterizer_impl.h:69-79)
 struct BinWs {
     uint32_t* vals;  uint32_t* vals_alt;          // [R]  vals = sorted point_list (Gaussian ids, per tile, front to back)

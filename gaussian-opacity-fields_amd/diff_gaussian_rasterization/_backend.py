@@ -43,7 +43,8 @@ def _load():
     lib.gof_last_error.restype = C.c_char_p
     lib.gof_abi_version.restype = C.c_int
     for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]),
-                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32, u32]), ("gof_mtets_tet_ws_bytes", [i64]),
+                       ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32, u32]), ("gof_backward_scratch_bytes_for", [i32, u32, u32]),
+                       ("gof_mtets_tet_ws_bytes", [i64]),
                        ("gof_mtets_edge_ws_bytes", [i64])):
         f = getattr(lib, name)
         f.restype = sz
@@ -53,6 +54,8 @@ def _load():
     lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_forward_fused.restype = C.c_int
     lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 10 + [vp, sz, vp]
+    lib.gof_backward_query.argtypes = [A, u32, vp, sz, C.POINTER(u32), vp]
+    lib.gof_backward_query.restype = C.c_int
     lib.gof_backward_blend.argtypes = lib.gof_backward_preprocess.argtypes = lib.gof_backward.argtypes
     lib.gof_backward_blend.restype = lib.gof_backward_preprocess.restype = C.c_int
     lib.gof_integrate_prepare_points.argtypes = [A, i32, vp, vp, sz, C.POINTER(u32), vp]
@@ -200,6 +203,7 @@ def _prepare_and_bin(v):
 
 GOF_E_CAPACITY = -5
 FUSED_FORWARD = os.environ.get("GOF_FUSED_FORWARD", "1") != "0"
+FULL_BACKWARD_SCRATCH = os.environ.get("GOF_FULL_BACKWARD_SCRATCH", "0") == "1"
 _capacity = {}          # (device, P, W, H) -> instance capacity learnt from earlier frames
 _stats = {"fused_redone_frames": 0, "last_num_rendered": 0}      # bench.py's `views` leg reads these (no effect on the path)
 _pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
@@ -319,7 +323,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):
             R = _layout_count(R)                  # the size the forward laid the binning workspace out for (NumRendered)
-            nscratch = lib.gof_backward_scratch_bytes(P, int(R))
+            # the record pool of the scratch: as many records as the forward staged entries (~30 % of R at S1M), asked of the image
+            # workspace -- one 4-byte read-back that waits for the forward, which a training step's backward follows anyway
+            # (GOF_FULL_BACKWARD_SCRATCH=1: the worst case, a record per instance, without the read-back)
+            if FULL_BACKWARD_SCRATCH:
+                nscratch = lib.gof_backward_scratch_bytes(P, int(R))
+            else:
+                staged = C.c_uint32(0)
+                _check(lib.gof_backward_query(v.ref(), int(R), _ptr(imageBuffer), imageBuffer.numel(), C.byref(staged), _stream()))
+                nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), int(staged.value))
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),

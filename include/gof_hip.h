@@ -147,10 +147,20 @@ int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
                       int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, void* stream);
 
 /* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
-/* Scratch the backward needs besides the outputs: per tile instance (num_rendered of them) the 68-byte partial gradient record the
- * per-pixel backward stores and the per-Gaussian gather adds up (no atomics), plus P offsets.  num_rendered = the
- * value the backward is called with. */
+/* Scratch the backward needs besides the outputs: P offsets, per tile instance (num_rendered of them) one slot word, and a POOL of
+ * 68-byte partial gradient records -- one per (tile, Gaussian) instance the per-pixel backward actually stages -- which the
+ * per-Gaussian gather adds up (no atomics).  num_rendered = the value the backward is called with.
+ *   gof_backward_scratch_bytes(P, R):                a pool of R records: always enough (every instance staged).
+ *   gof_backward_query(...):                         the number of entries the forward of this frame staged (~30 % of R at 1M
+ *                                                    Gaussians @ 1600x1063), read from the image workspace.  SYNCHRONISES `stream`.
+ *   gof_backward_scratch_bytes_for(P, R, staged):    the size for a pool of exactly that many records (4 + 68 x staged / R bytes per
+ *                                                    instance instead of 72).
+ * The backward derives the pool's capacity from the scratch_bytes it is given.  A pool smaller than what the frame stages (impossible
+ * with either size above) loses records and raises the late status word: the next library call returns GOF_E_DEVICE. */
 size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered);
+size_t gof_backward_scratch_bytes_for(int32_t P, uint32_t num_rendered, uint32_t staged_entries);
+int gof_backward_query(const GofRasterArgs* args, uint32_t num_rendered, const void* image_ws, size_t image_bytes,
+                       uint32_t* staged_entries_host, void* stream);
 /* dL_dout is [9,H,W].  All gradient outputs are fully written by the call (the library
  * zero-fills them itself; the reference binding allocates them with torch::zeros,
  * rasterize_points.cu:161-170).  dL_dcov3D [P,6] is all zero in the reference (its producer

@@ -124,7 +124,7 @@ class EmuScene:
                                            _p(self.img), self.img.size, _p(self.color), None))
         return self.color, self.radii
 
-    def backward(self, dL):
+    def backward(self, dL, full_scratch=False):
         lib, P, M = self.lib, self.P, self.M
         dl = _f32(dL)
         g = {"means2D": np.zeros((P, 3), np.float32), "colors": np.zeros((P, 3), np.float32), "opacity": np.zeros((P, 1), np.float32),
@@ -133,7 +133,15 @@ class EmuScene:
         for v in g.values():
             v.fill(np.nan)          # the library must write every element it owns
         g["cov3D"].fill(0)
-        nscratch = lib.gof_backward_scratch_bytes(P, self.R)
+        # the record pool sized for exactly what the forward staged (gof_backward_query), as the product's binding does; the guard
+        # bytes behind it catch a pool overrun.  full_scratch=True: the worst case, a record per instance
+        if full_scratch:
+            nscratch = lib.gof_backward_scratch_bytes(P, self.R)
+        else:
+            staged = C.c_uint32(0)
+            self._check(lib.gof_backward_query(C.byref(self.args), self.R, _p(self.img), self.img.size, C.byref(staged), None))
+            self.staged = int(staged.value)
+            nscratch = lib.gof_backward_scratch_bytes_for(P, self.R, self.staged)
         scratch = _aligned(nscratch, what="backward scratch")
         self._check(lib.gof_backward(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
                                      _p(self.img), self.img.size, _p(dl), _p(g["means2D"]), _p(g["colors"]), _p(g["opacity"]), _p(g["means3D"]), None,
