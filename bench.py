@@ -373,12 +373,20 @@ def workspace_report(B, P, W, H, R, staged):
     (DESIGN.md section 7): masks and records buy the backward without re-derived decisions and without atomics."""
     lib = B.lib
     geom, image = int(lib.gof_geom_bytes(P)), int(lib.gof_image_bytes(W, H))
-    binning = int(lib.gof_binning_bytes(R, W, H))
-    scratch_full, scratch = int(lib.gof_backward_scratch_bytes(P, R)), int(lib.gof_backward_scratch_bytes_for(P, R, staged))
-    d_bin = (int(lib.gof_binning_bytes(2 * R, W, H)) - binning) / max(R, 1)
+    binning_full = int(lib.gof_binning_bytes(R, W, H))
+    # what the shipped binding allocates in steady state: the instance capacity (1.25 x the count + 64 Ki) and a mask pool 1.25 x the
+    # largest request seen (learnt at the first backward) on top of the sort state
+    key = [k for k in B._capacity if k[1:] == (P, W, H)]
+    cap = B._capacity[key[0]] if key else R
+    sub = B._mask_pool_subchunks(key[0]) if key else None
+    binning = int(lib.gof_binning_bytes(cap, W, H) if sub is None else lib.gof_binning_bytes_for(cap, W, H, sub))
+    scratch_full, scratch = int(lib.gof_backward_scratch_bytes(P, R)), int(lib.gof_backward_scratch_bytes_for(P, cap, staged))
+    d_bin = binning / max(R, 1)
     fixed = int(lib.gof_backward_scratch_bytes_for(P, 0, 0))
     d_scr = (scratch - fixed) / max(R, 1)
-    return {"geometry_bytes": geom, "image_bytes": image, "binning_bytes": binning, "backward_scratch_bytes": scratch,
+    return {"geometry_bytes": geom, "image_bytes": image, "binning_bytes": binning, "binning_bytes_worst_case": binning_full,
+            "mask_subchunks_requested": (B._mask_need.get(key[0]) if key else None), "mask_subchunks_held": sub, "instance_capacity": cap,
+            "backward_scratch_bytes": scratch,
             "backward_scratch_bytes_worst_case": scratch_full, "staged_fraction_of_instances": round(staged / max(R, 1), 4),
             "per_gaussian_geometry_bytes": round(geom / max(P, 1), 1), "per_instance_binning_bytes": round(d_bin, 1),
             "per_instance_backward_scratch_bytes": round(d_scr, 1), "per_instance_total_bytes": round(d_bin + d_scr, 1),

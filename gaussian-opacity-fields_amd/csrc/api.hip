@@ -58,14 +58,14 @@ __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* 
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
-                              float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
+                              float* out_color, MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                               uint32_t* tile_cost);
 __global__ void blend_forward_exact(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                                     float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
-                                    float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
+                                    float* out_color, MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                                     uint32_t* tile_cost);
 __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges);
-__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, const uint32_t* cmask,
+__global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
                                float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_next, uint32_t rec_cap, uint32_t* async_status,
@@ -210,7 +210,7 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
     if (out) *out = im;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
-size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool with_masks)
+size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, BinMode mode, size_t bytes)
 {
     BinWs b;
     char* p = static_cast<char*>(base);
@@ -218,15 +218,51 @@ size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool
     const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     carve(p, b.vals, n);            // sorted point_list first: the only part the backward reads
     carve(p, b.tiles, n);
+    b.cmask = nullptr; b.pt_xy = nullptr; b.pt_depth = nullptr; b.pt_T = nullptr; b.pt_acc = nullptr; b.pt_order = nullptr; b.pt_queue = nullptr;
+    b.mp.table = nullptr; b.mp.pool = nullptr; b.mp.cap = 0;
+    if (mode == BIN_MASK_POOL) {
+        // [table][sort scratch][vals_alt][tiles_alt] and the pool ON TOP of the two ping-pong buffers: they are dead once the tile
+        // sort has left its result in vals / tiles, i.e. before blend_forward writes the first mask word
+        carve(p, b.mp.table, 4 * mask_slots(n, T));
+        carve(p, b.sort_tmp, rs_tmp_words(n));
+        char* const pool0 = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(p)));
+        carve(p, b.vals_alt, n);
+        carve(p, b.tiles_alt, n);
+        b.mp.pool = reinterpret_cast<uint32_t*>(pool0);
+        const size_t sub = (size_t)MASK_SUBCHUNK_WORDS * sizeof(uint32_t);
+        const size_t full = 4 * mask_slots(n, T);
+        const size_t head = (size_t)(pool0 - static_cast<char*>(base)) + ALIGN;      // bytes in front of the pool (incl. the caller's alignment slack)
+        size_t cap = full;
+        if (bytes) cap = bytes > head ? (bytes - head) / sub : 0;
+        if (cap > full) cap = full;
+        b.mp.cap = (uint32_t)cap;
+        char* const pool_end = pool0 + cap * sub;
+        if (pool_end > p) p = pool_end;
+        if (out) *out = b;
+        return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+    }
     carve(p, b.vals_alt, n);
     carve(p, b.tiles_alt, n);
     carve(p, b.sort_tmp, rs_tmp_words(n));
-    b.cmask = nullptr; b.pt_xy = nullptr; b.pt_depth = nullptr; b.pt_T = nullptr; b.pt_acc = nullptr; b.pt_order = nullptr; b.pt_queue = nullptr;
-    if (with_masks) carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
+    if (mode == BIN_STATIC_MASKS) carve(p, b.cmask, cmask_words(n, T) * TILE_PIX);
     else { carve(p, b.pt_xy, n); carve(p, b.pt_depth, n); carve(p, b.pt_T, n); carve(p, b.pt_acc, n);
            carve(p, b.pt_order, (size_t)NXCD * tile_queue_stride((uint32_t)T)); carve(p, b.pt_queue, (size_t)TILE_QUEUE_WORDS); }
     if (out) *out = b;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
+}
+// size of a BIN_MASK_POOL workspace whose pool holds `subchunks` sub-chunks (never less than the sort state needs)
+static size_t bin_static_bytes(uint32_t R, int32_t W, int32_t H) { return bin_layout(R, W, H, nullptr, nullptr, BIN_STATIC_MASKS) + ALIGN; }
+static size_t bin_pool_bytes(uint32_t R, int32_t W, int32_t H, size_t subchunks)
+{
+    BinWs b;
+    const size_t full_bytes = bin_layout(R, W, H, nullptr, &b, BIN_MASK_POOL, 0);
+    const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    const size_t full = 4 * mask_slots((size_t)R, T);
+    if (subchunks >= full) return full_bytes;
+    const size_t head = reinterpret_cast<size_t>(b.mp.pool) + ALIGN;                                   // (base is null: the pointer IS the offset)
+    const size_t alt_end = reinterpret_cast<size_t>(b.tiles_alt) + align_up((size_t)R * sizeof(uint32_t)) + ALIGN;
+    const size_t want = head + subchunks * (size_t)MASK_SUBCHUNK_WORDS * sizeof(uint32_t);
+    return want > alt_end ? want : alt_end;
 }
 size_t point_layout(int32_t PN, void* base, PointWs* out)
 {
@@ -350,7 +386,7 @@ static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const Ge
     auto* kernel = g_forward_exact.load(std::memory_order_relaxed) ? blend_forward_exact : blend_forward;
     hipLaunchKernelGGL(kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
+                       im.final_T, im.n_contrib, out_color, b.mp, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
 }
 
 } // namespace gof
@@ -368,8 +404,14 @@ int gof_abi_version(void) { return 9; }   // 8: gof_set_forward_exact / gof_set_
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
-size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H) { return bin_layout(R, W, H, nullptr, nullptr, true) + ALIGN; }
-size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_layout(NI, W, H, nullptr, nullptr, false) + ALIGN; }
+// one size for both users of a binning workspace: the opacity-field query (static masks) and the forward blend with a FULL mask pool
+size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H)
+{
+    const size_t a = bin_layout(R, W, H, nullptr, nullptr, BIN_STATIC_MASKS), b = bin_pool_bytes(R, W, H, (size_t)-1);
+    return (a > b ? a : b) + ALIGN;
+}
+size_t gof_binning_bytes_for(uint32_t R, int32_t W, int32_t H, uint32_t mask_subchunks) { return bin_pool_bytes(R, W, H, mask_subchunks) + ALIGN; }
+size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_layout(NI, W, H, nullptr, nullptr, BIN_POINTS) + ALIGN; }
 size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
 
 // preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
@@ -456,12 +498,12 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     if (!num_rendered_pinned_host || !out_color) { set_error("num_rendered_pinned_host / out_color is NULL"); return GOF_E_INVALID; }
     if (a->P == 0 || a->prefiltered || a->debug) { set_error("gof_forward_fused: empty / prefiltered / debug calls use gof_forward_prepare + gof_forward_render"); return GOF_E_INVALID; }
     if (!radii || !geom_ws || !binning_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(capacity, a->W, a->H)) {
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(capacity, a->W, a->H, 0)) {
         set_error("workspace too small (geom %zu, image %zu, binning %zu)", geom_bytes, image_bytes, binning_bytes); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(capacity, a->W, a->H, aligned_base(binning_ws), &b, true);
+    bin_layout(capacity, a->W, a->H, aligned_base(binning_ws), &b, BIN_MASK_POOL, binning_bytes);
     const Dims d = dims_of(a);
     const uint32_t* total_dev = nullptr;
     rc = forward_stage1(a, g, im, radii, &total_dev, stream);
@@ -505,12 +547,12 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
         return GOF_OK;
     }
     if (!radii || !geom_ws || !binning_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(R, a->W, a->H, 0)) {
         set_error("workspace too small (geom %zu, image %zu, binning %zu)", geom_bytes, image_bytes, binning_bytes); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, BIN_MASK_POOL, binning_bytes);
     const Dims d = dims_of(a);
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
@@ -583,12 +625,12 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
     const bool split_sh = a->shs_rest != nullptr;
     if (split_sh != (dL_dsh_rest != nullptr)) { set_error("dL_dsh_rest must be given exactly when args->shs_rest is"); return GOF_E_INVALID; }
     if (!a->scales || !a->rotations) { set_error("backward needs scales and rotations (backward.cu:621)"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(R, a->W, a->H, 0)) {
         set_error("workspace too small"); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, BIN_MASK_POOL, binning_bytes);
     const Dims d = dims_of(a);
     const size_t P = (size_t)a->P;
     // torch::zeros of the binding (rasterize_points.cu:161-170): needed for what blend_backward ACCUMULATES into and for the dead
@@ -617,7 +659,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_PROFILE("blend_backward", stream);
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                           im.ranges, b.vals, g.rec, g.conic, b.cmask, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
+                           im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
                            im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_NEXT, rec_cap, async_status_word(), d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
@@ -657,25 +699,32 @@ GOF_BACKWARD_ENTRY(gof_backward_blend, 1)
 GOF_BACKWARD_ENTRY(gof_backward_preprocess, 2)
 #undef GOF_BACKWARD_ENTRY
 
-// What the backward of the frame in `image_ws` will need: the number of tile-list entries it stages = records its scratch must hold
-// (sum over the tiles of the deepest blended list position, left by the forward's order_tiles_for_backward).  SYNCHRONISES `stream`
-// (one 4-byte read-back) -- by the time a training step calls its backward the forward has finished anyway.
-int gof_backward_query(const GofRasterArgs* a, uint32_t R, const void* image_ws, size_t image_bytes, uint32_t* staged_entries_host, void* stream_)
+// What the backward of the frame in `image_ws` will need, and whether the forward's mask pool was large enough:
+//   out3_host[0] = tile-list entries the backward stages = records its scratch must hold (sum over the tiles of the deepest blended
+//                  list position, left by the forward's order_tiles_for_backward),
+//   out3_host[1] = sub-chunks of contributor masks the forward asked for, out3_host[2] = sub-chunks a binning workspace of
+//                  `binning_bytes` holds: [1] > [2] means masks are missing -- repeat the frame's forward with a binning workspace of
+//                  gof_binning_bytes_for(R, W, H, out3_host[1]) or more before calling its backward.
+// SYNCHRONISES `stream` (8 bytes read back) -- by the time a training step calls its backward the forward has finished anyway.
+int gof_backward_query(const GofRasterArgs* a, uint32_t R, size_t binning_bytes, const void* image_ws, size_t image_bytes, uint32_t* out3_host, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
     if (rc) return rc;
-    if (!staged_entries_host) { set_error("staged_entries_host is NULL"); return GOF_E_INVALID; }
-    *staged_entries_host = R;
-    if (a->P == 0 || R == 0) { *staged_entries_host = 0; return GOF_OK; }
+    if (!out3_host) { set_error("out3_host is NULL"); return GOF_E_INVALID; }
+    out3_host[0] = R; out3_host[1] = 0; out3_host[2] = 0;
+    if (a->P == 0 || R == 0) { out3_host[0] = 0; return GOF_OK; }
     if (!image_ws || image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace missing or too small"); return GOF_E_WORKSPACE; }
-    if (bw_order_by_length()) return GOF_OK;               // (developer toggle: the forward left no backward order, hence no sum)
-    ImageWs im;
+    ImageWs im; BinWs b;
     image_layout(a->W, a->H, aligned_base(const_cast<void*>(image_ws)), &im);
-    uint32_t n = 0;
-    GOF_HIP_CHECK(hipMemcpyAsync(&n, im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    bin_layout(R, a->W, a->H, nullptr, &b, BIN_MASK_POOL, binning_bytes);
+    out3_host[2] = b.mp.cap;
+    uint32_t words[2] = { 0, 0 };
+    GOF_HIP_CHECK(hipMemcpyAsync(&words[0], im.tile_queue + MASK_NEXT_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipMemcpyAsync(&words[1], im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
-    *staged_entries_host = n < R ? n : R;
+    out3_host[1] = words[0];
+    if (!bw_order_by_length()) out3_host[0] = words[1] < R ? words[1] : R;      // (developer toggle: the forward left no backward order, hence no sum: worst case)
     return GOF_OK;
 }
 
@@ -719,12 +768,12 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
     if (!radii || !out_color) { set_error("an output / radii pointer is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes(R, a->W, a->H)) {
+    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < bin_static_bytes(R, a->W, a->H)) {
         set_error("workspace too small"); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
+    bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, BIN_STATIC_MASKS);
     const Dims d = dims_of(a);
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
@@ -778,7 +827,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     // the accumulating variants may leave out the image and the colour
     if (!base_color || !out_alpha_integrated || (!acc_min && (!out_color || !out_color_integrated))) { set_error("an output pointer is NULL"); return GOF_E_INVALID; }
     if (geom_bytes < (packed ? gof_integrate_packed_geom_bytes(a->P) : gof_geom_bytes(a->P)) || image_bytes < gof_image_bytes(a->W, a->H) ||
-        binning_bytes < gof_binning_bytes(R, a->W, a->H) ||
+        binning_bytes < bin_static_bytes(R, a->W, a->H) ||
         point_bytes < gof_point_bytes(PN) || point_binning_bytes < gof_point_binning_bytes(NI, a->W, a->H)) { set_error("workspace too small"); return GOF_E_WORKSPACE; }
     const SplatRec* rec_ptr; const float* zfront_ptr; int zstride;
     if (packed) { packed_geom_layout(a->P, aligned_base(const_cast<void*>(geom_ws)), &rec_ptr, &zfront_ptr); zstride = 1; }
@@ -786,9 +835,9 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
            zfront_ptr = reinterpret_cast<const float*>(gg.fconic) + 7; zstride = 8; }        // fconic[2i + 1].w
     ImageWs im; BinWs b, pb; PointWs w;
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    bin_layout(R, a->W, a->H, aligned_base(const_cast<void*>(binning_ws)), &b, true);
+    bin_layout(R, a->W, a->H, aligned_base(const_cast<void*>(binning_ws)), &b, BIN_STATIC_MASKS);
     point_layout(PN, aligned_base(point_ws), &w);
-    bin_layout(NI, a->W, a->H, aligned_base(point_binning_ws), &pb, false);
+    bin_layout(NI, a->W, a->H, aligned_base(point_binning_ws), &pb, BIN_POINTS);
     const Dims d = dims_of(a);
     // one stable sort of the visible points by (tile, pixel of the tile): 3 radix passes (see point_keys)
     { GOF_PROFILE("bin_points", stream);
@@ -971,7 +1020,7 @@ __global__ void unpack_rec(int P, const SplatRec* __restrict__ rec, const float4
 // per tile: number of contributing (pixel, list entry) pairs = set bits of the contributor masks blend_forward left, over the
 // words the backward reads (positions below the tile's last contributor)
 __global__ void __launch_bounds__(256)
-count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ cmask,
+count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_contrib, const MaskPool masks,
                          int W, int H, uint32_t gx, uint32_t ntiles, uint32_t* __restrict__ out, int hash)
 {
     // hash != 0: a position-sensitive checksum of the same words instead of their bit count (two forward modes that agree on it agree
@@ -988,10 +1037,11 @@ count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __res
     __syncthreads();
     const uint2 range = ranges[tile];
     const uint32_t max_last = min(s_max, range.y - range.x);
-    const uint32_t* cm = cmask + cmask_base(range.x, tile) * TILE_PIX;
+    const uint32_t* entry = masks.table + (mask_slot0(range.x, tile) * 4 + (tid >> 6));
     uint32_t c = 0;
     for (uint32_t w = 0; w < (max_last + 31) / 32; w++) {
-        uint32_t word = cm[(size_t)w * TILE_PIX + tid];
+        const uint32_t sub = entry[(size_t)(w >> 3) * 4];
+        uint32_t word = (sub == MASK_ZERO || sub >= masks.cap) ? 0u : masks.pool[(size_t)sub * MASK_SUBCHUNK_WORDS + (w & 7u) * 64u + (tid & 63u)];
         if (w == max_last / 32 && (max_last & 31u)) word &= (1u << (max_last & 31u)) - 1u;      // (positions the backward never stages)
         c += hash ? word * (2u * (w * TILE_PIX + tid) + 1u) + (word >> 7) : (uint32_t)__popc(word);
     }
@@ -1010,7 +1060,7 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
     const Dims d = dims_of(a);
     if (geom_ws) geom_layout(a->P, aligned_base(geom_ws), &g);
     if (image_ws) image_layout(a->W, a->H, aligned_base(image_ws), &im);
-    if (binning_ws) bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, true);
+    if (binning_ws) bin_layout(R, a->W, a->H, aligned_base(binning_ws), &b, BIN_MASK_POOL);      // (the sorted lists lie at the same offsets in every mode)
     const void* src = nullptr; size_t bytes = 0; int64_t count = 0;
     int unpack = -1; size_t per = 0; bool bytes_out = false;
     const std::string n(name);
@@ -1030,7 +1080,7 @@ extern "C" int64_t gof_debug_fetch(const char* name, const GofRasterArgs* a, uin
     }
     else if ((n == "contrib_pairs" || n == "contrib_hash") && binning_ws && image_ws) {
         if (dst_bytes < (size_t)d.ntiles * 4) { set_error("dst too small"); return GOF_E_INVALID; }
-        hipLaunchKernelGGL(count_contributing_pairs, dim3(d.ntiles), dim3(256), 0, stream, im.ranges, im.n_contrib, b.cmask, a->W, a->H, d.gx, d.ntiles,
+        hipLaunchKernelGGL(count_contributing_pairs, dim3(d.ntiles), dim3(256), 0, stream, im.ranges, im.n_contrib, b.mp, a->W, a->H, d.gx, d.ntiles,
                            static_cast<uint32_t*>(dst), n == "contrib_hash" ? 1 : 0);
         if (hipGetLastError() != hipSuccess) { set_error("count_contributing_pairs launch failed"); return GOF_E_DEVICE; }
         return (int64_t)d.ntiles;

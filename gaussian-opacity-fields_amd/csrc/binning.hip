@@ -201,20 +201,13 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
     __shared__ uint32_t s_staged;
     if (tid == 0) s_staged = 0u;
     __syncthreads();
-    {   // sum over the tiles of min(cost, list length) -> queue[BW_STAGED_WORD]: what a kernel that walks `cost` entries of every tile stages
-        uint32_t mine_sum = 0;
-        for (uint32_t t = tid; t < ntiles; t += 1024) {
-            const uint32_t len = ranges[t].y - ranges[t].x;
-            mine_sum += cost_in ? min(cost_in[t], len) : len;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mine_sum += (uint32_t)__shfl_xor((int)mine_sum, o);
-        if (lane == 0) atomicAdd(&s_staged, mine_sum);
-    }
-    __syncthreads();
-    if (tid == 0 && queue) queue[BW_STAGED_WORD] = s_staged;
+    // (on the way: the sum over the tiles of min(cost, list length) -> queue[BW_STAGED_WORD]: what a kernel that walks `cost` entries
+    // of every tile stages -- accumulated where the counting pass reads every tile's cost once anyway)
+    uint32_t staged_sum = 0;
+    bool counting = true;
     auto bucket = [&](uint32_t t) -> uint32_t {
-        uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);
+        uint32_t c = cost_in ? cost_in[t] : (ranges[t].y - ranges[t].x);      // (a measured cost never exceeds the list length)
+        if (counting) staged_sum += c;
         if (times_ranges) {            // the point pass of the opacity-field query: #points of the tile x (entries its pixels walked + a fixed per-point share)
             const unsigned long long m = (unsigned long long)(times_ranges[t].y - times_ranges[t].x) * (unsigned long long)(c + 32u);
             c = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m;
@@ -265,7 +258,14 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
         match(i < t1, bkt, r_, c_);
         if (c_) s_wc[wave][bkt] += c_;
     }
+    counting = false;
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) staged_sum += (uint32_t)__shfl_xor((int)staged_sum, o);
+        if (lane == 0 && staged_sum) atomicAdd(&s_staged, staged_sum);
+    }
     __syncthreads();
+    if (tid == 0 && queue) { queue[BW_STAGED_WORD] = s_staged; queue[MASK_NEXT_WORD] = 0u; }      // (+ the mask pool's cursor: the forward blend of this frame starts at sub-chunk 0)
     {   // per bucket: exclusive prefix over the waves (ascending tile id), total n_b; then G_b = tiles in heavier buckets
         uint32_t run = 0, inc = 0;
         if (tid < NB) {

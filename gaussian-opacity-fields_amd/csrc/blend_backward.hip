@@ -142,7 +142,7 @@ __device__ __forceinline__ float lane_xor(float v, uint32_t lane, uint32_t mask)
 // one tile; called by all 256 threads of the workgroup (persistent loop in blend_backward)
 __device__ __forceinline__ void
 blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-                    const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
+                    const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                     const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
                     float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_next,
@@ -165,7 +165,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     const f2 PXM = { (float)px, (float)py };       // pixf - 0.5 (backward.cu:770), exact
 
     const uint2 range = ranges[tile];
-    const uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
+    const uint32_t* const mask_entry = masks.table + (mask_slot0(range.x, tile) * 4 + (tid >> 6));      // this wave's sub-chunks, one per forward batch of 256 entries
 
     // LDS record of a staged entry, arranged as the operand pairs of the packed arithmetic (v = view2gaussian):
     //   q0 = {v0, v1 | v1, v3}, q1 = {v2, v4 | v2, v6}, q2 = {v4, v7 | v5, v8}   (prelude, as in blend_forward)
@@ -252,9 +252,11 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         uint32_t cmw[BATCH / 32];
         {
             const int nw = (n + 31) >> 5;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_entry[(size_t)(p0 >> 8) * 4]);      // MASK_ZERO: the wave was saturated in that batch
+            const uint32_t* const src = masks.pool + (size_t)c * MASK_SUBCHUNK_WORDS + ((p0 & 255u) >> 5) * 64u + lane;
 #pragma unroll
             for (int q = 0; q < BATCH / 32; q++)
-                cmw[q] = (q < nw) ? cm_tile[((size_t)(p0 >> 5) + q) * TILE_PIX + tid] : 0u;
+                cmw[q] = (q < nw && c != MASK_ZERO) ? src[q * 64] : 0u;
         }
         __syncthreads();
         if (tid == 0) BSTAT_ADD(4, n);
@@ -514,7 +516,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_BW_MIN_WAVES, 8)))
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
-               const float4* __restrict__ conic, const uint32_t* __restrict__ cmask, int W, int H, float focal_x, float focal_y,
+               const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
                float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_next,
@@ -524,7 +526,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     __shared__ uint32_t s_tile;
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
-    blend_backward_tile(tile, ranges, point_list, rec, conic, cmask, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
+    blend_backward_tile(tile, ranges, point_list, rec, conic, masks, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
                         inst_off, part16, part17, slot_of, rec_next, rec_cap, async_status, gx);
 }
 

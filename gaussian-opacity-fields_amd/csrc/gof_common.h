@@ -71,14 +71,35 @@ struct ImageWs {
 };
 constexpr int NXCD = 8;
 constexpr int TILE_QUEUE_WORDS = 64;
+constexpr int MASK_NEXT_WORD = 17;      // tile_queue[17]: cursor of the contributor-mask pool (sub-chunks requested so far; cleared by order_tiles with the heads)
 constexpr int BW_STAGED_WORD = 16;      // queue[16] of an order_tiles call = sum over the tiles of min(cost, list length): for the backward's
                                         // order (tile_queue[32 + 16]) the entries the backward stages = partial records it writes (gof_backward_query)
+// Contributor masks of the forward / backward blend (round 4): one bit per (pixel of the tile, list position), set by blend_forward
+// when that entry contributed to the pixel -- exactly the pairs the backward has to visit (backward.cu:763-805).  Rounds 1-3 reserved
+// 32 B for EVERY instance (static layout, cmask_base below: still what the opacity-field query uses); the forward only visits ~40 % of
+// the lists, so the words now live in a POOL of 2 KB sub-chunks -- 8 words x 64 lanes = one wave's pixels x one staged batch of 256
+// entries -- which a wave takes from a cursor (one atomic) when it has something to write.  table[(slot0(tile) + batch) * 4 + wave]
+// names the sub-chunk (MASK_ZERO: the wave was saturated, all its words of that batch are 0); slot0 needs no scan:
+// sum_{t' < t} ceil(len_t' / 256) <= ranges[t].x / 256 + t.  The pool's capacity is whatever the caller's binning workspace leaves
+// behind the sort state (gof_binning_bytes_for); a request beyond it is counted but not stored, and the caller learns from
+// gof_backward_query (requested vs capacity) that this frame's forward has to be repeated with more room before its backward.
+struct MaskPool {
+    uint32_t* table;      // [4 * mask_slots(R, T)]
+    uint32_t* pool;       // [cap][8][64]
+    uint32_t cap;         // sub-chunks the pool holds
+};
+constexpr uint32_t MASK_ZERO = 0xFFFFFFFEu;
+constexpr uint32_t MASK_SUBCHUNK_WORDS = 8u * 64u;
+__host__ __device__ inline size_t mask_slots(size_t R, size_t ntiles) { return R / 256 + ntiles + 2; }
+__device__ __forceinline__ size_t mask_slot0(uint32_t range_start, uint32_t tile) { return (size_t)(range_start >> 8) + tile; }
+
 // Binning workspace (replaces BinningState, rasterizer_impl.h:69-79)
 struct BinWs {
     uint32_t* vals;  uint32_t* vals_alt;          // [R]  vals = sorted point_list (Gaussian ids, per tile, front to back)
     uint32_t* tiles; uint32_t* tiles_alt;         // [R]  tiles = tile id of every sorted instance
     uint32_t* sort_tmp;                           // rs_tmp_words(R) words
-    uint32_t* cmask;                              // [cmask_words(R, T)][256] contributor bit masks written by blend_forward
+    uint32_t* cmask;                              // [cmask_words(R, T)][256] contributor bit masks of the opacity-field query (static layout: integrate_pixels / integrate_points)
+    MaskPool mp;                                  // contributor masks of the forward / backward blend (pool; aliases vals_alt / tiles_alt, dead after the tile sort)
     // query-point variant (integrate): per-point data gathered into LIST order, so the point pass streams it
     float2* pt_xy; float* pt_depth; float* pt_T; float* pt_acc;   // [NI]
     uint32_t* pt_order; uint32_t* pt_queue;                       // [T + 8], [TILE_QUEUE_WORDS]: dispatch order of integrate_points (pop_tile)
@@ -101,7 +122,9 @@ struct Cam {
 
 size_t geom_layout(int32_t P, void* base, GeomWs* out);
 size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out);
-size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, bool with_masks);
+enum BinMode { BIN_POINTS = 0, BIN_STATIC_MASKS = 1, BIN_MASK_POOL = 2 };
+// BIN_MASK_POOL: `bytes` = size of the caller's buffer (the pool takes what is left; 0 = the full capacity, 4 * mask_slots sub-chunks)
+size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, BinMode mode, size_t bytes = 0);
 size_t point_layout(int32_t PN, void* base, PointWs* out);
 
 // ---- error handling ----------------------------------------------------------------------------
@@ -142,9 +165,8 @@ __device__ __forceinline__ uint32_t tile_thread(uint32_t lx, uint32_t ly)
     return (wave << 6) + (row << 4) + ((ly & 3u) << 2) + (lx & 3u);
 }
 
-// Contributor masks: for every pixel of a tile one bit per tile-list position, set by blend_forward when that
-// entry contributed to the pixel (passed the alpha test before the pixel saturated) -- exactly the set of pairs the
-// backward has to visit (backward.cu:763-805).  Tile t's words start at cmask_base(ranges[t].x, t): since
+// Contributor masks, STATIC layout (the opacity-field query: integrate_pixels writes, integrate_points reads): for every pixel of a
+// tile one bit per tile-list position.  Tile t's words start at cmask_base(ranges[t].x, t): since
 // sum_{t' < t} ceil(len_t' / 32) <= ranges[t].x / 32 + t, the bases need no scan and never overlap.
 // Layout [word][thread] (256 threads), so a wave reads / writes 256 contiguous bytes per word.
 __host__ __device__ inline size_t cmask_words(size_t R, size_t ntiles) { return R / 32 + ntiles + 2; }

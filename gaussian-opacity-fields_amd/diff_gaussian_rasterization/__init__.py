@@ -51,6 +51,20 @@ def _call_with_snapshot(fn, args, debug, dump_name, what):
         raise
 
 
+def _backward_with_mask_pool_redo(rs, args_of, fwd_args, geomBuffer, num_rendered, binningBuffer, imgBuffer):
+    """The native backward; if the frame's forward ran with a contributor-mask pool that turned out too small (learnt capacity,
+    _backend.MaskPoolTooSmall -- raised before anything is launched), its forward is repeated here with a full pool -- same inputs,
+    hence the same image, lists and masks, now complete -- and the backward runs on those workspaces."""
+    try:
+        return _call_with_snapshot(_C.rasterize_gaussians_backward, args_of(geomBuffer, num_rendered, binningBuffer, imgBuffer),
+                                   rs.debug, "snapshot_bw.dump", "backward")
+    except _C.MaskPoolTooSmall:
+        _C._stats["mask_pool_redone_frames"] += 1
+        num_rendered, _color, _radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*fwd_args, fused=False)
+        return _call_with_snapshot(_C.rasterize_gaussians_backward, args_of(geomBuffer, num_rendered, binningBuffer, imgBuffer),
+                                   rs.debug, "snapshot_bw.dump", "backward")
+
+
 def _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, sh):
     """Argument order of the native forward/integrate entry points after the leading (bg[, points3D])."""
     return (means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view2gaussian_precomp,
@@ -69,8 +83,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # (opacities: not an input of the reference's backward; kept -- a reference, no copy -- for the one case in which the frame's
+        # forward has to be repeated before its backward: _backward_with_mask_pool_redo)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
-                              geomBuffer, binningBuffer, imgBuffer)
+                              geomBuffer, binningBuffer, imgBuffer, opacities)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
@@ -78,14 +94,16 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
-         geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
-        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-                view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size,
-                rs.subpixel_offset, grad_out_color, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
-                binningBuffer, imgBuffer, rs.debug)
+         geomBuffer, binningBuffer, imgBuffer, opacities) = ctx.saved_tensors
+
+        def args_of(geom, num_rendered, binning, img):
+            return (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size,
+                    rs.subpixel_offset, grad_out_color, sh, rs.sh_degree, rs.campos, geom, num_rendered, binning, img, rs.debug)
+        fwd_args = (rs.bg,) + _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, sh)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_view2gaussian_precomp) = _call_with_snapshot(
-            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+         grad_rotations, grad_view2gaussian_precomp) = _backward_with_mask_pool_redo(
+            rs, args_of, fwd_args, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer)
         # one gradient per forward input, in the forward's order (reference :152-165)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, grad_view2gaussian_precomp, None)
@@ -125,7 +143,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest,
-                              geomBuffer, binningBuffer, imgBuffer)
+                              geomBuffer, binningBuffer, imgBuffer, opacities)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
@@ -133,13 +151,16 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
     def backward(ctx, grad_out_color, _):
         rs = ctx.raster_settings
         (means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest, geomBuffer, binningBuffer,
-         imgBuffer) = ctx.saved_tensors
-        args = (rs.bg, means3D, radii, torch.Tensor([]), scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-                view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size,
-                rs.subpixel_offset, grad_out_color, (sh_dc, sh_rest), rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
-                binningBuffer, imgBuffer, rs.debug)
+         imgBuffer, opacities) = ctx.saved_tensors
+        empty = torch.Tensor([])
+
+        def args_of(geom, num_rendered, binning, img):
+            return (rs.bg, means3D, radii, empty, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    view2gaussian_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size,
+                    rs.subpixel_offset, grad_out_color, (sh_dc, sh_rest), rs.sh_degree, rs.campos, geom, num_rendered, binning, img, rs.debug)
+        fwd_args = (rs.bg,) + _view_args(rs, means3D, empty, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, (sh_dc, sh_rest))
         (grad_means2D, _gc, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations,
-         grad_view2gaussian_precomp) = _call_with_snapshot(_C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+         grad_view2gaussian_precomp) = _backward_with_mask_pool_redo(rs, args_of, fwd_args, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer)
         return (grad_means3D, grad_means2D, grad_sh[0], grad_sh[1], grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, grad_view2gaussian_precomp, None)
 

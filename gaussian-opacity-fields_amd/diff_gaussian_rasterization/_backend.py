@@ -42,7 +42,7 @@ def _load():
     A = C.POINTER(GofRasterArgs)
     lib.gof_last_error.restype = C.c_char_p
     lib.gof_abi_version.restype = C.c_int
-    for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]),
+    for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]), ("gof_binning_bytes_for", [u32, i32, i32, u32]),
                        ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32, u32]), ("gof_backward_scratch_bytes_for", [i32, u32, u32]),
                        ("gof_mtets_tet_ws_bytes", [i64]),
                        ("gof_mtets_edge_ws_bytes", [i64])):
@@ -54,7 +54,7 @@ def _load():
     lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
     lib.gof_forward_fused.restype = C.c_int
     lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 10 + [vp, sz, vp]
-    lib.gof_backward_query.argtypes = [A, u32, vp, sz, C.POINTER(u32), vp]
+    lib.gof_backward_query.argtypes = [A, u32, sz, vp, sz, C.POINTER(u32), vp]
     lib.gof_backward_query.restype = C.c_int
     lib.gof_backward_blend.argtypes = lib.gof_backward_preprocess.argtypes = lib.gof_backward.argtypes
     lib.gof_backward_blend.restype = lib.gof_backward_preprocess.restype = C.c_int
@@ -204,8 +204,27 @@ def _prepare_and_bin(v):
 GOF_E_CAPACITY = -5
 FUSED_FORWARD = os.environ.get("GOF_FUSED_FORWARD", "1") != "0"
 FULL_BACKWARD_SCRATCH = os.environ.get("GOF_FULL_BACKWARD_SCRATCH", "0") == "1"
+FULL_MASK_POOL = os.environ.get("GOF_FULL_MASK_POOL", "0") == "1"
 _capacity = {}          # (device, P, W, H) -> instance capacity learnt from earlier frames
-_stats = {"fused_redone_frames": 0, "last_num_rendered": 0}      # bench.py's `views` leg reads these (no effect on the path)
+_mask_need = {}         # (device, P, W, H) -> most contributor-mask sub-chunks a forward of this shape has asked for (learnt at its backward)
+_stats = {"fused_redone_frames": 0, "last_num_rendered": 0, "mask_pool_redone_frames": 0}      # bench.py reads these (no effect on the path)
+
+
+class MaskPoolTooSmall(RuntimeError):
+    """Raised by rasterize_gaussians_backward BEFORE anything is launched: the forward of this frame asked for more contributor-mask
+    sub-chunks than its binning workspace held (include/gof_hip.h: gof_binning_bytes_for), so masks are missing.  The autograd
+    functions repeat the frame's forward with a full pool and call the backward again; the learnt need has been raised."""
+
+    def __init__(self, requested, capacity):
+        super().__init__("contributor-mask pool too small: %d sub-chunks requested, %d held" % (requested, capacity))
+        self.requested, self.capacity = requested, capacity
+
+
+def _mask_pool_subchunks(shape_key):
+    """sub-chunks to size the fused forward's mask pool for: 1.25 x the largest request seen for this shape (None: not learnt yet,
+    or switched off -> the worst case)"""
+    need = None if FULL_MASK_POOL else _mask_need.get(shape_key)
+    return None if need is None else int(need * 1.25) + 256
 _pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
 
 
@@ -253,7 +272,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         if cap is not None:
             geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
             img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
-            binning = v.bytes_tensor(lib.gof_binning_bytes(cap, v.W, v.H))
+            sub = _mask_pool_subchunks(shape_key)
+            binning = v.bytes_tensor(lib.gof_binning_bytes(cap, v.W, v.H) if sub is None else lib.gof_binning_bytes_for(cap, v.W, v.H, sub))
             radii = torch.empty(v.P, dtype=torch.int32, device=v.device)
             pin = _pinned.get(str(v.device))
             if pin is None:
@@ -326,12 +346,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             # the record pool of the scratch: as many records as the forward staged entries (~30 % of R at S1M), asked of the image
             # workspace -- one 4-byte read-back that waits for the forward, which a training step's backward follows anyway
             # (GOF_FULL_BACKWARD_SCRATCH=1: the worst case, a record per instance, without the read-back)
-            if FULL_BACKWARD_SCRATCH:
+            full_pool = binningBuffer.numel() >= lib.gof_binning_bytes(int(R), W, H)
+            if FULL_BACKWARD_SCRATCH and full_pool:
                 nscratch = lib.gof_backward_scratch_bytes(P, int(R))
             else:
-                staged = C.c_uint32(0)
-                _check(lib.gof_backward_query(v.ref(), int(R), _ptr(imageBuffer), imageBuffer.numel(), C.byref(staged), _stream()))
-                nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), int(staged.value))
+                q = (C.c_uint32 * 3)()
+                _check(lib.gof_backward_query(v.ref(), int(R), binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), q, _stream()))
+                staged, requested, held = int(q[0]), int(q[1]), int(q[2])
+                shape_key = (str(dev), P, W, H)
+                _mask_need[shape_key] = max(_mask_need.get(shape_key, 0), requested)
+                if requested > held:
+                    raise MaskPoolTooSmall(requested, held)
+                nscratch = lib.gof_backward_scratch_bytes(P, int(R)) if FULL_BACKWARD_SCRATCH else lib.gof_backward_scratch_bytes_for(P, int(R), staged)
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),

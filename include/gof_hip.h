@@ -109,6 +109,17 @@ size_t gof_point_bytes(int32_t PN);
 /* replaces required<BinningState>(num_integrated) for the query points (rasterizer_impl.cu:706): the sort state only,
  * without the contributor masks of gof_binning_bytes (a gof_binning_bytes-sized buffer is accepted too) */
 size_t gof_point_binning_bytes(uint32_t num_integrated, int32_t W, int32_t H);
+/* A SMALLER binning workspace for the forward / backward pair (round 4).  The contributor masks the forward blend leaves for the
+ * backward -- one bit per (pixel of the tile, list entry) -- are stored in a pool of 2 KB sub-chunks (one wave's 64 pixels x one staged
+ * batch of 256 entries), taken as the blend reaches them; the forward only reaches ~40 % of the lists.  gof_binning_bytes(R, W, H)
+ * sizes the pool for the worst case, 4 (R / 256 + tiles + 2) sub-chunks = 32 B per instance (and is also what the opacity-field query
+ * needs); gof_binning_bytes_for(R, W, H, n) sizes it for n sub-chunks (never below the sort state).  gof_forward_render /
+ * gof_forward_fused / gof_backward derive the pool's capacity from the binning_bytes they are given.  A forward that needs more
+ * sub-chunks than the pool holds still renders its image exactly, counts its requests and stores no masks beyond the capacity:
+ * BEFORE that frame's backward, gof_backward_query reports requested vs. capacity, and the caller repeats the forward with
+ * gof_binning_bytes_for(R, W, H, requested) bytes (the shipped binding sizes the pool 1.25 x the largest request seen so far, starting
+ * from the worst case). */
+size_t gof_binning_bytes_for(uint32_t num_rendered, int32_t W, int32_t H, uint32_t mask_subchunks);
 
 /* ---- forward (replaces _C.rasterize_gaussians, rasterize_points.cu:36-122) ------------- */
 /* Stage 1: preprocess (forward.cu:283-404) + inclusive scan of tiles_touched
@@ -151,16 +162,18 @@ int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
  * 68-byte partial gradient records -- one per (tile, Gaussian) instance the per-pixel backward actually stages -- which the
  * per-Gaussian gather adds up (no atomics).  num_rendered = the value the backward is called with.
  *   gof_backward_scratch_bytes(P, R):                a pool of R records: always enough (every instance staged).
- *   gof_backward_query(...):                         the number of entries the forward of this frame staged (~30 % of R at 1M
- *                                                    Gaussians @ 1600x1063), read from the image workspace.  SYNCHRONISES `stream`.
+ *   gof_backward_query(...):                         [0] the number of entries the forward of this frame staged (~30 % of R at 1M
+ *                                                    Gaussians @ 1600x1063), read from the image workspace; [1], [2]: the forward's
+ *                                                    contributor-mask pool, see gof_binning_bytes_for.  SYNCHRONISES `stream`.
  *   gof_backward_scratch_bytes_for(P, R, staged):    the size for a pool of exactly that many records (4 + 68 x staged / R bytes per
  *                                                    instance instead of 72).
  * The backward derives the pool's capacity from the scratch_bytes it is given.  A pool smaller than what the frame stages (impossible
  * with either size above) loses records and raises the late status word: the next library call returns GOF_E_DEVICE. */
 size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered);
 size_t gof_backward_scratch_bytes_for(int32_t P, uint32_t num_rendered, uint32_t staged_entries);
-int gof_backward_query(const GofRasterArgs* args, uint32_t num_rendered, const void* image_ws, size_t image_bytes,
-                       uint32_t* staged_entries_host, void* stream);
+int gof_backward_query(const GofRasterArgs* args, uint32_t num_rendered, size_t binning_bytes, const void* image_ws, size_t image_bytes,
+                       uint32_t* out3_host /* [0] staged entries, [1] mask sub-chunks requested, [2] mask sub-chunks binning_bytes holds */,
+                       void* stream);
 /* dL_dout is [9,H,W].  All gradient outputs are fully written by the call (the library
  * zero-fills them itself; the reference binding allocates them with torch::zeros,
  * rasterize_points.cu:161-170).  dL_dcov3D [P,6] is all zero in the reference (its producer

@@ -108,7 +108,9 @@ class EmuScene:
         return dict(color=self.color, radii=self.radii, final_T=self.fetch("final_T"), n_contrib=self.fetch("n_contrib"),
                     contrib_hash=self.fetch("contrib_hash"), tile_cost=self.fetch("tile_cost"))
 
-    def forward(self):
+    def forward(self, mask_subchunks=None):
+        """mask_subchunks: size the binning workspace's contributor-mask pool for that many sub-chunks (gof_binning_bytes_for)
+        instead of the worst case -- allocated at exactly that size, guard bytes behind it"""
         lib = self.lib
         lib.gof_set_forward_exact(1 if self.exact else 0)
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
@@ -118,7 +120,8 @@ class EmuScene:
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
-        self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
+        nb = lib.gof_binning_bytes(self.R, self.W, self.H) if mask_subchunks is None else lib.gof_binning_bytes_for(self.R, self.W, self.H, int(mask_subchunks))
+        self.binning = _aligned(nb, what="binning")
         self.color = np.zeros((9, self.H, self.W), np.float32)
         self._check(lib.gof_forward_render(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,
                                            _p(self.img), self.img.size, _p(self.color), None))
@@ -138,9 +141,11 @@ class EmuScene:
         if full_scratch:
             nscratch = lib.gof_backward_scratch_bytes(P, self.R)
         else:
-            staged = C.c_uint32(0)
-            self._check(lib.gof_backward_query(C.byref(self.args), self.R, _p(self.img), self.img.size, C.byref(staged), None))
-            self.staged = int(staged.value)
+            q = (C.c_uint32 * 3)()
+            self._check(lib.gof_backward_query(C.byref(self.args), self.R, self.binning.size, _p(self.img), self.img.size, q, None))
+            self.staged, self.masks_requested, self.masks_held = int(q[0]), int(q[1]), int(q[2])
+            if self.masks_requested > self.masks_held:
+                raise RuntimeError("mask pool too small: %d sub-chunks requested, %d held" % (self.masks_requested, self.masks_held))
             nscratch = lib.gof_backward_scratch_bytes_for(P, self.R, self.staged)
         scratch = _aligned(nscratch, what="backward scratch")
         self._check(lib.gof_backward(C.byref(self.args), self.R, _p(self.radii), _p(self.geom), self.geom.size, _p(self.binning), self.binning.size,

@@ -198,6 +198,51 @@ def test_emulated_sync_free_forward_respects_its_capacity():
         assert rc == -5 and count == R and intact, (cap, rc, count, intact)          # GOF_E_CAPACITY, the true count reported
 
 
+def test_emulated_compact_workspaces_the_mask_pool_and_the_record_pool():
+    """Round 4: the contributor masks live in a POOL of sub-chunks whose size the caller chooses (gof_binning_bytes_for) and the
+    backward's partial gradient records in a pool sized from what the forward staged (gof_backward_query +
+    gof_backward_scratch_bytes_for).  With both pools at EXACTLY the reported need (guard bytes behind every workspace) the gradients
+    are bit-identical to the worst-case workspaces'; a mask pool one sub-chunk short is reported by the query (requested > held)
+    before any backward runs, and the image of that forward is still exact."""
+    exercised = 0
+    for name in ("posed_ragged", "posed_long_lists", "lego10k"):
+        sc = TP.SCENES[name]()
+        full = E.EmuScene(sc)
+        img, _ = full.forward()
+        dL = np.random.default_rng(11).normal(size=img.shape).astype(np.float32)
+        want = full.backward(dL, full_scratch=True)
+        again = full.backward(dL)                                   # record pool at exactly the staged count
+        need, staged = full.masks_requested, full.staged
+        assert 0 < staged <= full.R and 0 < need <= full.masks_held
+        T = ((sc["W"] + 15) // 16) * ((sc["H"] + 15) // 16)
+        assert full.masks_held == 4 * (full.R // 256 + T + 2)        # the worst case
+        for k in want:
+            assert np.array_equal(bits(want[k]), bits(again[k])), (name, k)
+        tight = E.EmuScene(sc)
+        img2, _ = tight.forward(mask_subchunks=need)                # mask pool at exactly the need
+        assert np.array_equal(bits(img2), bits(img))
+        got = tight.backward(dL)
+        # (the pool lies on top of the tile sort's two ping-pong buffers, dead by then: a workspace never holds fewer sub-chunks than those 8 B per instance make)
+        floor = E.EmuScene(sc); floor.forward(mask_subchunks=0)
+        try:
+            floor.backward(dL)
+        except RuntimeError:
+            pass
+        assert tight.masks_held == max(need, floor.masks_held) and tight.masks_requested == need
+        for k in want:
+            assert np.array_equal(bits(want[k]), bits(got[k])), (name, k)
+        assert tight.binning.size < full.binning.size
+        if need > floor.masks_held:
+            exercised += 1
+            short = E.EmuScene(sc)
+            img3, _ = short.forward(mask_subchunks=need - 1)
+            assert np.array_equal(bits(img3), bits(img))            # the image does not depend on the pool
+            with pytest.raises(RuntimeError, match="mask pool too small"):
+                short.backward(dL)
+            assert short.masks_requested == need and short.masks_held == need - 1
+    assert exercised >= 2
+
+
 def test_emulated_cull_audit_counts_no_dropped_pair():
     """the instrumented build (-DGOF_STATS -DGOF_CULL_AUDIT: the consumption walks EVERY list entry and counts the pairs the exact
     path accepts that the footprint-conic scan had not marked) run from source on the host: 0 dropped on the stress scenes, the

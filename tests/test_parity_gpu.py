@@ -528,6 +528,51 @@ def test_fused_forward_matches_the_two_stage_forward_and_recovers_from_a_small_c
     assert torch.equal(product_forward_raw(sd, fused=True)["color"], exact["color"])
 
 
+def test_learnt_mask_pool_its_redo_and_the_record_pool_through_autograd():
+    """Round 4, compact workspaces behind the unchanged operator API: the forward's contributor masks live in a pool the binding
+    sizes 1.25 x the largest request seen for the shape (learnt at the first backward; the worst case until then), the backward's
+    partial records in a pool sized from what the forward staged.  Same gradients bit for bit whatever the pools' sizes; a pool that
+    turns out too small (here: the learnt need sabotaged) is noticed at the backward's entry, the frame's forward is repeated with a
+    full pool and the step's gradients are still exact."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    sc = SCENES["posed_mid100k"]()
+    sd = to_dev(sc)
+    key = (str(sd["means3D"].device), sd["means3D"].shape[0], sd["W"], sd["H"])
+    B._capacity.pop(key, None); B._mask_need.pop(key, None)
+    dL = torch.randn((9, sd["H"], sd["W"]), generator=torch.Generator().manual_seed(4)).cuda()
+
+    def step():
+        leaf = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros_like(leaf["means3D"], requires_grad=True)
+        color, _ = GaussianRasterizer(settings_from(sd))(means3D=leaf["means3D"], means2D=m2, shs=leaf["shs"], opacities=leaf["opacities"],
+                                                       scales=leaf["scales"], rotations=leaf["rotations"])
+        color.backward(dL)
+        torch.cuda.synchronize()
+        return color.detach(), {k: v.grad.clone() for k, v in leaf.items()} | {"means2D": m2.grad.clone()}
+    c0, g0 = step()                         # two-stage forward, worst-case pools; the backward learns the mask need
+    need = B._mask_need[key]
+    T = ((sd["W"] + 15) // 16) * ((sd["H"] + 15) // 16)
+    assert 0 < need < 4 * (B._stats["last_num_rendered"] // 256 + T + 2)
+    redone = B._stats["mask_pool_redone_frames"]
+    c1, g1 = step()                         # fused forward, mask pool at 1.25 x the need
+    assert B._stats["mask_pool_redone_frames"] == redone
+    B._mask_need[key] = 16                  # sabotage: the next forward gets a pool far too small
+    c2, g2 = step()
+    assert B._stats["mask_pool_redone_frames"] == redone + 1 and B._mask_need[key] == need      # noticed, repeated, learnt again
+    for c in (c1, c2):
+        assert torch.equal(c, c0)
+    for g in (g1, g2):
+        for k in g0:
+            assert torch.equal(g[k], g0[k]), k
+    # the workspaces did shrink: binning (sort state + mask pool) and the backward scratch (slot words + record pool)
+    R = B._stats["last_num_rendered"]
+    P = sd["means3D"].shape[0]
+    q_full = B.lib.gof_binning_bytes(R, sd["W"], sd["H"]) + B.lib.gof_backward_scratch_bytes(P, R)
+    sub = B._mask_pool_subchunks(key)
+    q_now = B.lib.gof_binning_bytes_for(R, sd["W"], sd["H"], sub) + B.lib.gof_backward_scratch_bytes_for(P, R, R // 2)
+    assert q_now < 0.75 * q_full
+
+
 def test_parameter_gradients_share_one_allocation_for_the_dp_reducer():
     """The backward carves the gradients of (means3D, opacity, scales, rotations, sh) from ONE buffer in that order; after
     autograd they are still views of it, so dp.GradientAllReducer all-reduces the bucket in place (no pack / unpack)."""
