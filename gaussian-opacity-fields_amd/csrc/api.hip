@@ -58,17 +58,18 @@ __global__ void rebuild_keys(uint32_t R, const uint32_t* tiles, const uint32_t* 
 
 __global__ void blend_forward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                               float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
-                              float* out_color, MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
+                              float* out_color, MaskPool masks, uint32_t* mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                               uint32_t* tile_cost);
 __global__ void blend_forward_exact(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* fconic, int W, int H,
                                     float focal_x, float focal_y, const float* bg_color, float* final_T, uint32_t* n_contrib,
-                                    float* out_color, MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
+                                    float* out_color, MaskPool masks, uint32_t* mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                                     uint32_t* tile_cost);
-__global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges);
+__global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges,
+                            uint32_t* clear_cursors);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
-                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_next, uint32_t rec_cap, uint32_t* async_status,
+                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_cursors, uint32_t rec_cap, uint32_t* async_status,
                                uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                uint32_t* tile_queue, const uint32_t* tile_lens);
 __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
@@ -207,6 +208,7 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
     carve(p, im.tile_queue, (size_t)TILE_QUEUE_WORDS);
     carve(p, im.tile_cost, T);
     carve(p, im.tile_order_bw, (size_t)NXCD * tile_queue_stride((uint32_t)T));
+    carve(p, im.mask_cursors, (size_t)POOL_SHARDS + 1);
     if (out) *out = im;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -223,14 +225,14 @@ size_t bin_layout(uint32_t R, int32_t W, int32_t H, void* base, BinWs* out, BinM
     if (mode == BIN_MASK_POOL) {
         // [table][sort scratch][vals_alt][tiles_alt] and the pool ON TOP of the two ping-pong buffers: they are dead once the tile
         // sort has left its result in vals / tiles, i.e. before blend_forward writes the first mask word
-        carve(p, b.mp.table, 4 * mask_slots(n, T));
+        carve(p, b.mp.table, mask_slots(n, T));
         carve(p, b.sort_tmp, rs_tmp_words(n));
         char* const pool0 = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(p)));
         carve(p, b.vals_alt, n);
         carve(p, b.tiles_alt, n);
         b.mp.pool = reinterpret_cast<uint32_t*>(pool0);
         const size_t sub = (size_t)MASK_SUBCHUNK_WORDS * sizeof(uint32_t);
-        const size_t full = 4 * mask_slots(n, T);
+        const size_t full = 4 * (mask_slots(n, T) + POOL_SHARDS);          // every (tile, batch) a chunk + what the shards' rounding leaves unused
         const size_t head = (size_t)(pool0 - static_cast<char*>(base)) + ALIGN;      // bytes in front of the pool (incl. the caller's alignment slack)
         size_t cap = full;
         if (bytes) cap = bytes > head ? (bytes - head) / sub : 0;
@@ -257,7 +259,7 @@ static size_t bin_pool_bytes(uint32_t R, int32_t W, int32_t H, size_t subchunks)
     BinWs b;
     const size_t full_bytes = bin_layout(R, W, H, nullptr, &b, BIN_MASK_POOL, 0);
     const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
-    const size_t full = 4 * mask_slots((size_t)R, T);
+    const size_t full = 4 * (mask_slots((size_t)R, T) + POOL_SHARDS);
     if (subchunks >= full) return full_bytes;
     const size_t head = reinterpret_cast<size_t>(b.mp.pool) + ALIGN;                                   // (base is null: the pointer IS the offset)
     const size_t alt_end = reinterpret_cast<size_t>(b.tiles_alt) + align_up((size_t)R * sizeof(uint32_t)) + ALIGN;
@@ -352,7 +354,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     }
     // dispatch order of the tile kernels: every XCD an equal share of every cost class, heaviest first (gof_common.h: pop_tile)
     { GOF_PROFILE("order_tiles", stream);
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr); }
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors); }
     GOF_LAUNCH_CHECK(stream, dbg);
     return GOF_OK;
 }
@@ -370,7 +372,7 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
     if (bw_order_by_length()) return;
     GOF_PROFILE("order_tiles_bw", stream);
     // (queue lengths at tile_queue[40..47]; the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr, nullptr);
 }
 
 // The forward blend.  Default: the reference's arithmetic without its two fp64 divisions per pair (blend_forward.hip: pair_nodiv_cc).
@@ -386,7 +388,7 @@ static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const Ge
     auto* kernel = g_forward_exact.load(std::memory_order_relaxed) ? blend_forward_exact : blend_forward;
     hipLaunchKernelGGL(kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
-                       im.final_T, im.n_contrib, out_color, b.mp, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
+                       im.final_T, im.n_contrib, out_color, b.mp, im.mask_cursors, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
 }
 
 } // namespace gof
@@ -517,7 +519,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
         rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr);
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors);
     }
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
@@ -569,8 +571,9 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 // 16.  The pool holds `records` records: R for the worst case (every instance staged), or the number the forward actually staged
 // (gof_backward_query: ~30 % of R at S1M) -- 4 + 68 x 0.3 B per instance instead of 69.
 struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint32_t* queue; uint32_t* slot_of; float* part17; float4* part16; };
-constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads ([0..7]) and the record cursor ([BWD_REC_NEXT]) sit right in front of the slot words: one memset clears both
-constexpr int BWD_REC_NEXT = 16;
+constexpr size_t BWD_QUEUE_BYTES = 512;      // the backward's tile-queue heads ([0..7]) and the record pool's cursors ([BWD_REC_CURSORS .. + POOL_SHARDS]) sit right in front of the slot words: one memset clears both
+constexpr int BWD_REC_CURSORS = 16;
+constexpr uint32_t BWD_REC_SLACK = 64 * POOL_SHARDS;      // a shard cannot serve a wave's request from its last < 64 slots: room for one such tail per shard
 static size_t bwd_scratch_layout(int32_t P, uint32_t R, uint32_t records, void* base, BwdScratch* o)
 {
     char* p = static_cast<char*>(base);
@@ -585,10 +588,10 @@ static size_t bwd_scratch_layout(int32_t P, uint32_t R, uint32_t records, void* 
     if (o) *o = t;
     return reinterpret_cast<size_t>(p) - p0;
 }
-size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered) { return bwd_scratch_layout(P, num_rendered, num_rendered, nullptr, nullptr) + ALIGN; }
+size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered) { return bwd_scratch_layout(P, num_rendered, num_rendered + BWD_REC_SLACK, nullptr, nullptr) + ALIGN; }
 size_t gof_backward_scratch_bytes_for(int32_t P, uint32_t num_rendered, uint32_t staged_entries)
 {
-    return bwd_scratch_layout(P, num_rendered, staged_entries < num_rendered ? staged_entries : num_rendered, nullptr, nullptr) + ALIGN;
+    return bwd_scratch_layout(P, num_rendered, (staged_entries < num_rendered ? staged_entries : num_rendered) + BWD_REC_SLACK, nullptr, nullptr) + ALIGN;
 }
 // records a scratch of `bytes` bytes can hold (the inverse of gof_backward_scratch_bytes_for)
 static uint32_t bwd_scratch_records(int32_t P, uint32_t R, size_t bytes)
@@ -596,7 +599,7 @@ static uint32_t bwd_scratch_records(int32_t P, uint32_t R, size_t bytes)
     const size_t fixed = bwd_scratch_layout(P, R, 0, nullptr, nullptr) + ALIGN;
     if (bytes < fixed) return 0;
     size_t n = (bytes - fixed) / 68 + 16;                   // (the pool arrays of the zero-record layout already hold one record and their alignment padding)
-    if (n > R) n = R;
+    if (n > (size_t)R + BWD_REC_SLACK) n = (size_t)R + BWD_REC_SLACK;
     while (n > 0 && bwd_scratch_layout(P, R, (uint32_t)n, nullptr, nullptr) + ALIGN > bytes) n--;      // (the two pool arrays are 256-byte aligned each)
     return (uint32_t)n;
 }
@@ -613,7 +616,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
     if (!rc && (stages & 1)) rc = take_async_status();
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
-    if (!scratch || scratch_bytes < gof_backward_scratch_bytes_for(a->P, R, 0)) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
+    if (!scratch || scratch_bytes < bwd_scratch_layout(a->P, R, 0, nullptr, nullptr) + ALIGN) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
     // the record pool is as large as the caller's buffer allows: R records (gof_backward_scratch_bytes: always enough) or the
     // forward's staged count (gof_backward_query + gof_backward_scratch_bytes_for).  A pool that turns out too small raises the late
     // status word (the next library call returns GOF_E_DEVICE) -- it cannot happen with either of the two sizes.
@@ -660,7 +663,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_NEXT, rec_cap, async_status_word(), d.gx, d.ntiles,
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSORS, rec_cap, async_status_word(), d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
@@ -719,12 +722,18 @@ int gof_backward_query(const GofRasterArgs* a, uint32_t R, size_t binning_bytes,
     image_layout(a->W, a->H, aligned_base(const_cast<void*>(image_ws)), &im);
     bin_layout(R, a->W, a->H, nullptr, &b, BIN_MASK_POOL, binning_bytes);
     out3_host[2] = b.mp.cap;
-    uint32_t words[2] = { 0, 0 };
-    GOF_HIP_CHECK(hipMemcpyAsync(&words[0], im.tile_queue + MASK_NEXT_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GOF_HIP_CHECK(hipMemcpyAsync(&words[1], im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    uint32_t cur[POOL_SHARDS + 1], staged = 0;
+    GOF_HIP_CHECK(hipMemcpyAsync(cur, im.mask_cursors, sizeof(cur), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipMemcpyAsync(&staged, im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
-    out3_host[1] = words[0];
-    if (!bw_order_by_length()) out3_host[0] = words[1] < R ? words[1] : R;      // (developer toggle: the forward left no backward order, hence no sum: worst case)
+    {   // chunks (of 4 sub-chunks) taken from the shards + chunks no shard had room for
+        const uint32_t chunks = b.mp.cap / 4u, shards = pool_shards(chunks), per = chunks / shards;
+        uint64_t asked = cur[POOL_SHARDS];
+        for (uint32_t k = 0; k < shards; k++) asked += cur[k] < per ? cur[k] : per;
+        out3_host[1] = (uint32_t)(4u * asked > 0xFFFFFFFFull ? 0xFFFFFFFFull : 4u * asked);
+        if (cur[POOL_SHARDS]) out3_host[1] = out3_host[1] > b.mp.cap ? out3_host[1] : b.mp.cap + 4u;      // (unserved requests: certainly more than held)
+    }
+    if (!bw_order_by_length()) out3_host[0] = staged < R ? staged : R;          // (developer toggle: the forward left no backward order, hence no sum: worst case)
     return GOF_OK;
 }
 
@@ -862,7 +871,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         GOF_LAUNCH_CHECK(stream, a->debug);
     } }
     // dispatch order of the point pass: #points of the tile x what its pixels walked (tile_cost, left by integrate_pixels), heaviest first
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges, nullptr);
     GOF_LAUNCH_CHECK(stream, a->debug);
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
@@ -1037,11 +1046,11 @@ count_contributing_pairs(const uint2* __restrict__ ranges, const uint32_t* __res
     __syncthreads();
     const uint2 range = ranges[tile];
     const uint32_t max_last = min(s_max, range.y - range.x);
-    const uint32_t* entry = masks.table + (mask_slot0(range.x, tile) * 4 + (tid >> 6));
+    const uint32_t* entry = masks.table + mask_slot0(range.x, tile);
     uint32_t c = 0;
     for (uint32_t w = 0; w < (max_last + 31) / 32; w++) {
-        const uint32_t sub = entry[(size_t)(w >> 3) * 4];
-        uint32_t word = (sub == MASK_ZERO || sub >= masks.cap) ? 0u : masks.pool[(size_t)sub * MASK_SUBCHUNK_WORDS + (w & 7u) * 64u + (tid & 63u)];
+        const uint32_t chunk = entry[w >> 3];
+        uint32_t word = (chunk == POOL_NONE) ? 0u : masks.pool[((size_t)chunk * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + (w & 7u) * 64u + (tid & 63u)];
         if (w == max_last / 32 && (max_last & 31u)) word &= (1u << (max_last & 31u)) - 1u;      // (positions the backward never stages)
         c += hash ? word * (2u * (w * TILE_PIX + tid) + 1u) + (word >> 7) : (uint32_t)__popc(word);
     }

@@ -185,8 +185,9 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
 // the tile's query points (point pass).  What it buys is measured in bench.py's "clustered" leg (profiles/r03_tile_schedule.md).
 __global__ void __launch_bounds__(1024)
 order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cost_in, uint32_t* __restrict__ order,
-            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges)
+            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges, uint32_t* __restrict__ clear_cursors)
 {
+    if (clear_cursors && threadIdx.x <= POOL_SHARDS) clear_cursors[threadIdx.x] = 0u;      // the mask pool of the frame's forward blend starts empty
     constexpr int NB = 128;                       // bucket = 2 * floor(log2(c)) + next bit, descending (64 used; quarter-octave classes ordered
                                                   // more finely but cut an XCD's share into more, shorter runs: +30 % L2 -> fabric reads in the backward)
     constexpr int NW = 16;                        // waves of the workgroup
@@ -265,7 +266,7 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
         if (lane == 0 && staged_sum) atomicAdd(&s_staged, staged_sum);
     }
     __syncthreads();
-    if (tid == 0 && queue) { queue[BW_STAGED_WORD] = s_staged; queue[MASK_NEXT_WORD] = 0u; }      // (+ the mask pool's cursor: the forward blend of this frame starts at sub-chunk 0)
+    if (tid == 0 && queue) queue[BW_STAGED_WORD] = s_staged;
     {   // per bucket: exclusive prefix over the waves (ascending tile id), total n_b; then G_b = tiles in heavier buckets
         uint32_t run = 0, inc = 0;
         if (tid < NB) {

@@ -145,7 +145,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                     const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-                    float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_next,
+                    float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursors,
                     uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx)
 {
     TILE_CLOCK_START();
@@ -165,7 +165,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     const f2 PXM = { (float)px, (float)py };       // pixf - 0.5 (backward.cu:770), exact
 
     const uint2 range = ranges[tile];
-    const uint32_t* const mask_entry = masks.table + (mask_slot0(range.x, tile) * 4 + (tid >> 6));      // this wave's sub-chunks, one per forward batch of 256 entries
+    const uint32_t* const mask_entry = masks.table + mask_slot0(range.x, tile);      // this tile's chunks of the mask pool, one per forward batch of 256 entries
 
     // LDS record of a staged entry, arranged as the operand pairs of the packed arithmetic (v = view2gaussian):
     //   q0 = {v0, v1 | v1, v3}, q1 = {v2, v4 | v2, v6}, q2 = {v4, v7 | v5, v8}   (prelude, as in blend_forward)
@@ -252,11 +252,11 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         uint32_t cmw[BATCH / 32];
         {
             const int nw = (n + 31) >> 5;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_entry[(size_t)(p0 >> 8) * 4]);      // MASK_ZERO: the wave was saturated in that batch
-            const uint32_t* const src = masks.pool + (size_t)c * MASK_SUBCHUNK_WORDS + ((p0 & 255u) >> 5) * 64u + lane;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_entry[p0 >> 8]);
+            const uint32_t* const src = masks.pool + ((size_t)c * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + ((p0 & 255u) >> 5) * 64u + lane;
 #pragma unroll
             for (int q = 0; q < BATCH / 32; q++)
-                cmw[q] = (q < nw && c != MASK_ZERO) ? src[q * 64] : 0u;
+                cmw[q] = (q < nw) ? src[q * 64] : 0u;
         }
         __syncthreads();
         if (tid == 0) BSTAT_ADD(4, n);
@@ -471,7 +471,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, stored as the partial
         // gradient record of this (tile, Gaussian) instance.  Records live in a POOL (round 4: the scratch holds a record per STAGED
         // instance -- ~30 % of R at S1M -- not per instance): a wave takes as many consecutive slots as it has visited entries with
-        // one atomic on the pool's cursor, and leaves slot + 1 in slot_of[instance] (0 = no record), which gather_tile_partials reads
+        // one atomic on a cursor of the pool (pool_take: sharded cursors), and leaves slot + 1 in slot_of[instance] (0 = no record), which gather_tile_partials reads
         // where it read a validity byte before.  The values a Gaussian receives do not depend on WHICH slot held them: bit-reproducible.
         if (tid < (uint32_t)BATCH) {                                   // (whole waves: BATCH is a multiple of 64)
             const uint32_t qw = tid >> 5, qb = 1u << (tid & 31u);
@@ -481,11 +481,11 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
             const unsigned long long m = __ballot(live);
             if (m) {
                 uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(rec_next, (uint32_t)__popcll(m));
+                if (lane == (uint32_t)__builtin_ctzll(m)) base = pool_take(rec_cursors, rec_cap, (uint32_t)__popcll(m), tile);
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
                 if (live) {
                     const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (slot < rec_cap) {
+                    if (base != POOL_NONE) {
                         auto total = [&](int k) {
                             float x = v0 ? s_slab[0][k][tid] : 0.f;
                             x += v1 ? s_slab[1][k][tid] : 0.f;
@@ -519,7 +519,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-               float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_next,
+               float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursors,
                uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx, uint32_t ntiles,
                const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, const uint32_t* __restrict__ tile_lens)
 {
@@ -527,7 +527,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_backward_tile(tile, ranges, point_list, rec, conic, masks, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
-                        inst_off, part16, part17, slot_of, rec_next, rec_cap, async_status, gx);
+                        inst_off, part16, part17, slot_of, rec_cursors, rec_cap, async_status, gx);
 }
 
 // Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):

@@ -89,7 +89,7 @@ __device__ __forceinline__ void
 blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                    const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                   const MaskPool masks, uint32_t* __restrict__ mask_next, uint32_t gx, uint32_t* __restrict__ tile_cost)
+                   const MaskPool masks, uint32_t* __restrict__ mask_cursors, uint32_t gx, uint32_t* __restrict__ tile_cost)
 {
     TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -118,8 +118,8 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
     uint32_t* const s_tile = &s_mask[0][0];      // (the epilogue's scratch word: the masks are dead by then)
     // footprint conic, SoA: s_cf[c][entry], c = {m00, 2 m01, m11, 2 m02, 2 m12, m22}; read as float4 = one coefficient of 4 entries
     __shared__ f4 s_cf[6][TILE_PIX / 4];
-    // this wave's entries of the contributor-mask table (gof_common.h: MaskPool), one per staged batch
-    uint32_t* const mask_entry = masks.table + (mask_slot0(range.x, tile) * 4 + (tid >> 6));
+    // this tile's entries of the contributor-mask table (gof_common.h: MaskPool), one per staged batch
+    uint32_t* const mask_entry = masks.table + mask_slot0(range.x, tile);
     // evaluation-error margin of the unit-normalised conic (sum |M_ij| = 1, the doubled off-diagonal coefficients counted doubled):
     // the Horner form below is five FMAs and one add, each rounding a partial sum bounded by B = max(1, rx^2, ry^2) -- 6 eps B,
     // eps = 2^-24 -- plus the fp32 rounding of the six coefficients, <= eps B together: 7 eps B = 4.2e-7 B (the ray is the fp32 ray
@@ -143,6 +143,8 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
 
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_and(done)) break;
+        // the batch's chunk of the mask pool (4 sub-chunks, one per wave): taken by one thread, known to all behind the staging barrier
+        if (tid == 0) mask_entry[i] = pool_take(mask_cursors, masks.cap / 4u, 1u, tile);
         const uint32_t k = range.x + (uint32_t)i * TILE_PIX + tid;
         if (k < range.y) {
             const uint32_t id = point_list[k];
@@ -160,8 +162,11 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
         }
         __syncthreads();
         const int nwords_batch = (min(TILE_PIX, toDo) + 31) >> 5;
-        if (__ballot(!done) == 0ull) {             // whole wave saturated: it only helps staging (and reports "no contributors": no sub-chunk)
-            if ((tid & 63u) == 0u) mask_entry[(size_t)i * 4] = MASK_ZERO;
+        const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_entry[i]);      // (written by thread 0 in front of the barrier)
+        uint32_t* const mask_dst = masks.pool + ((size_t)chunk * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + (tid & 63u);
+        if (__ballot(!done) == 0ull) {             // whole wave saturated: it only helps staging (and reports "no contributors")
+            if (chunk != POOL_NONE)
+                for (int q = 0; q < nwords_batch; q++) mask_dst[q * 64] = 0u;
             continue;
         }
 
@@ -293,16 +298,10 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
         for (int q = w + 1; q < nw; q++) s_mask[q][tid] = 0u;       // candidate words this pixel never reached (it saturated)
         words_valid = nw;
         }   // chunk
-        {   // the batch's contributor words -> a sub-chunk of the pool (one atomic per wave and batch; beyond the pool's capacity the
-            // request is counted -- the caller repeats the frame's forward with more room before its backward -- and nothing is stored)
-            uint32_t c = 0;
-            if ((tid & 63u) == 0u) { c = atomicAdd(mask_next, 1u); mask_entry[(size_t)i * 4] = c; }
-            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-            if (c < masks.cap) {
-                uint32_t* const dst = masks.pool + (size_t)c * MASK_SUBCHUNK_WORDS + (tid & 63u);
-                for (int q = 0; q < nwords_batch; q++) dst[q * 64] = (q < words_valid) ? s_mask[q][tid] : 0u;
-            }
-        }
+        // the batch's contributor words -> this wave's sub-chunk (a batch the pool had no room for is counted by pool_take -- the
+        // caller repeats the frame's forward with more room before its backward -- and not stored)
+        if (chunk != POOL_NONE)
+            for (int q = 0; q < nwords_batch; q++) mask_dst[q * 64] = (q < words_valid) ? s_mask[q][tid] : 0u;
     }
 
     if (inside) {
@@ -350,7 +349,7 @@ __device__ __forceinline__ void
 blend_forward_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                    const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                   const MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+                   const MaskPool masks, uint32_t* __restrict__ mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
                    uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
     // The kernel's LDS must stay at 32 000 B: 25 allocation granules of 1280 B, five workgroups per CU.  One more word -- a
@@ -360,26 +359,26 @@ blend_forward_body(const uint2* __restrict__ ranges, const uint32_t* __restrict_
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_mask[0][0]);
     if (tile >= ntiles) return;
     blend_forward_tile<EXACT>(tile, s_mask, ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, masks,
-                              tile_queue + MASK_NEXT_WORD, gx, tile_cost);
+                              mask_cursors, gx, tile_cost);
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))     // 30 KB of LDS allow 5 workgroups per CU: keep the registers below 512 / 5
 blend_forward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
               const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-              const MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+              const MaskPool masks, uint32_t* __restrict__ mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
               uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
-    blend_forward_body<false>(ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, masks, gx, ntiles, tile_order, tile_queue, tile_cost);
+    blend_forward_body<false>(ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, masks, mask_cursors, gx, ntiles, tile_order, tile_queue, tile_cost);
 }
 // the verification mode (gof_set_forward_exact(1) / GOF_FW_EXACT=1): every pair in the reference's own arithmetic
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_FW_WAVES, 8)))
 blend_forward_exact(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                     const float4* __restrict__ fconic, int W, int H, float focal_x, float focal_y, const float* __restrict__ bg_color,
                     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                    const MaskPool masks, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
+                    const MaskPool masks, uint32_t* __restrict__ mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* __restrict__ tile_order,
                     uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
-    blend_forward_body<true>(ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, masks, gx, ntiles, tile_order, tile_queue, tile_cost);
+    blend_forward_body<true>(ranges, point_list, rec, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, masks, mask_cursors, gx, ntiles, tile_order, tile_queue, tile_cost);
 }
 
 #ifdef GOF_TILE_CLOCK

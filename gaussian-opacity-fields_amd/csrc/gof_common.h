@@ -68,27 +68,47 @@ struct ImageWs {
     uint32_t* tile_queue;   // [TILE_QUEUE_WORDS] [0..7] heads / [8..15] lengths of the forward-side queues, [32..47] the backward's lengths (its heads: scratch)
     uint32_t* tile_cost;    // [T] what blend_forward measured per tile (entries walked): the backward's cost
     uint32_t* tile_order_bw;// [8][tile_queue_stride(T)] dispatch order of blend_backward: by tile_cost (deepest walk first), written after the forward blend
+    uint32_t* mask_cursors; // [POOL_SHARDS + 1] cursors of the contributor-mask pool's shards + the requests no shard could serve (cleared by the forward-side order_tiles)
 };
 constexpr int NXCD = 8;
 constexpr int TILE_QUEUE_WORDS = 64;
-constexpr int MASK_NEXT_WORD = 17;      // tile_queue[17]: cursor of the contributor-mask pool (sub-chunks requested so far; cleared by order_tiles with the heads)
 constexpr int BW_STAGED_WORD = 16;      // queue[16] of an order_tiles call = sum over the tiles of min(cost, list length): for the backward's
                                         // order (tile_queue[32 + 16]) the entries the backward stages = partial records it writes (gof_backward_query)
+// A pool with SHARDED cursors.  One cursor for a whole pool is one address for every allocating wave of the GPU: 67 k same-address
+// atomics per frame cost blend_forward 0.46 ms at S1M (measured, round 4).  The pool is cut into POOL_SHARDS equal shards with a cursor
+// each; a taker starts at the shard its tile number names and moves on while a shard is full.  cursors[POOL_SHARDS] counts the slots
+// of requests that found no room anywhere.  (What the host learns: sum over the shards of min(cursor, shard size) + that word.)
+constexpr uint32_t POOL_SHARDS = 64;
+constexpr uint32_t POOL_NONE = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t pool_shards(uint32_t cap) { return cap >= 16u * POOL_SHARDS ? POOL_SHARDS : 1u; }      // (a small pool is one shard)
+__device__ __forceinline__ uint32_t pool_take(uint32_t* __restrict__ cursors, uint32_t cap, uint32_t n, uint32_t start)
+{
+    const uint32_t shards = pool_shards(cap);
+    const uint32_t per = cap / shards;
+    for (uint32_t k = 0; k < shards; k++) {
+        const uint32_t s = (start + k) & (shards - 1);
+        if (__hip_atomic_load(&cursors[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n > per) continue;      // (a full shard keeps its cursor: look first)
+        const uint32_t pos = atomicAdd(&cursors[s], n);
+        if (pos + n <= per) return s * per + pos;
+    }
+    atomicAdd(&cursors[POOL_SHARDS], n);
+    return POOL_NONE;
+}
+
 // Contributor masks of the forward / backward blend (round 4): one bit per (pixel of the tile, list position), set by blend_forward
 // when that entry contributed to the pixel -- exactly the pairs the backward has to visit (backward.cu:763-805).  Rounds 1-3 reserved
 // 32 B for EVERY instance (static layout, cmask_base below: still what the opacity-field query uses); the forward only visits ~40 % of
-// the lists, so the words now live in a POOL of 2 KB sub-chunks -- 8 words x 64 lanes = one wave's pixels x one staged batch of 256
-// entries -- which a wave takes from a cursor (one atomic) when it has something to write.  table[(slot0(tile) + batch) * 4 + wave]
-// names the sub-chunk (MASK_ZERO: the wave was saturated, all its words of that batch are 0); slot0 needs no scan:
-// sum_{t' < t} ceil(len_t' / 256) <= ranges[t].x / 256 + t.  The pool's capacity is whatever the caller's binning workspace leaves
-// behind the sort state (gof_binning_bytes_for); a request beyond it is counted but not stored, and the caller learns from
-// gof_backward_query (requested vs capacity) that this frame's forward has to be repeated with more room before its backward.
+// the lists, so the words now live in a POOL of 8 KB chunks -- [wave 4][word 8][lane 64] = the tile's pixels x one staged batch of 256
+// entries -- which a tile takes (pool_take, one atomic) as its blend reaches the batch.  table[slot0(tile) + batch] names the chunk;
+// slot0 needs no scan: sum_{t' < t} ceil(len_t' / 256) <= ranges[t].x / 256 + t.  The pool's capacity is whatever the caller's
+// binning workspace leaves behind the sort state (gof_binning_bytes_for; in sub-chunks of 2 KB = one wave's share of a chunk); a
+// request beyond it is counted but not stored, and the caller learns from gof_backward_query (requested vs held) that this frame's
+// forward has to be repeated with more room before its backward.
 struct MaskPool {
-    uint32_t* table;      // [4 * mask_slots(R, T)]
+    uint32_t* table;      // [mask_slots(R, T)]: first sub-chunk of (tile, batch), POOL_NONE if the pool was full
     uint32_t* pool;       // [cap][8][64]
     uint32_t cap;         // sub-chunks the pool holds
 };
-constexpr uint32_t MASK_ZERO = 0xFFFFFFFEu;
 constexpr uint32_t MASK_SUBCHUNK_WORDS = 8u * 64u;
 __host__ __device__ inline size_t mask_slots(size_t R, size_t ntiles) { return R / 256 + ntiles + 2; }
 __device__ __forceinline__ size_t mask_slot0(uint32_t range_start, uint32_t tile) { return (size_t)(range_start >> 8) + tile; }

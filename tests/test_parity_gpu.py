@@ -552,7 +552,7 @@ def test_learnt_mask_pool_its_redo_and_the_record_pool_through_autograd():
     c0, g0 = step()                         # two-stage forward, worst-case pools; the backward learns the mask need
     need = B._mask_need[key]
     T = ((sd["W"] + 15) // 16) * ((sd["H"] + 15) // 16)
-    assert 0 < need < 4 * (B._stats["last_num_rendered"] // 256 + T + 2)
+    assert 0 < need < 4 * (B._stats["last_num_rendered"] // 256 + T + 2 + 64)
     redone = B._stats["mask_pool_redone_frames"]
     c1, g1 = step()                         # fused forward, mask pool at 1.25 x the need
     assert B._stats["mask_pool_redone_frames"] == redone
