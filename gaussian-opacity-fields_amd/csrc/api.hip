@@ -69,7 +69,7 @@ __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
-                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_cursors, uint32_t rec_cap, uint32_t* async_status,
+                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_cursor, uint32_t rec_cap, uint32_t* async_status,
                                uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                uint32_t* tile_queue, const uint32_t* tile_lens);
 __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
@@ -571,9 +571,9 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 // 16.  The pool holds `records` records: R for the worst case (every instance staged), or the number the forward actually staged
 // (gof_backward_query: ~30 % of R at S1M) -- 4 + 68 x 0.3 B per instance instead of 69.
 struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint32_t* queue; uint32_t* slot_of; float* part17; float4* part16; };
-constexpr size_t BWD_QUEUE_BYTES = 512;      // the backward's tile-queue heads ([0..7]) and the record pool's cursors ([BWD_REC_CURSORS .. + POOL_SHARDS]) sit right in front of the slot words: one memset clears both
-constexpr int BWD_REC_CURSORS = 16;
-constexpr uint32_t BWD_REC_SLACK = 64 * POOL_SHARDS;      // a shard cannot serve a wave's request from its last < 64 slots: room for one such tail per shard
+constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads ([0..7]) and the record pool's cursor ([BWD_REC_CURSOR]) sit right in front of the slot words: one memset clears both
+constexpr int BWD_REC_CURSOR = 16;
+constexpr uint32_t BWD_REC_SLACK = 0;        // (a tile takes exactly its staged entries: the sum is what gof_backward_query reports)
 static size_t bwd_scratch_layout(int32_t P, uint32_t R, uint32_t records, void* base, BwdScratch* o)
 {
     char* p = static_cast<char*>(base);
@@ -663,7 +663,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSORS, rec_cap, async_status_word(), d.gx, d.ntiles,
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, async_status_word(), d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }

@@ -145,7 +145,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                     const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-                    float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursors,
+                    float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
                     uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx)
 {
     TILE_CLOCK_START();
@@ -211,6 +211,16 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     __syncthreads();
     const uint32_t max_last = min(s_max_last, range.y - range.x);
     if (max_last == 0) { TILE_CLOCK_END(g_bw_tile_clock); return; }
+    // this tile's block of the record pool: one record slot per staged list position (sum over the tiles = what gof_backward_query
+    // reports, so a scratch sized from it always has room; a smaller one loses the tile's records and raises the late status word)
+    __shared__ uint32_t s_rec_base;
+    if (tid == 0) {
+        const uint32_t b0 = atomicAdd(rec_cursor, max_last);
+        s_rec_base = (b0 + max_last <= rec_cap) ? b0 : POOL_NONE;
+        if (b0 + max_last > rec_cap) *async_status = 2u;
+    }
+    __syncthreads();
+    const uint32_t rec_base = s_rec_base;
 
     // accum_rec / accum_normal_rec of backward.cu:824-837, 862-867 for the channel pairs (colour 0, 1), (colour 2, normal 2),
     // (normal 0, 1).  The reference folds the PREVIOUS pair into them at the start of a pair (last_alpha, last_color); here the
@@ -470,38 +480,27 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         __syncthreads();
         // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, stored as the partial
         // gradient record of this (tile, Gaussian) instance.  Records live in a POOL (round 4: the scratch holds a record per STAGED
-        // instance -- ~30 % of R at S1M -- not per instance): a wave takes as many consecutive slots as it has visited entries with
-        // one atomic on a cursor of the pool (pool_take: sharded cursors), and leaves slot + 1 in slot_of[instance] (0 = no record), which gather_tile_partials reads
-        // where it read a validity byte before.  The values a Gaussian receives do not depend on WHICH slot held them: bit-reproducible.
-        if (tid < (uint32_t)BATCH) {                                   // (whole waves: BATCH is a multiple of 64)
+        // instance -- ~30 % of R at S1M -- not per instance): the tile took a block of max_last records when it started (one atomic
+        // per tile: rec_base above), the entry at list position p writes record rec_base + p and leaves that + 1 in
+        // slot_of[instance] (0 = no record), which gather_tile_partials reads where it read a validity byte before.  The values a
+        // Gaussian receives do not depend on WHERE its records lie: bit-reproducible.
+        if ((int)tid < n) {
             const uint32_t qw = tid >> 5, qb = 1u << (tid & 31u);
-            bool v0 = false, v1 = false, v2 = false, v3 = false;
-            if ((int)tid < n) { v0 = (s_vis[0][qw] & qb) != 0u; v1 = (s_vis[1][qw] & qb) != 0u; v2 = (s_vis[2][qw] & qb) != 0u; v3 = (s_vis[3][qw] & qb) != 0u; }
-            const bool live = v0 | v1 | v2 | v3;
-            const unsigned long long m = __ballot(live);
-            if (m) {
-                uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(m)) base = pool_take(rec_cursors, rec_cap, (uint32_t)__popcll(m), tile);
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
-                if (live) {
-                    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (base != POOL_NONE) {
-                        auto total = [&](int k) {
-                            float x = v0 ? s_slab[0][k][tid] : 0.f;
-                            x += v1 ? s_slab[1][k][tid] : 0.f;
-                            x += v2 ? s_slab[2][k][tid] : 0.f;
-                            x += v3 ? s_slab[3][k][tid] : 0.f;
-                            return x;
-                        };
-                        float4* dst = part16 + (size_t)slot * 4;
+            const bool v0 = (s_vis[0][qw] & qb) != 0u, v1 = (s_vis[1][qw] & qb) != 0u, v2 = (s_vis[2][qw] & qb) != 0u, v3 = (s_vis[3][qw] & qb) != 0u;
+            if ((v0 | v1 | v2 | v3) && rec_base != POOL_NONE) {
+                const uint32_t slot = rec_base + p0 + tid;            // the tile's block of the pool, indexed by list position
+                auto total = [&](int k) {
+                    float x = v0 ? s_slab[0][k][tid] : 0.f;
+                    x += v1 ? s_slab[1][k][tid] : 0.f;
+                    x += v2 ? s_slab[2][k][tid] : 0.f;
+                    x += v3 ? s_slab[3][k][tid] : 0.f;
+                    return x;
+                };
+                float4* dst = part16 + (size_t)slot * 4;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
-                        part17[slot] = -0.5f * s_rec[3][tid].y * total(6);      // dL_dv2g[9], see the gradient block
-                        slot_of[s_inst[tid]] = slot + 1u;
-                    } else {
-                        *async_status = 2u;      // the caller sized the scratch for fewer records than the forward staged (gof_backward_query)
-                    }
-                }
+                for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
+                part17[slot] = -0.5f * s_rec[3][tid].y * total(6);      // dL_dv2g[9], see the gradient block
+                slot_of[s_inst[tid]] = slot + 1u;
             }
         }
     }
@@ -519,7 +518,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-               float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursors,
+               float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
                uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx, uint32_t ntiles,
                const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, const uint32_t* __restrict__ tile_lens)
 {
@@ -527,7 +526,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_backward_tile(tile, ranges, point_list, rec, conic, masks, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
-                        inst_off, part16, part17, slot_of, rec_cursors, rec_cap, async_status, gx);
+                        inst_off, part16, part17, slot_of, rec_cursor, rec_cap, async_status, gx);
 }
 
 // Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):

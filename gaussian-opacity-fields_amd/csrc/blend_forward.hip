@@ -162,11 +162,13 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
         }
         __syncthreads();
         const int nwords_batch = (min(TILE_PIX, toDo) + 31) >> 5;
-        const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_entry[i]);      // (written by thread 0 in front of the barrier)
-        uint32_t* const mask_dst = masks.pool + ((size_t)chunk * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + (tid & 63u);
+        const uint32_t chunk_v = mask_entry[i];      // (written by thread 0 in front of the barrier; needed only when the batch's words are stored: the load's latency hides behind the batch)
         if (__ballot(!done) == 0ull) {             // whole wave saturated: it only helps staging (and reports "no contributors")
-            if (chunk != POOL_NONE)
+            const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_v);
+            if (chunk != POOL_NONE) {
+                uint32_t* const mask_dst = masks.pool + ((size_t)chunk * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + (tid & 63u);
                 for (int q = 0; q < nwords_batch; q++) mask_dst[q * 64] = 0u;
+            }
             continue;
         }
 
@@ -300,8 +302,11 @@ blend_forward_tile(const uint32_t tile, uint32_t (*s_mask)[TILE_PIX], const uint
         }   // chunk
         // the batch's contributor words -> this wave's sub-chunk (a batch the pool had no room for is counted by pool_take -- the
         // caller repeats the frame's forward with more room before its backward -- and not stored)
-        if (chunk != POOL_NONE)
+        const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_v);
+        if (chunk != POOL_NONE) {
+            uint32_t* const mask_dst = masks.pool + ((size_t)chunk * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + (tid & 63u);
             for (int q = 0; q < nwords_batch; q++) mask_dst[q * 64] = (q < words_valid) ? s_mask[q][tid] : 0u;
+        }
     }
 
     if (inside) {
