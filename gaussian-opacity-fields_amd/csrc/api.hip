@@ -69,7 +69,7 @@ __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
-                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_cursor, uint32_t rec_cap, uint32_t* async_status,
+                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_cursor, uint32_t rec_cap,
                                uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                uint32_t* tile_queue, const uint32_t* tile_lens);
 __global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
@@ -128,10 +128,8 @@ static int take_async_status()
 {
     std::lock_guard<std::mutex> lk(g_status_mutex);
     if (g_status_host && *g_status_host) {
-        const uint32_t code = *g_status_host;
         *g_status_host = 0;
-        if (code == 2u) set_error("an EARLIER backward was given a scratch whose record pool was smaller than what its frame staged (size it with gof_backward_scratch_bytes, or with gof_backward_query + gof_backward_scratch_bytes_for): its gradients are incomplete");
-        else set_error("an EARLIER call's tile sort timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
+        set_error("an EARLIER call's tile sort timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
         return GOF_E_DEVICE;
     }
     return GOF_OK;
@@ -617,9 +615,9 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
     if (rc) return rc;
     if (a->P == 0) return GOF_OK;
     if (!scratch || scratch_bytes < bwd_scratch_layout(a->P, R, 0, nullptr, nullptr) + ALIGN) { set_error("backward scratch missing or too small (gof_backward_scratch_bytes)"); return GOF_E_WORKSPACE; }
-    // the record pool is as large as the caller's buffer allows: R records (gof_backward_scratch_bytes: always enough) or the
-    // forward's staged count (gof_backward_query + gof_backward_scratch_bytes_for).  A pool that turns out too small raises the late
-    // status word (the next library call returns GOF_E_DEVICE) -- it cannot happen with either of the two sizes.
+    // the record pool is as large as the caller's buffer allows: R records (gof_backward_scratch_bytes: always enough), the forward's
+    // staged count (gof_backward_query + gof_backward_scratch_bytes_for), or a guess from earlier frames that the caller verifies
+    // afterwards (gof_forward_usage_async): a pool that turns out too small drops the records that do not fit.
     const uint32_t rec_cap = bwd_scratch_records(a->P, R, scratch_bytes);
     BwdScratch ws;
     bwd_scratch_layout(a->P, R, rec_cap, aligned_base(scratch), &ws);
@@ -663,7 +661,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, async_status_word(), d.gx, d.ntiles,
+                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
@@ -703,12 +701,48 @@ GOF_BACKWARD_ENTRY(gof_backward_preprocess, 2)
 #undef GOF_BACKWARD_ENTRY
 
 // What the backward of the frame in `image_ws` will need, and whether the forward's mask pool was large enough:
-//   out3_host[0] = tile-list entries the backward stages = records its scratch must hold (sum over the tiles of the deepest blended
-//                  list position, left by the forward's order_tiles_for_backward),
-//   out3_host[1] = sub-chunks of contributor masks the forward asked for, out3_host[2] = sub-chunks a binning workspace of
-//                  `binning_bytes` holds: [1] > [2] means masks are missing -- repeat the frame's forward with a binning workspace of
-//                  gof_binning_bytes_for(R, W, H, out3_host[1]) or more before calling its backward.
-// SYNCHRONISES `stream` (8 bytes read back) -- by the time a training step calls its backward the forward has finished anyway.
+//   out3[0] = tile-list entries the backward stages = records its scratch must hold (sum over the tiles of the deepest blended list
+//             position, left by the forward's order_tiles_for_backward),
+//   out3[1] = sub-chunks of contributor masks the forward asked for, out3[2] = sub-chunks a binning workspace of `binning_bytes`
+//             holds: [1] > [2] means masks are missing -- repeat the frame's forward with a binning workspace of
+//             gof_binning_bytes_for(R, W, H, out3[1]) or more, then its backward.
+// Two forms.  gof_backward_query SYNCHRONISES `stream` (268 bytes read back) and is for a caller that sizes its workspaces BEFORE the
+// backward.  gof_forward_usage_async + gof_usage_decode are for a caller that launches the backward optimistically (pools sized from
+// earlier frames; a backward whose pools were too small drops what does not fit and is simply repeated): the first enqueues the copy
+// of the raw counters (GOF_USAGE_WORDS words) into PINNED host memory behind the frame's forward and returns at once, the second
+// -- host arithmetic only -- turns the words into the three numbers once the caller has waited for its own event behind the copy.
+static void decode_usage(const uint32_t* words, uint32_t R, int32_t W, int32_t H, size_t binning_bytes, uint32_t* out3)
+{
+    BinWs b;
+    bin_layout(R, W, H, nullptr, &b, BIN_MASK_POOL, binning_bytes);
+    out3[2] = b.mp.cap;
+    const uint32_t chunks = b.mp.cap / 4u, shards = pool_shards(chunks), per = chunks / shards;      // chunks (of 4 sub-chunks) taken from the shards + chunks no shard had room for
+    uint64_t asked = words[POOL_SHARDS];
+    for (uint32_t k = 0; k < shards; k++) asked += words[k] < per ? words[k] : per;
+    out3[1] = (uint32_t)(4u * asked > 0xFFFFFFFFull ? 0xFFFFFFFFull : 4u * asked);
+    if (words[POOL_SHARDS]) out3[1] = out3[1] > b.mp.cap ? out3[1] : b.mp.cap + 4u;                   // (unserved requests: certainly more than held)
+    const uint32_t staged = words[POOL_SHARDS + 1];
+    out3[0] = (bw_order_by_length() || staged > R) ? R : staged;                                       // (developer toggle: the forward left no backward order, hence no sum: worst case)
+}
+int gof_usage_decode(const uint32_t* words_host, uint32_t R, int32_t W, int32_t H, size_t binning_bytes, uint32_t* out3_host)
+{
+    if (!words_host || !out3_host || W <= 0 || H <= 0) { set_error("NULL argument"); return GOF_E_INVALID; }
+    decode_usage(words_host, R, W, H, binning_bytes, out3_host);
+    return GOF_OK;
+}
+int gof_forward_usage_async(const GofRasterArgs* a, const void* image_ws, size_t image_bytes, uint32_t* words_pinned_host, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = validate(a);
+    if (rc) return rc;
+    if (!words_pinned_host) { set_error("words_pinned_host is NULL"); return GOF_E_INVALID; }
+    if (!image_ws || image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace missing or too small"); return GOF_E_WORKSPACE; }
+    ImageWs im;
+    image_layout(a->W, a->H, aligned_base(const_cast<void*>(image_ws)), &im);
+    GOF_HIP_CHECK(hipMemcpyAsync(words_pinned_host, im.mask_cursors, (POOL_SHARDS + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipMemcpyAsync(words_pinned_host + POOL_SHARDS + 1, im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return GOF_OK;
+}
 int gof_backward_query(const GofRasterArgs* a, uint32_t R, size_t binning_bytes, const void* image_ws, size_t image_bytes, uint32_t* out3_host, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -717,23 +751,11 @@ int gof_backward_query(const GofRasterArgs* a, uint32_t R, size_t binning_bytes,
     if (!out3_host) { set_error("out3_host is NULL"); return GOF_E_INVALID; }
     out3_host[0] = R; out3_host[1] = 0; out3_host[2] = 0;
     if (a->P == 0 || R == 0) { out3_host[0] = 0; return GOF_OK; }
-    if (!image_ws || image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace missing or too small"); return GOF_E_WORKSPACE; }
-    ImageWs im; BinWs b;
-    image_layout(a->W, a->H, aligned_base(const_cast<void*>(image_ws)), &im);
-    bin_layout(R, a->W, a->H, nullptr, &b, BIN_MASK_POOL, binning_bytes);
-    out3_host[2] = b.mp.cap;
-    uint32_t cur[POOL_SHARDS + 1], staged = 0;
-    GOF_HIP_CHECK(hipMemcpyAsync(cur, im.mask_cursors, sizeof(cur), hipMemcpyDeviceToHost, stream));
-    GOF_HIP_CHECK(hipMemcpyAsync(&staged, im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    uint32_t words[POOL_SHARDS + 2];
+    rc = gof_forward_usage_async(a, image_ws, image_bytes, words, stream_);
+    if (rc) return rc;
     GOF_HIP_CHECK(hipStreamSynchronize(stream));
-    {   // chunks (of 4 sub-chunks) taken from the shards + chunks no shard had room for
-        const uint32_t chunks = b.mp.cap / 4u, shards = pool_shards(chunks), per = chunks / shards;
-        uint64_t asked = cur[POOL_SHARDS];
-        for (uint32_t k = 0; k < shards; k++) asked += cur[k] < per ? cur[k] : per;
-        out3_host[1] = (uint32_t)(4u * asked > 0xFFFFFFFFull ? 0xFFFFFFFFull : 4u * asked);
-        if (cur[POOL_SHARDS]) out3_host[1] = out3_host[1] > b.mp.cap ? out3_host[1] : b.mp.cap + 4u;      // (unserved requests: certainly more than held)
-    }
-    if (!bw_order_by_length()) out3_host[0] = staged < R ? staged : R;          // (developer toggle: the forward left no backward order, hence no sum: worst case)
+    decode_usage(words, R, a->W, a->H, binning_bytes, out3_host);
     return GOF_OK;
 }
 

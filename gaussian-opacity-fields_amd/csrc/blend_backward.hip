@@ -146,7 +146,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                     const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
                     float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
-                    uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx)
+                    uint32_t rec_cap, uint32_t gx)
 {
     TILE_CLOCK_START();
     const uint32_t tx = tile % gx, ty = tile / gx;
@@ -212,12 +212,12 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     const uint32_t max_last = min(s_max_last, range.y - range.x);
     if (max_last == 0) { TILE_CLOCK_END(g_bw_tile_clock); return; }
     // this tile's block of the record pool: one record slot per staged list position (sum over the tiles = what gof_backward_query
-    // reports, so a scratch sized from it always has room; a smaller one loses the tile's records and raises the late status word)
+    // reports, so a scratch sized from it always has room; a smaller one loses the tile's records: the caller that sized it from
+    // earlier frames compares the staged count with its pool afterwards and repeats the backward, include/gof_hip.h)
     __shared__ uint32_t s_rec_base;
     if (tid == 0) {
         const uint32_t b0 = atomicAdd(rec_cursor, max_last);
-        s_rec_base = (b0 + max_last <= rec_cap) ? b0 : POOL_NONE;
-        if (b0 + max_last > rec_cap) *async_status = 2u;
+        s_rec_base = (b0 + max_last <= rec_cap) ? b0 : POOL_NONE;        // no room: this tile's records are dropped (the cursor still counts them)
     }
     __syncthreads();
     const uint32_t rec_base = s_rec_base;
@@ -263,10 +263,12 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         {
             const int nw = (n + 31) >> 5;
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask_entry[p0 >> 8]);
-            const uint32_t* const src = masks.pool + ((size_t)c * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + ((p0 & 255u) >> 5) * 64u + lane;
+            // (POOL_NONE: the forward's pool had no room for this batch -- the caller repeats the frame before it uses these gradients,
+            // gof_hip.h; nothing is read then)
+            const uint32_t* const src = masks.pool + ((size_t)(c == POOL_NONE ? 0u : c) * 4u + (tid >> 6)) * MASK_SUBCHUNK_WORDS + ((p0 & 255u) >> 5) * 64u + lane;
 #pragma unroll
             for (int q = 0; q < BATCH / 32; q++)
-                cmw[q] = (q < nw) ? src[q * 64] : 0u;
+                cmw[q] = (q < nw && c != POOL_NONE) ? src[q * 64] : 0u;
         }
         __syncthreads();
         if (tid == 0) BSTAT_ADD(4, n);
@@ -519,14 +521,14 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
                float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
-               uint32_t rec_cap, uint32_t* __restrict__ async_status, uint32_t gx, uint32_t ntiles,
+               uint32_t rec_cap, uint32_t gx, uint32_t ntiles,
                const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, const uint32_t* __restrict__ tile_lens)
 {
     __shared__ uint32_t s_tile;
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_backward_tile(tile, ranges, point_list, rec, conic, masks, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
-                        inst_off, part16, part17, slot_of, rec_cursor, rec_cap, async_status, gx);
+                        inst_off, part16, part17, slot_of, rec_cursor, rec_cap, gx);
 }
 
 // Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):

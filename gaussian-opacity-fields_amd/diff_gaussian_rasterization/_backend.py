@@ -55,7 +55,9 @@ def _load():
     lib.gof_forward_fused.restype = C.c_int
     lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 10 + [vp, sz, vp]
     lib.gof_backward_query.argtypes = [A, u32, sz, vp, sz, C.POINTER(u32), vp]
-    lib.gof_backward_query.restype = C.c_int
+    lib.gof_forward_usage_async.argtypes = [A, vp, sz, vp, vp]
+    lib.gof_usage_decode.argtypes = [vp, u32, i32, i32, sz, C.POINTER(u32)]
+    lib.gof_backward_query.restype = lib.gof_forward_usage_async.restype = lib.gof_usage_decode.restype = C.c_int
     lib.gof_backward_blend.argtypes = lib.gof_backward_preprocess.argtypes = lib.gof_backward.argtypes
     lib.gof_backward_blend.restype = lib.gof_backward_preprocess.restype = C.c_int
     lib.gof_integrate_prepare_points.argtypes = [A, i32, vp, vp, sz, C.POINTER(u32), vp]
@@ -207,7 +209,9 @@ FULL_BACKWARD_SCRATCH = os.environ.get("GOF_FULL_BACKWARD_SCRATCH", "0") == "1"
 FULL_MASK_POOL = os.environ.get("GOF_FULL_MASK_POOL", "0") == "1"
 _capacity = {}          # (device, P, W, H) -> instance capacity learnt from earlier frames
 _mask_need = {}         # (device, P, W, H) -> most contributor-mask sub-chunks a forward of this shape has asked for (learnt at its backward)
-_stats = {"fused_redone_frames": 0, "last_num_rendered": 0, "mask_pool_redone_frames": 0}      # bench.py reads these (no effect on the path)
+_staged_need = {}       # (device, P, W, H) -> most tile-list entries a backward of this shape has staged (= partial gradient records written)
+USAGE_WORDS = 66        # GOF_USAGE_WORDS (include/gof_hip.h)
+_stats = {"fused_redone_frames": 0, "last_num_rendered": 0, "mask_pool_redone_frames": 0, "record_pool_redone_backwards": 0}      # bench.py reads these (no effect on the path)
 
 
 class MaskPoolTooSmall(RuntimeError):
@@ -235,12 +239,32 @@ def _round_capacity(n):
 class NumRendered(int):
     """``num_rendered`` as the reference returns it -- the instance count of the frame (rasterize_points.cu:119) -- that also
     remembers the CAPACITY the frame's binning workspace was laid out for when the sync-free forward ran (``layout``; equal to
-    the count on the two-stage path).  The backward needs the layout size to find its arrays; everything else sees the count."""
+    the count on the two-stage path).  The backward needs the layout size to find its arrays; everything else sees the count.
+    ``usage``: (pinned words, event) of the frame's pool counters on their way to the host (gof_forward_usage_async), or None."""
 
-    def __new__(cls, count, layout=None):
+    def __new__(cls, count, layout=None, usage=None):
         self = super().__new__(cls, count)
         self.layout = int(count if layout is None else layout)
+        self.usage = usage
         return self
+
+    def __del__(self):                      # the frame is gone (its autograd graph was freed): its pinned words can serve another frame
+        u = getattr(self, "usage", None)
+        if u is not None and len(_usage_free) < 64:
+            _usage_free.append(u[0])
+
+
+_usage_free = []        # pinned host buffers (USAGE_WORDS int32 each) not attached to a live frame
+
+
+def _usage_in_flight(v, img):
+    """Enqueue, behind the forward just queued, the copy of the frame's pool counters into pinned host memory + an event behind it:
+    the backward of this frame reads them AFTER it has launched its kernels (optimistic pools, rasterize_gaussians_backward)."""
+    words = _usage_free.pop() if _usage_free else torch.empty(USAGE_WORDS, dtype=torch.int32).pin_memory()      # (pinning costs tens of microseconds: recycled)
+    _check(lib.gof_forward_usage_async(v.ref(), _ptr(img), img.numel(), C.c_void_p(words.data_ptr()), _stream()))
+    ev = torch.cuda.Event()
+    ev.record()
+    return words, ev
 
 
 def _layout_count(num_rendered):
@@ -285,7 +309,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 if _round_capacity(true_r) > cap:
                     _capacity[shape_key] = _round_capacity(true_r)        # growing scene: stay ahead of it
                 _stats["last_num_rendered"] = true_r
-                return NumRendered(true_r, cap), out_color, radii, geom, binning, img
+                return NumRendered(true_r, cap, None if (FULL_MASK_POOL and FULL_BACKWARD_SCRATCH) else _usage_in_flight(v, img)), out_color, radii, geom, binning, img
             if rc != GOF_E_CAPACITY:
                 _check(rc)
             _stats["fused_redone_frames"] += 1
@@ -342,19 +366,33 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):
-            R = _layout_count(R)                  # the size the forward laid the binning workspace out for (NumRendered)
-            # the record pool of the scratch: as many records as the forward staged entries (~30 % of R at S1M), asked of the image
-            # workspace -- one 4-byte read-back that waits for the forward, which a training step's backward follows anyway
-            # (GOF_FULL_BACKWARD_SCRATCH=1: the worst case, a record per instance, without the read-back)
+            # Pools (round 4).  The record pool of the scratch needs as many records as the forward staged entries (~30 % of R at S1M);
+            # the frame's mask pool (in binningBuffer) was sized from earlier frames.  Both numbers are on their way to pinned host
+            # memory since the end of the forward (NumRendered.usage).  OPTIMISTIC: size the record pool 1.25 x the most any earlier
+            # backward of this shape staged, launch, and only then look at the counters -- the host waits while the GPU already works
+            # on the backward; a pool that was too small (a new view that needs more than anything seen so far) drops what does not
+            # fit, and the backward is repeated with the exact size (or, for missing masks, after the frame's forward was repeated:
+            # MaskPoolTooSmall).  Without counters in flight (first frame of a shape, two-stage forward): the synchronising query.
+            shape_key = (str(dev), P, W, H)
+            usage = getattr(R, "usage", None)
+            R = _layout_count(R)
             full_pool = binningBuffer.numel() >= lib.gof_binning_bytes(int(R), W, H)
+            staged_guess = _staged_need.get(shape_key)
+            verify = None
             if FULL_BACKWARD_SCRATCH and full_pool:
                 nscratch = lib.gof_backward_scratch_bytes(P, int(R))
+            elif usage is not None and staged_guess is not None and not FULL_BACKWARD_SCRATCH and not (_sh_track["on"] and M > 0 and _sh_track["ready_cb"] is not None):
+                # (not when a data-parallel reducer starts its exchange from inside this backward: a repeated backward would come after
+                # the colour gradient has gone on the wire -- that path asks first)
+                rec_guess = min(int(R), int(staged_guess * 1.25) + 4096)
+                nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), rec_guess)
+                verify = (usage, rec_guess)
             else:
                 q = (C.c_uint32 * 3)()
                 _check(lib.gof_backward_query(v.ref(), int(R), binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), q, _stream()))
                 staged, requested, held = int(q[0]), int(q[1]), int(q[2])
-                shape_key = (str(dev), P, W, H)
                 _mask_need[shape_key] = max(_mask_need.get(shape_key, 0), requested)
+                _staged_need[shape_key] = max(_staged_need.get(shape_key, 0), staged)
                 if requested > held:
                     raise MaskPoolTooSmall(requested, held)
                 nscratch = lib.gof_backward_scratch_bytes(P, int(R)) if FULL_BACKWARD_SCRATCH else lib.gof_backward_scratch_bytes_for(P, int(R), staged)
@@ -378,6 +416,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _check(lib.gof_backward_preprocess(*call))
             else:
                 _check(lib.gof_backward(*call))
+            if verify is not None:
+                (words, ev), rec_guess = verify
+                ev.synchronize()                      # the FORWARD's counters (long there: the GPU is busy with the backward just queued)
+                q = (C.c_uint32 * 3)()
+                _check(lib.gof_usage_decode(C.c_void_p(words.data_ptr()), int(R), W, H, binningBuffer.numel(), q))
+                staged, requested, held = int(q[0]), int(q[1]), int(q[2])
+                _mask_need[shape_key] = max(_mask_need.get(shape_key, 0), requested)
+                _staged_need[shape_key] = max(_staged_need.get(shape_key, 0), staged)
+                if requested > held:                  # masks are missing: the gradients just computed are incomplete -> forward again, then backward
+                    raise MaskPoolTooSmall(requested, held)
+                if staged > rec_guess:                # records were dropped: the same backward again, with room for all of them
+                    _stats["record_pool_redone_backwards"] += 1
+                    nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), staged)
+                    scratch = v.bytes_tensor(nscratch)
+                    call = call[:-3] + (_ptr(scratch), nscratch, _stream())
+                    _check(lib.gof_backward(*call))
     return g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_v2g
 
 

@@ -168,12 +168,22 @@ int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
  *   gof_backward_scratch_bytes_for(P, R, staged):    the size for a pool of exactly that many records (4 + 68 x staged / R bytes per
  *                                                    instance instead of 72).
  * The backward derives the pool's capacity from the scratch_bytes it is given.  A pool smaller than what the frame stages (impossible
- * with either size above) loses records and raises the late status word: the next library call returns GOF_E_DEVICE. */
+ * with either size above) drops the records that do not fit: see gof_forward_usage_async for the caller that sizes it from earlier frames. */
 size_t gof_backward_scratch_bytes(int32_t P, uint32_t num_rendered);
 size_t gof_backward_scratch_bytes_for(int32_t P, uint32_t num_rendered, uint32_t staged_entries);
 int gof_backward_query(const GofRasterArgs* args, uint32_t num_rendered, size_t binning_bytes, const void* image_ws, size_t image_bytes,
                        uint32_t* out3_host /* [0] staged entries, [1] mask sub-chunks requested, [2] mask sub-chunks binning_bytes holds */,
                        void* stream);
+/* The same three numbers without a synchronisation inside the library, for a caller that launches the backward OPTIMISTICALLY: pools
+ * sized from earlier frames, the backward queued at once, the check afterwards.  A backward whose record pool was too small drops the
+ * records that did not fit; one whose frame lacks masks skips those batches -- both write incomplete gradients and nothing out of
+ * bounds, and the caller, who compares [0] with its pool and [1] with [2] before it uses the gradients, simply repeats what was short.
+ *   gof_forward_usage_async: enqueue, behind the frame's forward on `stream`, the copy of the raw counters (GOF_USAGE_WORDS uint32)
+ *                            into PINNED host memory; returns at once.  The caller records its own event behind it.
+ *   gof_usage_decode:        host arithmetic only: the raw counters -> out3 as above (after the caller has waited for its event). */
+#define GOF_USAGE_WORDS 66
+int gof_forward_usage_async(const GofRasterArgs* args, const void* image_ws, size_t image_bytes, uint32_t* words_pinned_host, void* stream);
+int gof_usage_decode(const uint32_t* words_host, uint32_t num_rendered, int32_t W, int32_t H, size_t binning_bytes, uint32_t* out3_host);
 /* dL_dout is [9,H,W].  All gradient outputs are fully written by the call (the library
  * zero-fills them itself; the reference binding allocates them with torch::zeros,
  * rasterize_points.cu:161-170).  dL_dcov3D [P,6] is all zero in the reference (its producer

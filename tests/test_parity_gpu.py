@@ -538,7 +538,7 @@ def test_learnt_mask_pool_its_redo_and_the_record_pool_through_autograd():
     sc = SCENES["posed_mid100k"]()
     sd = to_dev(sc)
     key = (str(sd["means3D"].device), sd["means3D"].shape[0], sd["W"], sd["H"])
-    B._capacity.pop(key, None); B._mask_need.pop(key, None)
+    B._capacity.pop(key, None); B._mask_need.pop(key, None); B._staged_need.pop(key, None)
     dL = torch.randn((9, sd["H"], sd["W"]), generator=torch.Generator().manual_seed(4)).cuda()
 
     def step():
@@ -559,9 +559,18 @@ def test_learnt_mask_pool_its_redo_and_the_record_pool_through_autograd():
     B._mask_need[key] = 16                  # sabotage: the next forward gets a pool far too small
     c2, g2 = step()
     assert B._stats["mask_pool_redone_frames"] == redone + 1 and B._mask_need[key] == need      # noticed, repeated, learnt again
-    for c in (c1, c2):
+    # the record pool is sized OPTIMISTICALLY from earlier backwards (1.25 x the most staged so far), the backward launched, the
+    # frame's counters read afterwards: a guess that was too small (sabotaged here) costs a repeated backward, not a wrong gradient
+    staged = B._staged_need[key]
+    again = B._stats["record_pool_redone_backwards"]
+    c3, g3 = step()
+    assert B._stats["record_pool_redone_backwards"] == again          # steady state: the guess holds
+    B._staged_need[key] = 10
+    c4, g4 = step()
+    assert B._stats["record_pool_redone_backwards"] == again + 1 and B._staged_need[key] == staged
+    for c in (c1, c2, c3, c4):
         assert torch.equal(c, c0)
-    for g in (g1, g2):
+    for g in (g1, g2, g3, g4):
         for k in g0:
             assert torch.equal(g[k], g0[k]), k
     # the workspaces did shrink: binning (sort state + mask pool) and the backward scratch (slot words + record pool)
