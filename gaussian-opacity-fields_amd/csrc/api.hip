@@ -65,7 +65,7 @@ __global__ void blend_forward_exact(const uint2* ranges, const uint32_t* point_l
                                     float* out_color, MaskPool masks, uint32_t* mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                                     uint32_t* tile_cost);
 __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges,
-                            uint32_t* clear_cursors);
+                            uint32_t* clear_cursors, uint32_t* staged_out);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
@@ -206,7 +206,7 @@ size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
     carve(p, im.tile_queue, (size_t)TILE_QUEUE_WORDS);
     carve(p, im.tile_cost, T);
     carve(p, im.tile_order_bw, (size_t)NXCD * tile_queue_stride((uint32_t)T));
-    carve(p, im.mask_cursors, (size_t)POOL_SHARDS + 1);
+    carve(p, im.mask_cursors, (size_t)POOL_SHARDS + 2);      // [POOL_SHARDS + 1]: the staged-entry sum of the backward's order (one copy brings all of it to the host)
     if (out) *out = im;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -352,7 +352,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     }
     // dispatch order of the tile kernels: every XCD an equal share of every cost class, heaviest first (gof_common.h: pop_tile)
     { GOF_PROFILE("order_tiles", stream);
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors); }
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr); }
     GOF_LAUNCH_CHECK(stream, dbg);
     return GOF_OK;
 }
@@ -370,7 +370,7 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
     if (bw_order_by_length()) return;
     GOF_PROFILE("order_tiles_bw", stream);
     // (queue lengths at tile_queue[40..47]; the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr, nullptr);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr, nullptr, im.mask_cursors + POOL_SHARDS + 1);
 }
 
 // The forward blend.  Default: the reference's arithmetic without its two fp64 divisions per pair (blend_forward.hip: pair_nodiv_cc).
@@ -517,7 +517,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
         rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors);
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr);
     }
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
@@ -739,8 +739,7 @@ int gof_forward_usage_async(const GofRasterArgs* a, const void* image_ws, size_t
     if (!image_ws || image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace missing or too small"); return GOF_E_WORKSPACE; }
     ImageWs im;
     image_layout(a->W, a->H, aligned_base(const_cast<void*>(image_ws)), &im);
-    GOF_HIP_CHECK(hipMemcpyAsync(words_pinned_host, im.mask_cursors, (POOL_SHARDS + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GOF_HIP_CHECK(hipMemcpyAsync(words_pinned_host + POOL_SHARDS + 1, im.tile_queue + TILE_QUEUE_WORDS / 2 + BW_STAGED_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipMemcpyAsync(words_pinned_host, im.mask_cursors, (POOL_SHARDS + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     return GOF_OK;
 }
 int gof_backward_query(const GofRasterArgs* a, uint32_t R, size_t binning_bytes, const void* image_ws, size_t image_bytes, uint32_t* out3_host, void* stream_)
@@ -893,7 +892,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         GOF_LAUNCH_CHECK(stream, a->debug);
     } }
     // dispatch order of the point pass: #points of the tile x what its pixels walked (tile_cost, left by integrate_pixels), heaviest first
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges, nullptr);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges, nullptr, nullptr);
     GOF_LAUNCH_CHECK(stream, a->debug);
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,

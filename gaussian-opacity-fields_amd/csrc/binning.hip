@@ -185,7 +185,7 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
 // the tile's query points (point pass).  What it buys is measured in bench.py's "clustered" leg (profiles/r03_tile_schedule.md).
 __global__ void __launch_bounds__(1024)
 order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cost_in, uint32_t* __restrict__ order,
-            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges, uint32_t* __restrict__ clear_cursors)
+            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges, uint32_t* __restrict__ clear_cursors, uint32_t* __restrict__ staged_out)
 {
     if (clear_cursors && threadIdx.x <= POOL_SHARDS) clear_cursors[threadIdx.x] = 0u;      // the mask pool of the frame's forward blend starts empty
     constexpr int NB = 128;                       // bucket = 2 * floor(log2(c)) + next bit, descending (64 used; quarter-octave classes ordered
@@ -267,6 +267,7 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
     }
     __syncthreads();
     if (tid == 0 && queue) queue[BW_STAGED_WORD] = s_staged;
+    if (tid == 0 && staged_out) *staged_out = s_staged;          // (the backward's order: next to the mask pool's cursors, so that one copy brings the frame's counters to the host)
     {   // per bucket: exclusive prefix over the waves (ascending tile id), total n_b; then G_b = tiles in heavier buckets
         uint32_t run = 0, inc = 0;
         if (tid < NB) {
