@@ -45,7 +45,7 @@ def pmc(sub):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in out.items()}
 
 
-passes = {s: pmc(s) for s in ("fetch", "write", "sq1", "sq2", "sq3", "sq4")}
+passes = {s: pmc(s) for s in ("fetch", "write", "sq1", "sq2", "sq3", "sq4", "tcc")}
 kernels = sorted(set().union(*[set(p) for p in passes.values()]))
 import bench as bench_mod
 data = {"_kernel_sha16": bench_mod.kernel_sha16(), "_sha16_by_kernel": {k: bench_mod.kernel_sha16(k) for k in kernels if k in bench_mod.KERNEL_SOURCES},
@@ -59,7 +59,7 @@ for k in kernels:
     if f is not None or w is not None:
         e.update(fetch_KiB_raw=f or 0.0, write_KiB=w or 0.0, hbm_bytes_corrected=2 * (f or 0.0) * 1024 + (w or 0.0) * 1024)
     c = {}
-    for s in ("sq1", "sq2", "sq3", "sq4"):
+    for s in ("sq1", "sq2", "sq3", "sq4", "tcc"):
         c.update(passes[s].get(k, {}))
     if c:
         e["counters"] = c
@@ -77,6 +77,8 @@ for k in kernels:
             e["valu_issue_frac"] = min(1.0, e["valu_active_over_simd_cycles"])
             if c.get("SQ_INSTS_VALU"):
                 e["valu_insts_per_simd_cycle"] = c["SQ_INSTS_VALU"] / (1024.0 * cycles)           # wave64 instructions issued per SIMD and cycle
+        if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
+            e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
         if c.get("SQ_INSTS_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
             e["cycles_per_valu_inst"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
         if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
@@ -108,14 +110,15 @@ with open(md, "w") as o:
             "issue rate; cycles per VALU instruction = active time / SQ_INSTS_VALU;\n"
             "lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wave-cycle split: parked at s_waitcnt / barrier (WAIT_ANY), issue stall\n"
             "(WAIT_INST_ANY), issuing (ACTIVE_INST_ANY).\n\n"
-            "| kernel | VALU insts | VALU active / SIMD-cycles | VALU inst / SIMD-cycle | cycles / VALU inst | lane utilisation | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | LDS bank conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|---|---|\n")
+            "| kernel | VALU insts | VALU active / SIMD-cycles | VALU inst / SIMD-cycle | cycles / VALU inst | lane utilisation | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | LDS bank conflict cycles / LDS active | L2 hit rate (TCC_HIT / (HIT + MISS)) |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
     for k, v in sorted(((k, v) for k, v in data.items() if isinstance(v, dict) and "valu_pipe_busy_frac" in v), key=lambda kv: -kv[1]["counters"].get("SQ_INSTS_VALU", 0)):
         c = v["counters"]
-        o.write("| %s | %.3e | %.2f | %.3f | %.2f | %s | %s | %s | %s | %s |\n" % (
+        o.write("| %s | %.3e | %.2f | %.3f | %.2f | %s | %s | %s | %s | %s | %s |\n" % (
             k, c.get("SQ_INSTS_VALU", 0), v["valu_pipe_busy_frac"], v.get("valu_insts_per_simd_cycle", float("nan")), v.get("cycles_per_valu_inst", float("nan")),
             "%.2f" % v["valu_lane_utilisation"] if "valu_lane_utilisation" in v else "-",
             *["%.2f" % v[n] if n in v else "-" for n in ("sq_wait_any_frac_of_wave_cycles", "sq_wait_inst_any_frac_of_wave_cycles", "sq_active_inst_any_frac_of_wave_cycles")],
-            "%.2f" % (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else "-"))
+            "%.2f" % (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else "-",
+            "%.3f" % v["l2_hit_rate"] if "l2_hit_rate" in v else "-"))
     o.write("\n## VALU instruction mix of the blend kernels (SQ_INSTS_VALU_* pass)\n\n| kernel | " + " | ".join(
         n.replace("SQ_INSTS_VALU_", "") for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
                                                  "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) + " |\n|---|" + "---|" * 8 + "\n")
