@@ -380,7 +380,11 @@ def workspace_report(B, P, W, H, R, staged):
     cap = B._capacity[key[0]] if key else R
     sub = B._mask_pool_subchunks(key[0]) if key else None
     binning = int(lib.gof_binning_bytes(cap, W, H) if sub is None else lib.gof_binning_bytes_for(cap, W, H, sub))
-    scratch_full, scratch = int(lib.gof_backward_scratch_bytes(P, R)), int(lib.gof_backward_scratch_bytes_for(P, cap, staged))
+    scratch_full = int(lib.gof_backward_scratch_bytes(P, R))
+    if B._exchange_starts_inside_backward():      # N > 1: the reducer starts its all-gather inside the backward -> worst-case pools (nothing to verify or repeat)
+        scratch = int(lib.gof_backward_scratch_bytes(P, cap))
+    else:
+        scratch = int(lib.gof_backward_scratch_bytes_for(P, cap, staged))
     d_bin = binning / max(R, 1)
     fixed = int(lib.gof_backward_scratch_bytes_for(P, 0, 0))
     d_scr = (scratch - fixed) / max(R, 1)

@@ -211,7 +211,8 @@ _capacity = {}          # (device, P, W, H) -> instance capacity learnt from ear
 _mask_need = {}         # (device, P, W, H) -> most contributor-mask sub-chunks a forward of this shape has asked for (learnt at its backward)
 _staged_need = {}       # (device, P, W, H) -> most tile-list entries a backward of this shape has staged (= partial gradient records written)
 USAGE_WORDS = 66        # GOF_USAGE_WORDS (include/gof_hip.h)
-_stats = {"fused_redone_frames": 0, "last_num_rendered": 0, "mask_pool_redone_frames": 0, "record_pool_redone_backwards": 0}      # bench.py reads these (no effect on the path)
+_stats = {"fused_redone_frames": 0, "last_num_rendered": 0, "mask_pool_redone_frames": 0, "record_pool_redone_backwards": 0,
+          "backward_queries": 0}      # bench.py reads these (no effect on the path)
 
 
 class MaskPoolTooSmall(RuntimeError):
@@ -224,10 +225,17 @@ class MaskPoolTooSmall(RuntimeError):
         self.requested, self.capacity = requested, capacity
 
 
+def _exchange_starts_inside_backward():
+    """A data-parallel reducer starts its all-gather from inside the backward (set_sh_grad_ready_callback): a backward that had to
+    be repeated would come after the colour gradient has gone on the wire, and a read-back in front of the backward would idle the
+    GPU on every rank and step -- such frames get WORST-CASE pools instead (118 B per instance as in rounds 2-3, nothing to verify)."""
+    return _sh_track["on"] and _sh_track["ready_cb"] is not None
+
+
 def _mask_pool_subchunks(shape_key):
     """sub-chunks to size the fused forward's mask pool for: 1.25 x the largest request seen for this shape (None: not learnt yet,
     or switched off -> the worst case)"""
-    need = None if FULL_MASK_POOL else _mask_need.get(shape_key)
+    need = None if (FULL_MASK_POOL or _exchange_starts_inside_backward()) else _mask_need.get(shape_key)
     return None if need is None else int(need * 1.25) + 256
 _pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
 
@@ -309,7 +317,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 if _round_capacity(true_r) > cap:
                     _capacity[shape_key] = _round_capacity(true_r)        # growing scene: stay ahead of it
                 _stats["last_num_rendered"] = true_r
-                return NumRendered(true_r, cap, None if (FULL_MASK_POOL and FULL_BACKWARD_SCRATCH) else _usage_in_flight(v, img)), out_color, radii, geom, binning, img
+                no_counters = (FULL_MASK_POOL and FULL_BACKWARD_SCRATCH) or _exchange_starts_inside_backward()
+                return NumRendered(true_r, cap, None if no_counters else _usage_in_flight(v, img)), out_color, radii, geom, binning, img
             if rc != GOF_E_CAPACITY:
                 _check(rc)
             _stats["fused_redone_frames"] += 1
@@ -379,23 +388,26 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             full_pool = binningBuffer.numel() >= lib.gof_binning_bytes(int(R), W, H)
             staged_guess = _staged_need.get(shape_key)
             verify = None
-            if FULL_BACKWARD_SCRATCH and full_pool:
-                nscratch = lib.gof_backward_scratch_bytes(P, int(R))
-            elif usage is not None and staged_guess is not None and not FULL_BACKWARD_SCRATCH and not (_sh_track["on"] and M > 0 and _sh_track["ready_cb"] is not None):
+            early_exchange = _exchange_starts_inside_backward() and M > 0
+            if (FULL_BACKWARD_SCRATCH or early_exchange) and full_pool:
+                nscratch = lib.gof_backward_scratch_bytes(P, int(R))          # a record per instance, a full mask pool: nothing can be missing
+            elif usage is not None and staged_guess is not None and not FULL_BACKWARD_SCRATCH and not early_exchange:
                 # (not when a data-parallel reducer starts its exchange from inside this backward: a repeated backward would come after
-                # the colour gradient has gone on the wire -- that path asks first)
+                # the colour gradient has gone on the wire -- such a frame has worst-case pools (branch above) or, if its forward
+                # ran before the reducer was switched on, asks first)
                 rec_guess = min(int(R), int(staged_guess * 1.25) + 4096)
                 nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), rec_guess)
                 verify = (usage, rec_guess)
             else:
                 q = (C.c_uint32 * 3)()
+                _stats["backward_queries"] += 1           # (a synchronising read-back: first frame of a shape, two-stage forward)
                 _check(lib.gof_backward_query(v.ref(), int(R), binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), q, _stream()))
                 staged, requested, held = int(q[0]), int(q[1]), int(q[2])
                 _mask_need[shape_key] = max(_mask_need.get(shape_key, 0), requested)
                 _staged_need[shape_key] = max(_staged_need.get(shape_key, 0), staged)
                 if requested > held:
                     raise MaskPoolTooSmall(requested, held)
-                nscratch = lib.gof_backward_scratch_bytes(P, int(R)) if FULL_BACKWARD_SCRATCH else lib.gof_backward_scratch_bytes_for(P, int(R), staged)
+                nscratch = lib.gof_backward_scratch_bytes(P, int(R)) if (FULL_BACKWARD_SCRATCH or early_exchange) else lib.gof_backward_scratch_bytes_for(P, int(R), staged)
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),

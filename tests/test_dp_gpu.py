@@ -150,6 +150,20 @@ def _worker_rccl(port, ret):
     for k in names:
         if not torch.equal(params[k].grad, local[k]):
             msg.append("dense: %s changed" % k)
+    # frames whose backward starts the exchange get worst-case pools (nothing to verify, nothing to repeat after the colour gradient
+    # has gone on the wire): no synchronising read-back in front of the backward on the sync-free forward's frames either
+    if not B._exchange_starts_inside_backward():
+        msg.append("the reducer's ready-callback is not installed")
+    q0 = B._stats["backward_queries"]
+    for _ in range(3):
+        color, _ = GaussianRasterizer(settings_from(sd))(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                                         opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"])
+        color.sum().backward()
+    torch.cuda.synchronize()
+    if B._stats["backward_queries"] != q0:
+        msg.append("%d read-backs in front of backwards that start the exchange" % (B._stats["backward_queries"] - q0))
+    red._early = []
+    B._sh_track.update(count=0, src=None)
     # packed fallback (gradients that are separate allocations), averaged: still the identity at one rank
     for k in names:
         params[k].grad = local[k].clone()
