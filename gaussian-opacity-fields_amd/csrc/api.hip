@@ -43,13 +43,15 @@ uint32_t higher_msb(uint32_t n);
 size_t scan_tmp_words(size_t n);
 hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
                            const uint32_t** total_dev_out, hipStream_t stream);
+hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host);
 size_t rs_tmp_words(size_t n);
 const uint32_t* radix_sort_error_flag(const uint32_t* tmp, size_t n, int end_bit);
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 int radix_passes(int end_bit);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity);
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first);
 __global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev, const uint32_t* sort_error,
@@ -65,7 +67,7 @@ __global__ void blend_forward_exact(const uint2* ranges, const uint32_t* point_l
                                     float* out_color, MaskPool masks, uint32_t* mask_cursors, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order, uint32_t* tile_queue,
                                     uint32_t* tile_cost);
 __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t* cost_in, uint32_t* order, uint32_t* queue, const uint2* times_ranges,
-                            uint32_t* clear_cursors, uint32_t* staged_out);
+                            uint32_t* clear_cursors, uint32_t* staged_out, const uint32_t* cursors_in, uint32_t* usage_host);
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
@@ -123,6 +125,16 @@ static uint32_t* async_status_word()
         g_status_dev = static_cast<uint32_t*>(d);
     }
     return g_status_dev;
+}
+// Device-visible address of `host_words` if that is pinned, device-mapped host memory (hipHostMalloc -- what torch's pin_memory() uses),
+// else nullptr: kernels then store a few result words there themselves, where a hipMemcpyAsync would put one or two blit kernels
+// (4-5 us each) on the stream.
+static uint32_t* device_view_of_pinned(uint32_t* host_words)
+{
+    if (!host_words) return nullptr;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host_words, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<uint32_t*>(d);
 }
 static int take_async_status()
 {
@@ -186,6 +198,7 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     carve(p, g.dval_a, n);          // depth-sorted Gaussian ids (kept for the render stage)
     carve(p, g.order_off, n);
     carve(p, g.dkey_a, n);
+    g.inst_first = g.dkey_a;        // (the sorted depth keys are dead once the depth sort has delivered the order: emit_instances writes over them)
     carve(p, g.dkey_b, n);
     carve(p, g.dval_b, n);
     carve(p, g.sort_tmp, rs_tmp_words(n) + scan_tmp_words(n));
@@ -333,7 +346,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
         { GOF_PROFILE("emit_instances", stream);
         hipLaunchKernelGGL(emit_instances, dim3((a->P + 255) / 256), dim3(256), 0, stream, a->P, g.dval_a, g.order_off, g.dkey_b, g.dval_b,
-                           t_in, v_in, d.gx, R); }
+                           t_in, v_in, d.gx, R, g.inst_first); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
         int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev);
@@ -352,7 +365,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     }
     // dispatch order of the tile kernels: every XCD an equal share of every cost class, heaviest first (gof_common.h: pop_tile)
     { GOF_PROFILE("order_tiles", stream);
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr); }
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr); }
     GOF_LAUNCH_CHECK(stream, dbg);
     return GOF_OK;
 }
@@ -365,12 +378,14 @@ static bool bw_order_by_length()
     static const bool on = [] { const char* e = getenv("GOF_BW_ORDER_BY_LENGTH"); return e && e[0] == '1'; }();
     return on;
 }
-static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream_t stream)
+// usage_host (nullable): device-visible address of the caller's pinned GOF_USAGE_WORDS words (gof_forward_fused)
+static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream_t stream, uint32_t* usage_host = nullptr)
 {
     if (bw_order_by_length()) return;
     GOF_PROFILE("order_tiles_bw", stream);
     // (queue lengths at tile_queue[40..47]; the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr, nullptr, im.mask_cursors + POOL_SHARDS + 1);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr, nullptr, im.mask_cursors + POOL_SHARDS + 1,
+                       im.mask_cursors, usage_host);
 }
 
 // The forward blend.  Default: the reference's arithmetic without its two fp64 divisions per pair (blend_forward.hip: pair_nodiv_cc).
@@ -398,7 +413,7 @@ extern "C" {
 const char* gof_last_error(void) { return g_error.c_str(); }
 int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
 int gof_set_tight_tile_rects(int on) { return g_tight_rects.exchange(on ? 1 : 0); }
-int gof_abi_version(void) { return 9; }   // 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query (round 4)
+int gof_abi_version(void) { return 10; }  // 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query; 10: gof_forward_fused(usage_pinned_host), backward scratch without its scan (round 4)
                                           // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
@@ -415,7 +430,8 @@ size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_l
 size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
 
 // preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
-static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream)
+static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream,
+                          uint32_t* total_host_mapped = nullptr)
 {
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
@@ -439,8 +455,8 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     // scanned in place
     hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, g.dkey_b, g.dval_b, g.order_off,
                        radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles);
-    GOF_HIP_CHECK(device_scan_u32(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
-                                  total_dev_out, stream)); }
+    GOF_HIP_CHECK(device_scan_u32_to_host(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
+                                          total_dev_out, stream, total_host_mapped)); }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
@@ -489,7 +505,8 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
 // the call, with emission, tile sort and the blend already queued behind it.  If the count exceeds the capacity the call returns
 // GOF_E_CAPACITY (nothing was written out of bounds) and the caller redoes the frame through gof_forward_prepare/render.
 int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes,
-                      void* image_ws, size_t image_bytes, int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, void* stream_)
+                      void* image_ws, size_t image_bytes, int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host,
+                      uint32_t* usage_pinned_host, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
@@ -506,22 +523,28 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     bin_layout(capacity, a->W, a->H, aligned_base(binning_ws), &b, BIN_MASK_POOL, binning_bytes);
     const Dims d = dims_of(a);
     const uint32_t* total_dev = nullptr;
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream);
+    // the two host-bound results -- the instance count (needed ~0.3 ms into the call) and the frame's pool counters (at its end) -- are
+    // stored by the kernels that produce them into the caller's pinned memory, if that is device-mapped: no copy launches in the stream
+    uint32_t* const count_mapped = device_view_of_pinned(num_rendered_pinned_host);
+    uint32_t* const usage_mapped = device_view_of_pinned(usage_pinned_host);
+    *num_rendered_pinned_host = 0xFFFFFFFFu;
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream, count_mapped);
     if (rc) return rc;
     static thread_local hipEvent_t ev = nullptr;
     if (!ev) GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    *num_rendered_pinned_host = 0xFFFFFFFFu;
-    GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!count_mapped) GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipEventRecord(ev, stream));
     if (capacity > 0) {
         rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr);
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr);
     }
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
-    order_tiles_for_backward(d, im, stream);
+    order_tiles_for_backward(d, im, stream, usage_mapped);
+    if (usage_pinned_host && !usage_mapped)       // (not device-mapped: the copy form, as gof_forward_usage_async)
+        GOF_HIP_CHECK(hipMemcpyAsync(usage_pinned_host, im.mask_cursors, (POOL_SHARDS + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipEventSynchronize(ev));
     if (*num_rendered_pinned_host >= GOF_SORT_FAILED_COUNT) {
         set_error("depth sort: a single-kernel radix pass timed out waiting for a predecessor block (GPU heavily oversubscribed?)");
@@ -563,12 +586,13 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     return GOF_OK;
 }
 
-// backward scratch: first instance of every Gaussian in GAUSSIAN-ID order ([P] u32: exclusive scan of tiles_touched), scan scratch,
+// backward scratch (the number of a Gaussian's first instance comes from the forward: GeomWs::inst_first, written by emit_instances --
+// until round 4 the backward scanned tiles_touched itself, two launches and 14 us per step):
 // the backward's queue heads + the record pool's cursor, then per tile instance (R of them) a slot word (slot + 1 of the instance's
 // partial gradient record, 0 = none), and the record POOL: per record the 17th partial gradient f32 and the 64-byte line of the other
 // 16.  The pool holds `records` records: R for the worst case (every instance staged), or the number the forward actually staged
 // (gof_backward_query: ~30 % of R at S1M) -- 4 + 68 x 0.3 B per instance instead of 69.
-struct BwdScratch { uint32_t* inst_off; uint32_t* scan_tmp; uint32_t* queue; uint32_t* slot_of; float* part17; float4* part16; };
+struct BwdScratch { uint32_t* queue; uint32_t* slot_of; float* part17; float4* part16; };
 constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads ([0..7]) and the record pool's cursor ([BWD_REC_CURSOR]) sit right in front of the slot words: one memset clears both
 constexpr int BWD_REC_CURSOR = 16;
 constexpr uint32_t BWD_REC_SLACK = 0;        // (a tile takes exactly its staged entries: the sum is what gof_backward_query reports)
@@ -577,8 +601,7 @@ static size_t bwd_scratch_layout(int32_t P, uint32_t R, uint32_t records, void* 
     char* p = static_cast<char*>(base);
     const size_t p0 = reinterpret_cast<size_t>(p);
     BwdScratch t;
-    carve(p, t.inst_off, (size_t)(P < 1 ? 1 : P));
-    carve(p, t.scan_tmp, scan_tmp_words((size_t)(P < 1 ? 1 : P)));
+    (void)P;
     carve(p, t.queue, BWD_QUEUE_BYTES / 4 + (size_t)R + 1);
     t.slot_of = t.queue + BWD_QUEUE_BYTES / 4;
     carve(p, t.part17, (size_t)records + 1);
@@ -658,16 +681,15 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
 
     if (R > 0) {
         GOF_PROFILE("blend_backward", stream);
-        GOF_HIP_CHECK(device_scan_u32(g.tiles_touched, nullptr, ws.inst_off, (size_t)a->P, false, ws.scan_tmp, nullptr, stream));
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, ws.inst_off, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, d.gx, d.ntiles,
+                           im.n_contrib, dL_dout, g.rect, g.inst_first, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);
       // R == 0: tiles_touched is 0 everywhere, the kernel writes zeros
-      hipLaunchKernelGGL(gather_tile_partials, dim3((unsigned)(((size_t)a->P * 4 + 255) / 256)), dim3(256), 0, stream, a->P, ws.inst_off, g.tiles_touched, ws.part16, ws.part17,
+      hipLaunchKernelGGL(gather_tile_partials, dim3((unsigned)(((size_t)a->P * 4 + 255) / 256)), dim3(256), 0, stream, a->P, g.inst_first, g.tiles_touched, ws.part16, ws.part17,
                          ws.slot_of, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian);
       GOF_LAUNCH_CHECK(stream, a->debug); }
     }
@@ -892,7 +914,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         GOF_LAUNCH_CHECK(stream, a->debug);
     } }
     // dispatch order of the point pass: #points of the tile x what its pixels walked (tile_cost, left by integrate_pixels), heaviest first
-    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges, nullptr, nullptr);
+    hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, pb.pt_order, pb.pt_queue, im.point_ranges, nullptr, nullptr, nullptr, nullptr);
     GOF_LAUNCH_CHECK(stream, a->debug);
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,

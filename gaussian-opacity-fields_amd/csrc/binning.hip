@@ -68,7 +68,8 @@ gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restr
 // of 64 slots scattered ~10 entries apart.
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
-               const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity)
+               const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity,
+               uint32_t* __restrict__ inst_first)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -76,6 +77,9 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     if (i < P) {
         idx = order[i];
         off = order_off[i];
+        // number of the Gaussian's first instance in THIS emission order, by Gaussian id: the backward numbers its partial gradient
+        // records with it (entry k of the rectangle, row-major, is instance inst_first + k) -- it used to scan tiles_touched itself
+        if (inst_first) inst_first[idx] = off;
         const uint32_t mxy = minxy_sorted[i], wh = wh_sorted[i];
         if (wh) {
             minx = mxy & 0xFFFFu; miny = mxy >> 16;
@@ -185,7 +189,8 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
 // the tile's query points (point pass).  What it buys is measured in bench.py's "clustered" leg (profiles/r03_tile_schedule.md).
 __global__ void __launch_bounds__(1024)
 order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cost_in, uint32_t* __restrict__ order,
-            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges, uint32_t* __restrict__ clear_cursors, uint32_t* __restrict__ staged_out)
+            uint32_t* __restrict__ queue, const uint2* __restrict__ times_ranges, uint32_t* __restrict__ clear_cursors, uint32_t* __restrict__ staged_out,
+            const uint32_t* __restrict__ cursors_in, uint32_t* __restrict__ usage_host)
 {
     if (clear_cursors && threadIdx.x <= POOL_SHARDS) clear_cursors[threadIdx.x] = 0u;      // the mask pool of the frame's forward blend starts empty
     constexpr int NB = 128;                       // bucket = 2 * floor(log2(c)) + next bit, descending (64 used; quarter-octave classes ordered
@@ -268,6 +273,12 @@ order_tiles(uint32_t ntiles, const uint2* __restrict__ ranges, const uint32_t* _
     __syncthreads();
     if (tid == 0 && queue) queue[BW_STAGED_WORD] = s_staged;
     if (tid == 0 && staged_out) *staged_out = s_staged;          // (the backward's order: next to the mask pool's cursors, so that one copy brings the frame's counters to the host)
+    // the frame's counters (GOF_USAGE_WORDS: the mask pool's cursors, final since the forward blend has ended, + the staged sum)
+    // stored straight into the caller's host-mapped pinned memory: no copy launch behind the forward (two blit kernels, 9 us)
+    if (usage_host) {
+        if (tid <= POOL_SHARDS) __hip_atomic_store(usage_host + tid, cursors_in[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(usage_host + POOL_SHARDS + 1, s_staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     {   // per bucket: exclusive prefix over the waves (ascending tile id), total n_b; then G_b = tiles in heavier buckets
         uint32_t run = 0, inc = 0;
         if (tid < NB) {

@@ -55,6 +55,7 @@ struct GeomWs {
     uint32_t* dkey_a; uint32_t* dkey_b;   // [P]
     uint32_t* dval_a; uint32_t* dval_b;   // [P]  dval_a holds the depth-sorted Gaussian ids after the sort
     uint32_t* order_off;    // [P] exclusive scan of tiles_touched in depth order = first instance of the i-th sorted Gaussian
+    uint32_t* inst_first;   // [P] = dkey_a, written by emit_instances: number of Gaussian id's first instance in emission (depth) order -- the backward's record numbering
     uint32_t* sort_tmp;     // radix / scan scratch (rs_tmp_words(P) + scan_tmp_words(P) words)
     uint32_t* total;        // [1] device copy of num_rendered
 };

@@ -70,7 +70,7 @@ scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restric
 }
 // single block: exclusive scan of sums[0..nb) in place; sums[nb] = grand total
 __global__ void __launch_bounds__(256)
-scan_sums(uint32_t* __restrict__ sums, uint32_t nb)
+scan_sums(uint32_t* __restrict__ sums, uint32_t nb, uint32_t* __restrict__ total_host)
 {
     __shared__ uint32_t s_wave[4];
     uint32_t carry = 0;
@@ -82,7 +82,10 @@ scan_sums(uint32_t* __restrict__ sums, uint32_t nb)
         if (i < nb) sums[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) sums[nb] = carry;
+    if (threadIdx.x == 0) {
+        sums[nb] = carry;
+        if (total_host) __hip_atomic_store(total_host, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // out[i] = (inclusive ? in[0..i] : in[0..i)) summed; optional gather: in[idx[i]] instead of in[i].
 // DIRECT: `sums` holds the RAW block sums (scan_sums was not run): every workgroup adds up the sums of the workgroups before it
@@ -90,7 +93,7 @@ scan_sums(uint32_t* __restrict__ sums, uint32_t nb)
 template <bool INCLUSIVE, bool GATHER, bool DIRECT>
 __global__ void __launch_bounds__(256)
 scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ sums,
-           uint32_t* __restrict__ out)
+           uint32_t* __restrict__ out, uint32_t* __restrict__ total_host)
 {
     __shared__ uint32_t s_wave[4];
     uint32_t before = 0;
@@ -116,7 +119,11 @@ scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, ui
     }
     uint32_t total;
     uint32_t run = before + block_exclusive_scan(s, &total, s_wave);
-    if (DIRECT && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) sums[gridDim.x] = before + total;
+    if (DIRECT && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sums[gridDim.x] = before + total;
+        // total_host (nullable): host-mapped pinned memory of the caller -- the grand total without a copy launch behind the scan
+        if (total_host) __hip_atomic_store(total_host, before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < n) out[base + k] = INCLUSIVE ? run + v[k] : run;
@@ -141,23 +148,32 @@ size_t scan_tmp_words(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK + 2; 
 
 // out = scan(in[idx]) if idx != nullptr else scan(in).  tmp: scan_tmp_words(n) u32.  The grand total is left in
 // tmp[nblocks] (device); total_dev_out (optional) receives its address.
-hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
-                           const uint32_t** total_dev_out, hipStream_t stream)
+// total_host (nullable): a DEVICE-VISIBLE address of host memory (hipHostGetDevicePointer) that receives the grand total as well.
+hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host)
 {
     const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (total_dev_out) *total_dev_out = tmp + nb;
-    if (n == 0) return hipMemsetAsync(tmp, 0, 2 * sizeof(uint32_t), stream);
+    if (n == 0) {
+        if (total_host) *total_host = 0;       // (host-mapped: a plain host store; nothing is queued for an empty input)
+        return hipMemsetAsync(tmp, 0, 2 * sizeof(uint32_t), stream);
+    }
     if (idx) hipLaunchKernelGGL(scan_block_sums_gather<true>, dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp);
     else hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, stream, in, (uint32_t)n, tmp);
     const bool direct = nb <= SCAN_DIRECT_MAX;         // few workgroups: each adds up its predecessors' sums itself, two launches
-    if (!direct) hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, tmp, nb);
+    if (!direct) hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, tmp, nb, total_host);
 #define GOF_SCAN_APPLY(INC, GA)                                                                                                        \
-    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out);   \
-         else hipLaunchKernelGGL((scan_apply<INC, GA, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out); } while (0)
+    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, total_host);   \
+         else hipLaunchKernelGGL((scan_apply<INC, GA, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, (uint32_t*)nullptr); } while (0)
     if (idx) { if (inclusive) GOF_SCAN_APPLY(true, true); else GOF_SCAN_APPLY(false, true); }
     else { if (inclusive) GOF_SCAN_APPLY(true, false); else GOF_SCAN_APPLY(false, false); }
 #undef GOF_SCAN_APPLY
     return hipGetLastError();
+}
+hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                           const uint32_t** total_dev_out, hipStream_t stream)
+{
+    return device_scan_u32_to_host(in, idx, out, n, inclusive, tmp, total_dev_out, stream, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------

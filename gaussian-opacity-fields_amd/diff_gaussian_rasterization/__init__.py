@@ -88,10 +88,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, opacities)
         ctx.mark_non_differentiable(radii)
+        # (autograd would otherwise hand the backward a zeros_like(radii) for the non-differentiable output: a 4 MB fill per step at 1M Gaussians)
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
+        if grad_out_color is None:          # (set_materialize_grads(False): the image took no part in the loss)
+            return (None,) * 10
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, opacities) = ctx.saved_tensors
@@ -145,10 +149,14 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest,
                               geomBuffer, binningBuffer, imgBuffer, opacities)
         ctx.mark_non_differentiable(radii)
+        # (autograd would otherwise hand the backward a zeros_like(radii) for the non-differentiable output: a 4 MB fill per step at 1M Gaussians)
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
+        if grad_out_color is None:          # (set_materialize_grads(False): the image took no part in the loss)
+            return (None,) * 10
         rs = ctx.raster_settings
         (means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest, geomBuffer, binningBuffer,
          imgBuffer, opacities) = ctx.saved_tensors

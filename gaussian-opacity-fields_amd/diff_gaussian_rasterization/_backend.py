@@ -51,7 +51,7 @@ def _load():
         f.argtypes = args
     lib.gof_forward_prepare.argtypes = [A, vp, sz, vp, sz, vp, C.POINTER(u32), vp]
     lib.gof_forward_render.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
-    lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp]
+    lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     lib.gof_forward_fused.restype = C.c_int
     lib.gof_backward.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp] + [vp] * 10 + [vp, sz, vp]
     lib.gof_backward_query.argtypes = [A, u32, sz, vp, sz, C.POINTER(u32), vp]
@@ -265,14 +265,15 @@ class NumRendered(int):
 _usage_free = []        # pinned host buffers (USAGE_WORDS int32 each) not attached to a live frame
 
 
-def _usage_in_flight(v, img):
-    """Enqueue, behind the forward just queued, the copy of the frame's pool counters into pinned host memory + an event behind it:
-    the backward of this frame reads them AFTER it has launched its kernels (optimistic pools, rasterize_gaussians_backward)."""
-    words = _usage_free.pop() if _usage_free else torch.empty(USAGE_WORDS, dtype=torch.int32).pin_memory()      # (pinning costs tens of microseconds: recycled)
-    _check(lib.gof_forward_usage_async(v.ref(), _ptr(img), img.numel(), C.c_void_p(words.data_ptr()), _stream()))
-    ev = torch.cuda.Event()
-    ev.record()
-    return words, ev
+_zeros = {}
+
+
+def _zero_scalar(dev):
+    """one zero per device, the storage of every stride-0 dL_dcov3D (a fill kernel per backward otherwise)"""
+    z = _zeros.get(dev)
+    if z is None:
+        z = _zeros[dev] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return z
 
 
 def _layout_count(num_rendered):
@@ -310,19 +311,29 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             pin = _pinned.get(str(v.device))
             if pin is None:
                 pin = _pinned[str(v.device)] = torch.zeros(4, dtype=torch.int32).pin_memory()
+            # the frame's pool counters go to pinned host memory at the end of the forward (stored by its last kernel: no copy launch),
+            # an event behind the call tells the backward when they are there (optimistic pools, rasterize_gaussians_backward)
+            no_counters = (FULL_MASK_POOL and FULL_BACKWARD_SCRATCH) or _exchange_starts_inside_backward()
+            words = None if no_counters else (_usage_free.pop() if _usage_free else torch.empty(USAGE_WORDS, dtype=torch.int32).pin_memory())      # (pinning costs tens of microseconds: recycled)
             rc = lib.gof_forward_fused(v.ref(), cap, _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
-                                       _ptr(radii), _ptr(out_color), C.c_void_p(pin.data_ptr()), _stream())
+                                       _ptr(radii), _ptr(out_color), C.c_void_p(pin.data_ptr()), None if words is None else C.c_void_p(words.data_ptr()), _stream())
+            usage = None
+            if words is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                usage = (words, ev)
             if rc == 0:
                 true_r = int(pin[0].item()) & 0xFFFFFFFF
                 if _round_capacity(true_r) > cap:
                     _capacity[shape_key] = _round_capacity(true_r)        # growing scene: stay ahead of it
                 _stats["last_num_rendered"] = true_r
-                no_counters = (FULL_MASK_POOL and FULL_BACKWARD_SCRATCH) or _exchange_starts_inside_backward()
-                return NumRendered(true_r, cap, None if no_counters else _usage_in_flight(v, img)), out_color, radii, geom, binning, img
+                return NumRendered(true_r, cap, usage), out_color, radii, geom, binning, img
             if rc != GOF_E_CAPACITY:
                 _check(rc)
             _stats["fused_redone_frames"] += 1
-            del geom, img, binning, radii                                     # too small: redo the frame below with the exact count
+            if words is not None:
+                _usage_free.append(words)
+            del geom, img, binning, radii, usage                                     # too small: redo the frame below with the exact count
         geom, img, binning, radii, rendered = _prepare_and_bin(v)
         _check(lib.gof_forward_render(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                       _ptr(img), img.numel(), _ptr(out_color), _stream()))
@@ -371,7 +382,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_v2g = acc[:10 * P].view(P, 10)
     g_means2D = acc[10 * P:13 * P].view(P, 3); g_colors = acc[13 * P:16 * P].view(P, 3)
     want_cov3D = isinstance(cov3D_precomp, torch.Tensor) and cov3D_precomp.numel() > 0
-    g_cov3D = torch.empty((P, 6), **f) if want_cov3D else torch.zeros(1, **f).expand(P, 6)
+    g_cov3D = torch.empty((P, 6), **f) if want_cov3D else _zero_scalar(dev).expand(P, 6)
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
         with torch.cuda.device(dev):

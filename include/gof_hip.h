@@ -151,14 +151,18 @@ int gof_forward_render(const GofRasterArgs* args,
  * waits for that copy only (~0.3 ms into the call, the rest already queued).  Returns GOF_E_CAPACITY -- with nothing written out
  * of bounds and *num_rendered_pinned_host = the required count -- when the capacity was too small: redo the frame with
  * gof_forward_prepare / gof_forward_render.  The backward and the introspection calls take `capacity` as their num_rendered
- * (it fixes the workspace layout).  Not for P == 0, prefiltered or debug calls. */
+ * (it fixes the workspace layout).  Not for P == 0, prefiltered or debug calls.
+ * usage_pinned_host (nullable): GOF_USAGE_WORDS uint32 of PINNED host memory that receive the frame's raw pool counters at the end of
+ * the forward -- what gof_forward_usage_async would copy there; the caller records its own event behind the call and hands the words
+ * to gof_usage_decode after waiting for it.  Both host buffers are written by the producing kernels themselves when the memory is
+ * device-mapped (hipHostMalloc / torch's pin_memory()): no copy launches in the stream; otherwise by hipMemcpyAsync. */
 int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
                       void* geom_ws, size_t geom_bytes, void* binning_ws, size_t binning_bytes,
                       void* image_ws, size_t image_bytes,
-                      int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, void* stream);
+                      int32_t* radii, float* out_color, uint32_t* num_rendered_pinned_host, uint32_t* usage_pinned_host, void* stream);
 
 /* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
-/* Scratch the backward needs besides the outputs: P offsets, per tile instance (num_rendered of them) one slot word, and a POOL of
+/* Scratch the backward needs besides the outputs: per tile instance (num_rendered of them) one slot word, and a POOL of
  * 68-byte partial gradient records -- one per (tile, Gaussian) instance the per-pixel backward actually stages -- which the
  * per-Gaussian gather adds up (no atomics).  num_rendered = the value the backward is called with.
  *   gof_backward_scratch_bytes(P, R):                a pool of R records: always enough (every instance staged).

@@ -208,12 +208,19 @@ class EmuScene:
         self.radii = np.zeros(self.P, np.int32)
         self.color = np.zeros((9, self.H, self.W), np.float32)
         pinned = np.zeros(4, np.uint32)
+        self.usage_words = np.full(66, 0xDEADBEEF, np.uint32)      # GOF_USAGE_WORDS: the frame's raw pool counters, stored by the forward's last kernel
         lib.gof_set_forward_exact(1 if self.exact else 0)
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
         rc = lib.gof_forward_fused(C.byref(self.args), int(capacity), _p(self.geom), self.geom.size, _p(self.binning), nb, _p(self.img), self.img.size,
-                                   _p(self.radii), _p(self.color), _p(pinned), None)
+                                   _p(self.radii), _p(self.color), _p(pinned), _p(self.usage_words), None)
         self.R = int(capacity)           # the layout size: what fetch() / backward() have to be given on this path
         return rc, int(pinned[0]), bool((raw[nb:] == 0xA5).all())
+
+    def usage_decoded(self):
+        """gof_usage_decode of the words the fused forward left: (staged entries, mask sub-chunks requested, held)"""
+        q = (C.c_uint32 * 3)()
+        self._check(self.lib.gof_usage_decode(_p(self.usage_words), self.R, self.W, self.H, C.c_size_t(self.binning.size), q))
+        return int(q[0]), int(q[1]), int(q[2])
 
     def integrate_view(self):
         """the Gaussian half of the opacity-field query (binning + pixel pass), kept on the object: -> base image [9,H,W]"""

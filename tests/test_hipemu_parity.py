@@ -192,6 +192,8 @@ def test_emulated_sync_free_forward_respects_its_capacity():
         assert np.array_equal(f.fetch("point_list")[:R], list_two_stage)
         g = f.backward(np.ones_like(want))                  # the backward finds its arrays through the capacity's layout
         assert all(np.isfinite(v).all() for v in g.values())
+        # the frame's counters, stored into the caller's host words by the forward's last kernel, decode to what the synchronising query reports
+        assert f.usage_decoded() == (f.staged, f.masks_requested, f.masks_held) and f.staged > 0
     for cap in (R - 1, R // 2, 64):
         f = E.EmuScene(sc)
         rc, count, intact = f.forward_fused(cap)
