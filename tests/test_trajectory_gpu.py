@@ -87,12 +87,16 @@ def test_training_trajectory_matches_the_references_own_kernels(tmp_path_factory
     # the whole curve.  The reference's atomics make two runs of the SAME kernels diverge once densification decisions flip: over four
     # reference runs on two GPU boxes the final PSNR ranged 44.79 ... 45.14 dB and the final count 6811 ... 6878 Gaussians
     # (profiles/r04_trajectory_parity.json); the product -- deterministic: 45.355 dB, 6895 Gaussians on both boxes -- is held to the
-    # mean of this run's two reference curves within 0.6 dB + their spread, and 3 % + their spread in the number of Gaussians.
+    # mean of this run's two reference curves within 0.6 dB + their spread, and 3 % + their spread in the number of Gaussians
+    # (over five reference-run pairs on four boxes by now: final PSNR 44.79 ... 45.14 dB).
     for m in MARKS[1:]:
         spread_psnr = abs(r[m]["psnr"] - r2[m]["psnr"])
         mean_psnr = 0.5 * (r[m]["psnr"] + r2[m]["psnr"])
         mean_n = 0.5 * (r[m]["gaussians"] + r2[m]["gaussians"])
         spread_n = abs(r[m]["gaussians"] - r2[m]["gaussians"]) / mean_n
         assert abs(p[m]["psnr"] - mean_psnr) <= (0.1 if m <= 250 else 0.6) + spread_psnr, (m, p[m], r[m], r2[m])
-        assert abs(p[m]["gaussians"] - mean_n) / mean_n <= (0.0 if m <= 250 else 0.03) + spread_n, (m, p[m], r[m], r2[m])
+        # (m <= 250: one pruning pass behind the start -- 1 %: on a fourth box both reference runs kept 325 Gaussians where every
+        # other run, reference or product, kept 326; the count at 100 is the initial 6000 on every side)
+        assert abs(p[m]["gaussians"] - mean_n) / mean_n <= (0.01 if m <= 250 else 0.03) + spread_n, (m, p[m], r[m], r2[m])
+    assert p[100]["gaussians"] == r[100]["gaussians"] == r2[100]["gaussians"]
     assert p[ITERS]["psnr"] > p[1]["psnr"] + 6.0 and r[ITERS]["psnr"] > r[1]["psnr"] + 6.0
