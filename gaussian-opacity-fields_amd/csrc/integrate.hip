@@ -39,8 +39,9 @@ namespace gof {
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build) of the opacity-field query's POINT pass: [0] (point, entry) pairs walked
 // (set bits of the pixel's contributor mask), [1] skipped by the front-depth test, [2] evaluated, [3] accepted (alpha >= 1/255),
-// [4] wave trips of the bit loop, [5] lane-trips with a bit to process; PIXEL pass: [6] candidates popped, [7] of them used by a sub-ray
-__device__ unsigned long long g_int_stats[8];
+// [4] wave trips of the bit loop, [5] lane-trips with a bit to process; PIXEL pass: [6] candidates popped, [7] of them used by a sub-ray,
+// [8] wave trips of the candidate loop (the longest lane's, per mask word), [9] (wave, entry) iterations of the cull scan
+__device__ unsigned long long g_int_stats[16];
 #define ISTAT_ADD(i, v) atomicAdd(&g_int_stats[i], (unsigned long long)(v))
 #else
 #define ISTAT_ADD(i, v)
@@ -152,6 +153,7 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                 const int bb = __builtin_ctzll(m);
                 m &= m - 1ull;
                 const int j = w * 32 + bb;
+                if (lane == 0) ISTAT_ADD(9, 1);                                          // [9] (wave, touching entry) iterations of the cull scan
                 // conservative footprint box: integer-rounded bounds {ceil(lo), floor(hi)}, exact for integer pixel positions; the
                 // corner sub-rays sit at p +- 0.5, and p + 0.5 >= lo is implied by p + 1 >= ceil(lo): widened by one full pixel.
                 const float4 bx = s_box[j];
@@ -182,7 +184,13 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
         for (int w = 0; w < 8; w++) {
             uint32_t cand = s_used[w][tid];
             uint32_t word = 0;
+#ifdef GOF_STATS
+            int my_trips = 0;
+#endif
             while (cand && !done) {
+#ifdef GOF_STATS
+                my_trips++;
+#endif
                 const int bit = __ffs((int)cand) - 1;
                 cand &= cand - 1;
                 const int j = w * 32 + bit;
@@ -204,9 +212,13 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                     // one IEEE division: -BB/(2*AA) == -(BB/AA)/2 and BB/4 are exact power-of-two scalings (forward.cu:927-931)
                     const float q = BB / AA;
                     const float t = -q * 0.5f;
-                    if ((double)t <= GOF_NEAR_PLANE) continue;
+                    // (double)t <= NEAR_PLANE (forward.cu:933) as an fp32 compare: 0.2f = 0x3E4CCCCD lies ABOVE the double 0.2, so "t <= 0.2 in
+                    // double" is "t < 0.2f" for every float t (NaN: false both ways) -- the forward blend's form (gof_common.h)
+                    if (t < 0.2f) continue;
                     const double min_value = (double)(-q) * (double)(BB * 0.25f) + (double)CC;
-                    float power = (float)(-0.5 * min_value);
+                    // (float)(-0.5 * min_value): the scaling by a power of two commutes with the rounding (a subnormal result, where it
+                    // does not, has exp() == 1 either way): one fp64 multiply less per sub-ray
+                    float power = -0.5f * (float)min_value;
                     if (power > 0.0f) power = 0.0f;
                     if (power < log_thr) continue;                           // w * exp(power) < 0.999/255: below the threshold for sure
                     const float alpha = fminf(0.99f, wgt * gexpf(power));
@@ -245,6 +257,10 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                 }
             }
             s_used[w][tid] = word;
+#ifdef GOF_STATS
+            for (int o = 32; o > 0; o >>= 1) my_trips = max(my_trips, __shfl_xor(my_trips, o));      // [8] wave trips of the candidate loop = the longest lane's
+            if (lane == 0) ISTAT_ADD(8, my_trips);
+#endif
         }
         // contributor words of this batch -> binning workspace (only the words the list covers)
         const int nwords = (n + 31) >> 5;
@@ -477,11 +493,11 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
 }
 
 #ifdef GOF_STATS
-extern "C" int gof_debug_int_stats(unsigned long long* out8, int reset)
+extern "C" int gof_debug_int_stats(unsigned long long* out16, int reset)
 {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_int_stats), sizeof(g_int_stats));
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_int_stats), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_int_stats), sizeof(g_int_stats));
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_int_stats), z, sizeof(z)); }
     return 0;
 }
 #endif
