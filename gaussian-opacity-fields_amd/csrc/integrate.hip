@@ -40,7 +40,9 @@ namespace gof {
 // developer-only instrumentation (never in the shipped build) of the opacity-field query's POINT pass: [0] (point, entry) pairs walked
 // (set bits of the pixel's contributor mask), [1] skipped by the front-depth test, [2] evaluated, [3] accepted (alpha >= 1/255),
 // [4] wave trips of the bit loop, [5] lane-trips with a bit to process; PIXEL pass: [6] candidates popped, [7] of them used by a sub-ray,
-// [8] wave trips of the candidate loop (the longest lane's, per mask word), [9] (wave, entry) iterations of the cull scan
+// [8] wave trips of the candidate loop (the longest lane's, per mask word), [9] (wave, entry) iterations of the cull scan,
+// [10] the trips lanes advancing on their own over a batch's 8 words would take (host counts, 400k Gaussians @ 640x400: 0.83 of [8];
+// lane utilisation 0.45 -> 0.54 -- the rest is pixels that have finished while their wave has not)
 __device__ unsigned long long g_int_stats[16];
 #define ISTAT_ADD(i, v) atomicAdd(&g_int_stats[i], (unsigned long long)(v))
 #else
@@ -181,6 +183,9 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
         // the wave on it, and 51 % of the evaluations take it.  profiles/HISTORY.md, round 4.)
         // (word by word, the wave moving on together: letting every lane advance over the 8 mask words on its own -- the forward
         // blend's scheme -- was measured SLOWER here, 8.17 -> 8.57 ms at S1M and 15.3 -> 16.6 ms at S5M, as in integrate_points)
+#ifdef GOF_STATS
+        int my_batch_trips = 0;
+#endif
         for (int w = 0; w < 8; w++) {
             uint32_t cand = s_used[w][tid];
             uint32_t word = 0;
@@ -258,10 +263,15 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
             }
             s_used[w][tid] = word;
 #ifdef GOF_STATS
+            my_batch_trips += my_trips;
             for (int o = 32; o > 0; o >>= 1) my_trips = max(my_trips, __shfl_xor(my_trips, o));      // [8] wave trips of the candidate loop = the longest lane's
             if (lane == 0) ISTAT_ADD(8, my_trips);
 #endif
         }
+#ifdef GOF_STATS
+        for (int o = 32; o > 0; o >>= 1) my_batch_trips = max(my_batch_trips, __shfl_xor(my_batch_trips, o));   // [10] what lanes advancing on their own over the batch's 8 words would take
+        if (lane == 0) ISTAT_ADD(10, my_batch_trips);
+#endif
         // contributor words of this batch -> binning workspace (only the words the list covers)
         const int nwords = (n + 31) >> 5;
         for (int w = 0; w < nwords; w++)
