@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _latest():
-    files = glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_bench_s1m_v*.json"))
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_bench_s1m_v*.json")) if re.search(r"_v(\d+)\.json$", f)]     # (a file named otherwise is not a bench line of the series)
     return max(files, key=lambda f: (int(re.search(r"r(\d+)_bench", f).group(1)), int(re.search(r"_v(\d+)\.json$", f).group(1))))
 
 
