@@ -723,7 +723,7 @@ def debug_fetch(name, view, num_rendered, geom, binning, img):
 
 def set_forward_exact(on):
     """Verification mode of the forward blend (gof_set_forward_exact, include/gof_hip.h): True = every (pixel, Gaussian) pair in the
-    reference's own arithmetic (every output bit the oracle's); False (default) = fp32 values with certified decisions.  Process-wide;
+    reference's own arithmetic (every output bit the oracle's); False (default) = the same arithmetic without its two fp64 divisions per pair (pair_nodiv_cc: decisions and channels 0-7 identical on every scene tested).  Process-wide;
     returns the previous setting."""
     return bool(lib.gof_set_forward_exact(1 if on else 0))
 

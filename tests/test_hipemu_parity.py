@@ -38,7 +38,7 @@ MEDIUM = ["lego10k", "posed_ragged", "posed_clustered150k"]
 
 
 def _pair(sc, **over):
-    """oracle + the emulated library in BOTH forward modes: `e` = the default mode (fp32 values, certified decisions: what ships; the
+    """oracle + the emulated library in BOTH forward modes: `e` = the default mode (the exact arithmetic without its fp64 divisions, pair_nodiv_cc: what ships; the
     integer arrays and the backward are checked on it), `e.exact` = the verification mode, whose image `pc` is held to the oracle's
     bits; the two modes are compared on the way (same decisions, floats within gpu_common.FAST_MODE_TOL)."""
     o = ob.OracleScene(sc, **over)

@@ -80,7 +80,7 @@ def _forward_pair(sc, **over):
     o = ob.OracleScene(sc, **{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in over.items()
                               if k in ("colors_precomp", "cov3D_precomp", "view2gaussian_precomp")})
     oc, orad = o.forward()
-    # the product in both forward modes: res = the DEFAULT mode (fp32 values, certified decisions: what ships, what the integer
+    # the product in both forward modes: res = the DEFAULT mode (the exact arithmetic without its fp64 divisions, pair_nodiv_cc: what ships, what the integer
     # arrays and the backward are checked on), res["exact"] = the verification mode (what the image's bits are held to the oracle on)
     sd = to_dev(sc)
     with forward_exact():
