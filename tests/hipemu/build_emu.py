@@ -38,7 +38,17 @@ def lib_path(tag=""):
 
 
 def build(asan=False, force=False, extra_flags=(), tag="", verbose=False):
+    """One builder at a time per output (an exclusive file lock): pytest-xdist workers that find the stamp stale would otherwise compile
+    into the same object files and link / load a half-written library (seen as one spuriously failing test per `-n 8` run after a
+    kernel edit)."""
+    import fcntl
     os.makedirs(os.path.join(OUT, "obj" + tag), exist_ok=True)
+    with open(os.path.join(OUT, "lock%s_%s" % (tag, "asan" if asan else "plain")), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(asan, force, extra_flags, tag, verbose)
+
+
+def _build_locked(asan, force, extra_flags, tag, verbose):
     flags = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-mfma", "-mavx2", "-fno-strict-aliasing", "-pthread",
              "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-unused-value", "-Wno-pass-failed",
              "-I", os.path.join(HERE, "include"), "-I", CSRC, "-DGOF_HIPEMU=1"] + list(extra_flags)
@@ -86,8 +96,9 @@ def build(asan=False, force=False, extra_flags=(), tag="", verbose=False):
             sys.stderr.write("---- %s (warnings) ----\n%s\n" % (f, log[-1500:]))
     if failed:
         raise RuntimeError("hipemu build failed")
-    link = [CXX, "-shared", "-pthread", "-o", out] + objs + (["-fsanitize=address,undefined"] if asan else [])
+    link = [CXX, "-shared", "-pthread", "-o", out + ".tmp"] + objs + (["-fsanitize=address,undefined"] if asan else [])
     subprocess.check_call(link)
+    os.replace(out + ".tmp", out)          # a process that already maps the old library keeps its inode
     open(stamp, "w").write(h.hexdigest())
     return out
 
