@@ -82,14 +82,15 @@ __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* g
                                  uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                  uint32_t* tile_queue, uint32_t* tile_cost);
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
-                                 const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H, float focal_x, float focal_y,
-                                 const float2* pt_xy, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
+                                 const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H,
+                                 const uint32_t* pt_key, const float2* pt_ray, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
                                  float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, int acc_min, uint32_t gx, uint32_t ntiles,
                                  const uint32_t* tile_order, uint32_t* tile_queue);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
                              const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
-__global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float4* pos, float2* pt_xy, float* pt_depth);
+__global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float4* pos, float2* pt_ray, float* pt_depth, int W, int H,
+                                     float focal_x, float focal_y);
 
 // ---- error text --------------------------------------------------------------------------------------
 static thread_local std::string g_error;
@@ -912,7 +913,8 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
         hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr,
                            radix_sort_error_flag(pb.sort_tmp, (size_t)NI, (int)higher_msb(d.ntiles) + 8), async_status_word());
         GOF_LAUNCH_CHECK(stream, a->debug);
-        hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.pos, pb.pt_xy, pb.pt_depth);
+        hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.pos, pb.pt_xy, pb.pt_depth, a->W, a->H,
+                           d.focal_x, d.focal_y);
         GOF_LAUNCH_CHECK(stream, a->debug);
     } }
     // dispatch order of the point pass: #points of the tile x what its pixels walked (tile_cost, left by integrate_pixels), heaviest first
@@ -920,7 +922,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     GOF_LAUNCH_CHECK(stream, a->debug);
     GOF_PROFILE("integrate_points", stream);
     hipLaunchKernelGGL(integrate_points, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, im.point_ranges, b.vals, pb.vals, rec_ptr, zfront_ptr, zstride, b.cmask, a->W, a->H, d.focal_x, d.focal_y, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
+                       im.ranges, im.point_ranges, b.vals, pb.vals, rec_ptr, zfront_ptr, zstride, b.cmask, a->W, a->H, pb.tiles, pb.pt_xy, pb.pt_depth, pb.pt_T, pb.pt_acc,
                        base_color, out_color, out_alpha_integrated, out_color_integrated, im.n_contrib, acc_min ? 1 : 0, d.gx, d.ntiles, pb.pt_order, pb.pt_queue);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;

@@ -174,18 +174,22 @@ point_keys(int PN, const float4* __restrict__ pos, const uint32_t* __restrict__ 
     }
 }
 
-// per-point data in LIST order (tile-major, depth within the tile): the point pass of integrate reads it once per staged batch,
+// per-point data in LIST order (tile-major, pixel by pixel within the tile): the point pass of integrate reads it once per staged batch,
 // a gather by point id there would touch a different DRAM sector per point per batch.  Position and depth of a point are one
-// 16-byte line (PointWs::pos): ONE random sector per point here, where two arrays cost two (this gather was half of bin_points)
+// 16-byte line (PointWs::pos): ONE random sector per point here, where two arrays cost two (this gather was half of bin_points).
+// What is stored is the point's RAY ((x - W/2) / focal_x, (y - H/2) / focal_y in double, rounded to fp32: forward.cu:1108-1109), not
+// its pixel position (BinWs::pt_xy keeps its name): integrate_points needs the ray in every staged batch of the tile -- two fp64
+// divisions per point and batch, ~25 batches per tile at the config-5 shape -- and the pixel of the tile only as the low byte of the
+// point's sorted key (point_keys), which lies in list order already.
 __global__ void __launch_bounds__(256)
 gather_sorted_points(uint32_t NI, const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ pos,
-                     float2* __restrict__ pt_xy, float* __restrict__ pt_depth)
+                     float2* __restrict__ pt_ray, float* __restrict__ pt_depth, int W, int H, float focal_x, float focal_y)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NI) return;
     const uint32_t id = sorted_ids[i];
     const float4 p = pos[id];
-    pt_xy[i] = make_float2(p.x, p.y);
+    pt_ray[i] = make_float2((float)(((double)p.x - W / 2.) / (double)focal_x), (float)(((double)p.y - H / 2.) / (double)focal_y));
     pt_depth[i] = p.z;
 }
 

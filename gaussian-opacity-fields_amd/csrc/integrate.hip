@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256)
 integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restrict__ point_ranges,
                  const uint32_t* __restrict__ gaussian_list, const uint32_t* __restrict__ point_list,
                  const SplatRec* __restrict__ rec, const float* __restrict__ zfront, int zstride, const uint32_t* __restrict__ cmask, int W, int H,
-                 float focal_x, float focal_y, const float2* __restrict__ pt_xy, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
+                 const uint32_t* __restrict__ pt_key, const float2* __restrict__ pt_ray, const float* __restrict__ pt_depth, float* __restrict__ pt_T,
                  float* __restrict__ pt_acc, const float* __restrict__ base_color, float* __restrict__ out_color, float* __restrict__ out_alpha_integrated,
                  float* __restrict__ out_color_integrated, const uint32_t* __restrict__ n_contrib, int acc_min, uint32_t gx, uint32_t ntiles,
                  const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue)
@@ -389,14 +389,16 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
         for (uint32_t base = prange.x; base < prange.y; base += TILE_PIX) {
             const uint32_t pi = base + tid;
             if (pi >= prange.y) continue;
-            const float2 xy = pt_xy[pi];               // list order: coalesced, L2-resident across the batches of the tile
+            // list order: coalesced, L2-resident across the batches of the tile.  The ray (forward.cu:1108-1109, two fp64 divisions)
+            // was formed once per call by gather_sorted_points, not here once per batch; the point's pixel of the tile is the low
+            // byte of its sorted key (point_keys: tile_thread of the pixel it projects to)
+            const float2 ray = pt_ray[pi];
             const float ray_depth = pt_depth[pi];
-            const uint32_t lp = tile_thread((uint32_t)xy.x - tx * TILE_X, (uint32_t)xy.y - ty * TILE_Y);
+            const uint32_t lp = pt_key[pi] & 0xFFu;
             float T, acc;
             if (b == 0) { T = 1.f; acc = 0.f; atomicAdd(&s_cnt[lp], 1u); }
             else { T = pt_T[pi]; acc = pt_acc[pi]; }
-            const float rx = (float)(((double)xy.x - W / 2.) / (double)focal_x);
-            const float ry = (float)(((double)xy.y - H / 2.) / (double)focal_y);
+            const float rx = ray.x, ry = ray.y;
             // the set bits of the pixel's 8 mask words, the wave moving from word to word together (a flat per-lane loop over all
             // words, lanes advancing independently, measured slower: 12.8 vs 12.3 ms at S5M with 45M points)
             int w = 0;
@@ -450,8 +452,9 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
                 }
                 if (take) out_alpha_integrated[pid] = acc;
                 if (take_color && out_color_integrated) {
-                    const uint32_t ppx = (uint32_t)xy.x, ppy = (uint32_t)xy.y;
-                    const size_t ppix = (size_t)W * ppy + ppx;
+                    uint32_t plx, ply;
+                    tile_pixel(lp, plx, ply);
+                    const size_t ppix = (size_t)W * (ty * TILE_Y + ply) + (tx * TILE_X + plx);      // the pixel the point projects to
                     out_color_integrated[3 * (size_t)pid + 0] = base_color[0 * HW + ppix];
                     out_color_integrated[3 * (size_t)pid + 1] = base_color[1 * HW + ppix];
                     out_color_integrated[3 * (size_t)pid + 2] = base_color[2 * HW + ppix];
@@ -488,10 +491,7 @@ integrate_points(const uint2* __restrict__ gaussian_ranges, const uint2* __restr
         const unsigned long long top = s_deepest;
         for (uint32_t pi = prange.x + tid; pi < prange.y; pi += TILE_PIX) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(pt_depth[pi]) << 32) | point_list[pi];
-            if (key == top) {
-                const float2 lxy = pt_xy[pi];
-                s_deepest_lp = tile_thread((uint32_t)lxy.x - tx * TILE_X, (uint32_t)lxy.y - ty * TILE_Y);
-            }
+            if (key == top) s_deepest_lp = pt_key[pi] & 0xFFu;
         }
         __syncthreads();
     }
