@@ -50,7 +50,7 @@ const uint32_t* radix_sort_error_flag(const uint32_t* tmp, size_t n, int end_bit
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 int radix_passes(int end_bit);
-uint32_t emit_instances_grid(uint32_t slots);
+uint32_t emit_instances_grid(uint32_t slots, int P);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
                                uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first);
 __global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
@@ -348,7 +348,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
         { GOF_PROFILE("emit_instances", stream);
         // one wave per EMIT_SLOTS output slots (R: the instance count, or the workspace's capacity when only the device knows the count)
-        hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R)), dim3(256), 0, stream, a->P, g.dval_a,
+        hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R, a->P)), dim3(256), 0, stream, a->P, g.dval_a,
                            g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);

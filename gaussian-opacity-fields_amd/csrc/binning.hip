@@ -81,7 +81,13 @@ gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restr
 #endif
 constexpr uint32_t EMIT_SLOTS = GOF_EMIT_SLOTS;       // output slots per wave
 // workgroups of an emit_instances launch that may write up to `slots` instances (api.hip sizes the grid with it)
-uint32_t emit_instances_grid(uint32_t slots) { return (uint32_t)(((size_t)slots + 4 * EMIT_SLOTS - 1) / (4 * EMIT_SLOTS)); }
+// (and never fewer than one thread per Gaussian: the threads also store inst_first, one Gaussian each -- a view that sees few of many
+// Gaussians would otherwise leave that loop to a handful of workgroups)
+uint32_t emit_instances_grid(uint32_t slots, int P)
+{
+    const size_t by_slots = ((size_t)slots + 4 * EMIT_SLOTS - 1) / (4 * EMIT_SLOTS), by_gaussians = ((size_t)P + 255) / 256;
+    return (uint32_t)(by_slots > by_gaussians ? by_slots : by_gaussians);
+}
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
                const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity,
