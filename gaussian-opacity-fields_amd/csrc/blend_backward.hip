@@ -314,6 +314,10 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
 #endif
 
                 float g[NGRAD];
+                // (Measured and dropped, round 4: EVERY lane running the gradient block with alpha = G = 0 and harmless stand-ins for a
+                // lane without a contribution -- T and the accumulators stay, all 16 values come out as zeros -- instead of 16 v_mov and
+                // the divergent branch: 11 VALU instructions fewer per trip (ISA count 598 -> 572 cycles), blend_backward 1.065 vs
+                // 1.067 ms at S1M, 1.379 vs 1.364 ms clustered: no difference.  profiles/r04_ab_call5_*.txt)
 #pragma unroll
                 for (int k = 0; k < NGRAD; k++) g[k] = 0.f;
                 if (contrib) {

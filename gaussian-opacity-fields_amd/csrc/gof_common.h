@@ -246,10 +246,13 @@ __device__ __forceinline__ uint32_t pop_tile(const uint32_t* __restrict__ order,
 // Deterministic fp32 exp (Cephes scheme): only IEEE mul / fma / rint / ldexp, <= 1 ulp on
 // [-87, 88].  The oracle evaluates the identical sequence, which makes per-pair alpha
 // bit-identical between host and device.
+// NONPOS: the caller guarantees x <= 0 or NaN (the blend's power, clamped at 0 in front of the call): the upper clamp can never
+// fire and is left out (a compare and a select per pair); every result bit is that of the general form.
+template <bool NONPOS = false>
 __device__ __forceinline__ float gexpf(float x)
 {
     x = (x < -87.0f) ? -87.0f : x;     // written as compares so NaN propagates exactly as on the host
-    x = (x > 88.0f) ? 88.0f : x;
+    if (!NONPOS) x = (x > 88.0f) ? 88.0f : x;
     const float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -449,7 +452,7 @@ __device__ __forceinline__ void pair_exact_cc(float CC, float w, PairEval& p)
     const double min_value = (-q) * (BB * 0.25) + (double)CC;
     float power = (float)(-0.5 * min_value);
     if (power > 0.0f) power = 0.0f;
-    p.G = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gexpf(power);
+    p.G = HW_EXP ? __builtin_amdgcn_exp2f(power * 1.44269504088896341f) : gexpf<true>(power);
     p.alpha = fminf(0.99f, w * p.G);
     if (p.alpha < 1.0f / 255.0f) p.skip = true;
 }
@@ -507,7 +510,7 @@ __device__ __forceinline__ void pair_nodiv_cc(float CC, float w, PairEval& p)
     const double min_value = (-q) * (BB * 0.25) + (double)CC;
     float power = (float)(-0.5 * min_value);
     if (power > 0.0f) power = 0.0f;
-    p.G = gexpf(power);
+    p.G = gexpf<true>(power);
     p.alpha = fminf(0.99f, w * p.G);
     if (p.alpha < 1.0f / 255.0f) p.skip = true;
 }

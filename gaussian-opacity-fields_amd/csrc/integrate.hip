@@ -226,7 +226,7 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
                     float power = -0.5f * (float)min_value;
                     if (power > 0.0f) power = 0.0f;
                     if (power < log_thr) continue;                           // w * exp(power) < 0.999/255: below the threshold for sure
-                    const float alpha = fminf(0.99f, wgt * gexpf(power));
+                    const float alpha = fminf(0.99f, wgt * gexpf<true>(power));      // (power <= 0: clamped above)
                     if (alpha < 1.0f / 255.0f) continue;
                     const float test_T = cT[c] * (1 - alpha);
                     if (test_T < 0.0001f) continue;
