@@ -53,7 +53,7 @@ constexpr int NGRAD = 16;   // colour 3, mean2D 3, opacity 1, view2gaussian 0..8
 #define GOF_BW_BATCH 64
 #endif
 constexpr int BATCH = GOF_BW_BATCH;
-static_assert(BATCH == 64 || BATCH == 128, "BATCH must be 64 or 128");
+static_assert(BATCH == 32 || BATCH == 64 || BATCH == 128, "BATCH must be 32, 64 or 128");
 // How the 16 per-pair values are summed over the wave (GOF_BW_REDUCE):
 //   0  in registers: transposed reduction with v_permlane32/16_swap, DPP quad levels and row rotations (rounds 2-3; ~75 VALU
 //      instructions of which 12 lane-group swaps at ~12 cycles: ~300 of the trip's 749 SIMD-cycles);
@@ -172,7 +172,15 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     //   q3 = {CC, w | r, g}, q4 = {b, - | mean2D.x, mean2D.y}, q5 = {conic.x, conic.z | conic.y, conic.y}
     __shared__ f4 s_rec[6][BATCH];
     __shared__ uint32_t s_inst[BATCH];                 // instance index of the staged (tile, Gaussian) pair
-    __shared__ float s_slab[4][NGRAD][BATCH];          // per wave: the wave totals of the entries it visited in this batch
+    // per wave: the wave totals of the entries it visited in this batch.  Rows padded by GOF_BW_SLAB_PAD words: the 8 lanes that store a
+    // visit's totals write 8 ROWS at the same column j -- with a row of exactly 64 words they all hit bank j (an 8-way conflict on both
+    // stores of every visit: half of this kernel's bank-conflict cycles).  Measured: 1.068 -> 1.064 ms at S1M, 1.370 -> 1.360 ms clustered.
+    // (Also measured, profiles/r04_ab_call6_*.txt: 32 staged entries per batch -- 20 KB of LDS, 79 VGPRs, SIX waves per SIMD -- is
+    // slower, 1.090 / 1.418 ms: the batch's barriers and staging cost more than the sixth wave hides.)
+#ifndef GOF_BW_SLAB_PAD
+#define GOF_BW_SLAB_PAD 1
+#endif
+    __shared__ float s_slab[4][NGRAD][BATCH + GOF_BW_SLAB_PAD];
     __shared__ uint32_t s_vis[4][BATCH / 32];           // per wave: which entries those are
     __shared__ uint32_t s_max_last;
 #if GOF_BW_REDUCE == 2
