@@ -33,7 +33,7 @@ def _no_write_past_a_workspace():
 
 
 FAST = ["tiny", "one", "small_ks0", "small_ks01", "long_lists", "stress_box", "posed_tiny", "posed_small_ks01", "posed_long_lists",
-        "posed_stress_box", "posed_mod2", "posed_mod05_ks01"]
+        "posed_stress_box", "posed_mod2", "posed_mod05_ks01", "emit_edges"]
 MEDIUM = ["lego10k", "posed_ragged", "posed_clustered150k"]
 
 

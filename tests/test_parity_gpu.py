@@ -123,8 +123,29 @@ SCENES = {
     "wide4k": lambda: S.scene_frustum(60_000, W=3840, H=2176, focal=2900.0, seed=6, sigma_px=4.0, pose_seed=14),
     "posed_mod2": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=9, sigma_px=1.5, pose_seed=7), "scale_modifier": 2.0},
     "posed_mod05_ks01": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=10, sigma_px=5.0, kernel_size=0.1, pose_seed=8), "scale_modifier": 0.5},
+    # round 4, late: emit_instances divides the OUTPUT slots among the waves (1024 per wave)
+    "emit_edges": lambda: emit_edges_scene(),
 }
 POSED = [k for k in SCENES if k.startswith("posed_")]
+
+
+def emit_edges_scene():
+    """What a wave of emit_instances (one per 1024 instance slots) can meet at the start, inside and at the end of its range: runs of
+    more than 64 depth-consecutive Gaussians WITHOUT an instance (behind the camera / outside the frustum), three image-filling
+    splats next to each other in depth (6700 tiles each: one Gaussian's instances span several range boundaries, and ranges hold
+    nothing but a part of one Gaussian), ordinary small splats in between, and the last Gaussian of the depth order without instances."""
+    sc = S.scene_frustum(1500, W=1600, H=1063, focal=1200.0, seed=21, sigma_px=2.0)
+    m, sca = sc["means3D"], sc["scales"]
+    m[0:200, 2] = -1.0                                        # behind the camera: culled, no instances (culled Gaussians sort to the
+    m[700:770, 0] = 1e3                                       # front of the depth order: a run of 270 without instances there)
+    for k, i in enumerate((400, 401, 402)):                   # image-filling splats (6700 tiles = 6.5 ranges each) at depth 5.00 / 5.01 / 5.02
+        m[i] = (0.0, 0.0, 5.0 + 0.01 * k)
+        sca[i] = (40.0, 40.0, 0.05)
+        sc["rotations"][i] = (1.0, 0.0, 0.0, 0.0)
+        sc["opacities"][i] = 0.05
+    far = int(np.argmax(m[:, 2]))
+    m[far] = (1e3, 0.0, 25.0)                                 # the deepest Gaussian: outside the image
+    return sc
 
 
 def stress_scene():
