@@ -496,7 +496,7 @@ __device__ __forceinline__ void pair_nodiv_cc(float CC, float w, PairEval& p)
     const float qh = p.BBf * ra;
     const double AA = (double)p.AAf, BB = (double)p.BBf;
     double q;
-    if (fabsf(qh) < 3e38f && fabsf(ra) < 3e38f) {        // (false for inf / NaN too)
+    if (fabsf(qh) < 3e38f) {        // (false for inf / NaN too; a reciprocal that is inf / NaN makes the quotient inf / NaN: no test of its own)
         const double y = (double)ra;
         q = (double)qh;
         q = fma(fma(-q, AA, BB), y, q);
@@ -507,8 +507,12 @@ __device__ __forceinline__ void pair_nodiv_cc(float CC, float w, PairEval& p)
     p.q = q;
     p.t = -0.5f * (float)q;                               // == (float)(-q * 0.5): the scaling is exact
     p.skip = p.t < 0.2f;                                  // (double)t <= 0.2  <=>  t < 0.2f  (0.2f is the fp32 above 0.2; NaN: neither)
-    const double min_value = (-q) * (BB * 0.25) + (double)CC;
-    float power = (float)(-0.5 * min_value);
+    // min_value = fl(fl((-q) (BB / 4)) + CC) of the exact path, with its power-of-two scalings moved to where they cost nothing:
+    // fl((-q) (BB / 4)) = -fl(q BB) / 4 exactly, and adding an exactly scaled product is what ONE fma with the factor -1/4 does
+    // (its single rounding is the addition's); likewise fl32(-min_value / 2) = -fl32(min_value) / 2.  Same bits, an fp64 scaling
+    // and an fp64 multiply less per pair.
+    const double min_value = fma(q * BB, -0.25, (double)CC);
+    float power = -0.5f * (float)min_value;
     if (power > 0.0f) power = 0.0f;
     p.G = gexpf<true>(power);
     p.alpha = fminf(0.99f, w * p.G);
