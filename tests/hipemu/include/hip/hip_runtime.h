@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -331,7 +332,21 @@ inline int hipemu_sbfe(int v, unsigned off, unsigned width)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) ((float)(1.0 / std::sqrt((double)(x))))
 #define __builtin_amdgcn_exp2f(x) (exp2f(x))
-#define __builtin_amdgcn_s_sleep(n) sched_yield()
+// s_sleep inside a poll loop (the sorts' bounded decoupled look-back): the workgroup polled for runs on another OS thread.  On a busy
+// host that thread may be off the CPU for longer than 2^18 bare sched_yield() calls last (seen once: the fiber-order test failed
+// while two other 8-thread jobs ran) -- so after a streak of 2048 polls every further one sleeps 20 us: the poll limit then stands
+// for seconds of waiting, as it does for milliseconds on the GPU.
+inline void hipemu_s_sleep()
+{
+    static thread_local unsigned streak = 0;
+    static thread_local std::chrono::steady_clock::time_point last;
+    const auto now = std::chrono::steady_clock::now();
+    if (now - last > std::chrono::milliseconds(5)) streak = 0;
+    last = now;
+    if (++streak < 2048u) sched_yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
+}
+#define __builtin_amdgcn_s_sleep(n) hipemu_s_sleep()
 // hwreg(HW_REG_XCC_ID): the dispatcher deals consecutive workgroups round-robin over the 8 XCDs
 #define __builtin_amdgcn_s_getreg(r) (hipemu::t_block->bid.x & 7u)
 inline unsigned long long wall_clock64() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10; }
