@@ -334,8 +334,8 @@ inline int hipemu_sbfe(int v, unsigned off, unsigned width)
 #define __builtin_amdgcn_exp2f(x) (exp2f(x))
 // s_sleep inside a poll loop (the sorts' bounded decoupled look-back): the workgroup polled for runs on another OS thread.  On a busy
 // host that thread may be off the CPU for longer than 2^18 bare sched_yield() calls last (seen once: the fiber-order test failed
-// while two other 8-thread jobs ran) -- so after a streak of 2048 polls every further one sleeps 20 us: the poll limit then stands
-// for seconds of waiting, as it does for milliseconds on the GPU.
+// while two other 8-thread jobs ran) -- so after a streak of 32768 polls (~10 ms of yielding on an idle core: ordinary waits never get
+// there) every further one sleeps 10 us: the poll limit then stands for seconds of waiting, as it does for milliseconds on the GPU.
 inline void hipemu_s_sleep()
 {
     static thread_local unsigned streak = 0;
@@ -343,8 +343,8 @@ inline void hipemu_s_sleep()
     const auto now = std::chrono::steady_clock::now();
     if (now - last > std::chrono::milliseconds(5)) streak = 0;
     last = now;
-    if (++streak < 2048u) sched_yield();
-    else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    if (++streak < 32768u) sched_yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(10));
 }
 #define __builtin_amdgcn_s_sleep(n) hipemu_s_sleep()
 // hwreg(HW_REG_XCC_ID): the dispatcher deals consecutive workgroups round-robin over the 8 XCDs
