@@ -33,7 +33,7 @@ def _no_write_past_a_workspace():
 
 
 FAST = ["tiny", "one", "small_ks0", "small_ks01", "long_lists", "stress_box", "posed_tiny", "posed_small_ks01", "posed_long_lists",
-        "posed_stress_box", "posed_mod2", "posed_mod05_ks01", "emit_edges"]
+        "posed_stress_box", "posed_mod2", "posed_mod05_ks01", "emit_edges", "sub_tile", "strip_h", "strip_v", "one_px"]
 MEDIUM = ["lego10k", "posed_ragged", "posed_clustered150k"]
 
 
@@ -122,7 +122,7 @@ def test_emulated_precomputed_inputs_forward_and_backward():
         TP.assert_grad_close(gp[k], go[k], k)
 
 
-@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "stress_box", "posed_small_ks01", "posed_stress_box", "posed_ragged"])
+@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "stress_box", "posed_small_ks01", "posed_stress_box", "posed_ragged", "sub_tile", "strip_h", "strip_v", "one_px"])
 def test_emulated_integrate_bit_exact(name):
     sc = TP.SCENES[name]()
     pts = np.ascontiguousarray(S.tetra_points(sc), dtype=np.float32)

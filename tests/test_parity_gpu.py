@@ -125,6 +125,11 @@ SCENES = {
     "posed_mod05_ks01": lambda: {**S.scene_frustum(4000, W=160, H=112, focal=120.0, seed=10, sigma_px=5.0, kernel_size=0.1, pose_seed=8), "scale_modifier": 0.5},
     # round 4, late: emit_instances divides the OUTPUT slots among the waves (1024 per wave)
     "emit_edges": lambda: emit_edges_scene(),
+    # images smaller than a tile, one tile high / wide, a single pixel (the grid's edge handling in every kernel)
+    "sub_tile": lambda: S.scene_frustum(60, W=10, H=7, focal=9.0, seed=41, sigma_px=1.5),
+    "strip_h": lambda: S.scene_frustum(400, W=700, H=3, focal=500.0, seed=42, sigma_px=2.0),
+    "strip_v": lambda: S.scene_frustum(400, W=5, H=530, focal=400.0, seed=43, sigma_px=2.0),
+    "one_px": lambda: S.scene_frustum(30, W=1, H=1, focal=1.0, seed=44, sigma_px=0.5),
 }
 POSED = [k for k in SCENES if k.startswith("posed_")]
 
@@ -367,7 +372,8 @@ def _product_backward(res, dL):
     return {n: g.cpu().numpy() for n, g in zip(names, grads)}
 
 
-@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "clustered150k", "wide4k"] + POSED)
+@pytest.mark.parametrize("name", ["tiny", "small_ks01", "lego10k", "ragged", "long_lists", "mid100k", "clustered150k", "wide4k", "emit_edges", "sub_tile",
+                                  "strip_h", "strip_v", "one_px"] + POSED)
 def test_backward_blend_gradients(name):
     sc = SCENES[name]()
     o, oc, orad, res = _forward_pair(sc)
@@ -459,7 +465,7 @@ def test_integrate_matches_oracle():
     assert (a[-2:] == 1.0).all()          # points outside the image keep the initial 1.0 (rasterize_points.cu:277)
 
 
-@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k", "wide4k"] + POSED)
+@pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k", "wide4k", "sub_tile", "strip_h", "strip_v"] + POSED)
 def test_integrate_bit_exact_on_scene(name):
     """The opacity-field query on the forward's scene table (incl. the cull stress scene: sub-pixel far splats, needles,
     splats containing the camera plane, opacities around 1/255): every output bit-identical to the oracle.  Query points =
