@@ -81,8 +81,10 @@ constexpr int RED_STRIDE = 68;
 // an entry to visit, [2] contributing (lane, entry) pairs, [3] word fetches, [4] staged entries, [5] pairs of CONSECUTIVE visited
 // entries of a wave whose contributing lanes are disjoint (greedy, within one mask word: what merging two entries into one gradient
 // block could save), [6] (row, entry) pairs with at least one contributing lane (a walk per 16-lane row would visit those),
-// [7] visited entries in which at most 32 lanes contribute
-__device__ unsigned long long g_bw_stats[8];
+// [7] visited entries in which at most 32 lanes contribute, [8] sum over the batches of the LARGEST visit count among the tile's four
+// waves (what the batch's barriers make every wave wait for), [9] batches, [10] sum over the tiles of the largest per-tile visit total
+// among the four waves (what the tile would take if its waves ran without the batch barriers)
+__device__ unsigned long long g_bw_stats[12];
 #define BSTAT_ADD(i, v) atomicAdd(&g_bw_stats[i], (unsigned long long)(v))
 #else
 #define BSTAT_ADD(i, v)
@@ -243,6 +245,10 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     // batches are aligned to the list start (so that they line up with the forward's mask words) and visited from
     // the back: batch kb covers list positions [kb * BATCH, min((kb + 1) * BATCH, max_last))
     const int nbatches = (int)((max_last + BATCH - 1) / BATCH);
+#ifdef GOF_STATS
+    __shared__ uint32_t s_stat_v[4];
+    uint32_t stat_tile_visits = 0;
+#endif
     for (int kb = nbatches - 1; kb >= 0; kb--) {
         __syncthreads();
         const uint32_t p0 = (uint32_t)kb * BATCH;
@@ -280,6 +286,9 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         }
         __syncthreads();
         if (tid == 0) BSTAT_ADD(4, n);
+#ifdef GOF_STATS
+        uint32_t stat_visits = 0;
+#endif
 
         // The wave walks the union of its pixels' contributors back to front (wave-uniform entry index: scalar bit walk over
         // the OR of the 64 mask words, LDS reads of the record are broadcasts).
@@ -293,6 +302,9 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
             const uint32_t word = cmw[w];
             uint32_t todo = wave_or(word);
             uint32_t visited = todo;
+#ifdef GOF_STATS
+            stat_visits += (uint32_t)__popc(todo);
+#endif
 #ifdef GOF_STATS
             unsigned long long stat_prev_set = 0ull;
             {   // [1] trips a walk per 16-lane row would need for this word (each row its own union: the slowest row counts), [3] the wave's
@@ -491,6 +503,12 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
             }
             if (lane == 0) s_vis[wave][w] = visited;
         }
+#ifdef GOF_STATS
+        stat_tile_visits += stat_visits;
+        if (lane == 0) s_stat_v[wave] = stat_visits;
+        __syncthreads();
+        if (tid == 0) { BSTAT_ADD(8, max(max(s_stat_v[0], s_stat_v[1]), max(s_stat_v[2], s_stat_v[3]))); BSTAT_ADD(9, 1); }
+#endif
         __syncthreads();
         // flush: one entry per thread -- the slabs of the waves that visited it, summed in wave order, stored as the partial
         // gradient record of this (tile, Gaussian) instance.  Records live in a POOL (round 4: the scratch holds a record per STAGED
@@ -518,6 +536,12 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
             }
         }
     }
+#ifdef GOF_STATS
+    __syncthreads();
+    if ((tid & 63u) == 0u) s_stat_v[tid >> 6] = stat_tile_visits;
+    __syncthreads();
+    if (tid == 0) BSTAT_ADD(10, max(max(s_stat_v[0], s_stat_v[1]), max(s_stat_v[2], s_stat_v[3])));
+#endif
     TILE_CLOCK_END(g_bw_tile_clock);
 }
 
@@ -662,11 +686,11 @@ extern "C" int gof_debug_bw_tile_clock(unsigned long long* out, int ntiles)     
 }
 #endif
 #ifdef GOF_STATS
-extern "C" int gof_debug_bw_stats(unsigned long long* out8, int reset)
+extern "C" int gof_debug_bw_stats(unsigned long long* out12, int reset)
 {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bw_stats), sizeof(g_bw_stats));
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stats), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_bw_stats), sizeof(g_bw_stats));
+    if (reset) { unsigned long long z[12] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stats), z, sizeof(z)); }
     return 0;
 }
 #endif

@@ -10,7 +10,7 @@ sd = to_dev(sc)
 res = product_forward_raw(sd)
 dL = torch.randn(9, sd["H"], sd["W"], device="cuda")
 a = res["args"]
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 B.lib.gof_debug_bw_stats(out, 1)
 B.rasterize_gaussians_backward(a[0], a[1], res["radii"], a[2], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14],
                                dL, a[17], a[18], a[19], res["geom"], res["R"], res["binning"], res["img"], False)

@@ -24,7 +24,7 @@ SCENES = {"s1m": lambda: S.scene_frustum(1_000_000, seed=0), "s1m_clustered": la
 def run(which, chunks=(256, 64, 32)):
     sc = SCENES[which]()
     npix = sc["W"] * sc["H"]
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 12)()
     rep = {"scene": which, "P": int(sc["means3D"].shape[0]), "W": sc["W"], "H": sc["H"], "forward": {}}
     for chunk in chunks:
         lib = E.load(extra_flags=("-DGOF_STATS", "-DGOF_FW_CHUNK=%d" % chunk), tag="stats_c%d" % chunk)
@@ -46,7 +46,10 @@ def run(which, chunks=(256, 64, 32)):
             rep["backward"] = {"staged_entries": b[4], "visited_wave_entries": b[0], "contributing_lane_pairs": b[2], "lanes_per_visit": b[2] / b[0],
                                "consecutive_visits_with_disjoint_lanes": b[5], "visits_saved_by_merging_fraction": b[5] / b[0],
                                "rows_with_a_contributor_per_visit": b[6] / b[0], "visits_with_at_most_32_lanes_fraction": b[7] / b[0],
-                               "trips_if_every_row_walked_its_own_union_fraction": b[1] / b[3]}
+                               "trips_if_every_row_walked_its_own_union_fraction": b[1] / b[3],
+                               "batches": b[9], "visits_per_batch_mean_over_waves": b[0] / (4.0 * b[9]), "visits_per_batch_of_the_slowest_wave": b[8] / b[9],
+                               "slowest_wave_over_mean_per_batch": b[8] * 4.0 / b[0],
+                               "slowest_wave_over_mean_per_tile_if_the_waves_ran_without_batch_barriers": b[10] * 4.0 / b[0]}
     return rep
 
 
