@@ -81,6 +81,13 @@ __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* g
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
                                  uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                  uint32_t* tile_queue, uint32_t* tile_cost);
+__global__ void integrate_pixels_capped(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
+                                        const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
+                                        uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, uint32_t* tile_cost);
+__global__ void integrate_rays(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec,
+                               const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
+                               uint32_t* n_contrib, float* out_color, uint32_t* cmask, uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
+                               uint32_t* tile_queue, uint32_t* tile_cost);
 __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* point_ranges, const uint32_t* gaussian_list,
                                  const uint32_t* point_list, const SplatRec* rec, const float* zfront, int zstride, const uint32_t* cmask, int W, int H,
                                  const uint32_t* pt_key, const float2* pt_ray, const float* pt_depth, float* pt_T, float* pt_acc, const float* base_color, float* out_color,
@@ -397,6 +404,9 @@ static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream
 // tile rectangle of a Gaussian intersected with its footprint box (opt-in: gof_set_tight_tile_rects / GOF_TIGHT_RECTS=1; preprocess.hip)
 static std::atomic<int> g_tight_rects{ [] { const char* e = getenv("GOF_TIGHT_RECTS"); return (e && e[0] == '1') ? 1 : 0; }() };
 
+// gof_set_integrate_pixel_pass(1) / GOF_INT_PIXELS=1: the opacity-field query's pixel pass in its pixel-centric form (rounds 1-4) instead of
+// the ray-centric one (round 5) -- same outputs bit for bit, kept for A/B timing and as the cap fallback (integrate.hip)
+static std::atomic<int> g_integrate_pixel_pass{ [] { const char* e = getenv("GOF_INT_PIXELS"); return (e && e[0] == '1') ? 1 : 0; }() };
 static std::atomic<int> g_forward_exact{ [] { const char* e = getenv("GOF_FW_EXACT"); return (e && e[0] == '1') ? 1 : 0; }() };
 static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const GeomWs& g, const BinWs& b, const ImageWs& im, float* out_color, hipStream_t stream)
 {
@@ -415,8 +425,9 @@ extern "C" {
 
 const char* gof_last_error(void) { return g_error.c_str(); }
 int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
+int gof_set_integrate_pixel_pass(int on) { return g_integrate_pixel_pass.exchange(on ? 1 : 0); }
 int gof_set_tight_tile_rects(int on) { return g_tight_rects.exchange(on ? 1 : 0); }
-int gof_abi_version(void) { return 10; }  // 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query; 10: gof_forward_fused(usage_pinned_host), backward scratch without its scan (round 4)
+int gof_abi_version(void) { return 11; }  // 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query; 10: gof_forward_fused(usage_pinned_host), backward scratch without its scan (round 4); 11: gof_set_integrate_pixel_pass (round 5)
                                           // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
@@ -546,7 +557,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
     order_tiles_for_backward(d, im, stream, usage_mapped);
-    if (usage_pinned_host && !usage_mapped)       // (not device-mapped: the copy form, as gof_forward_usage_async)
+    if (usage_pinned_host && (!usage_mapped || bw_order_by_length()))       // (not device-mapped, or the developer switch skipped the launch that stores the words: the copy form, as gof_forward_usage_async)
         GOF_HIP_CHECK(hipMemcpyAsync(usage_pinned_host, im.mask_cursors, (POOL_SHARDS + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipEventSynchronize(ev));
     if (*num_rendered_pinned_host >= GOF_SORT_FAILED_COUNT) {
@@ -833,9 +844,22 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
     GOF_PROFILE("integrate_pixels", stream);
-    hipLaunchKernelGGL(integrate_pixels, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
-                       im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
+    if (g_integrate_pixel_pass.load(std::memory_order_relaxed)) {      // the pixel-centric form of rounds 1-4 (gof_set_integrate_pixel_pass(1): A/B, tests)
+        hipLaunchKernelGGL(integrate_pixels, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
+                           im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
+                           out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
+        GOF_LAUNCH_CHECK(stream, a->debug);
+        return GOF_OK;
+    }
+    // ray-centric: every distinct sub-ray of a tile once (integrate.hip); the tiles it abandons at the reference's 1024-contributor
+    // cap (tile_cost == 0xFFFFFFFF) are rendered by the pixel-centric kernel behind it (one workgroup per tile, most return at once)
+    hipLaunchKernelGGL(integrate_rays, dim3(xcd_padded_tiles(d.ntiles)), dim3(576), 0, stream,
+                       im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
                        out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
+    GOF_LAUNCH_CHECK(stream, a->debug);
+    hipLaunchKernelGGL(integrate_pixels_capped, dim3(d.ntiles), dim3(TILE_PIX), 0, stream,
+                       im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
+                       out_color, b.cmask, d.gx, d.ntiles, im.tile_cost);
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }

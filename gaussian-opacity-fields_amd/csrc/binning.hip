@@ -95,7 +95,12 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
 {
     const uint32_t lane = threadIdx.x & 63u;
     if (inst_first)
-        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)P; i += gridDim.x * 256u) inst_first[order[i]] = order_off[i];
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)P; i += gridDim.x * 256u) {
+            // (a depth sort whose look-back poll expired leaves slots of `order` unwritten: whatever lies there must not become an
+            // address -- gather_rects guards its reads with the sort's error flag, this store with the range itself)
+            const uint32_t id = order[i];
+            if (id < (uint32_t)P) inst_first[id] = order_off[i];
+        }
     // the instance count: exclusive offset + count of the last Gaussian in the order (0 after a failed depth sort: gather_rects)
     const uint32_t wh_last = wh_sorted[P - 1];
     const uint32_t total = order_off[P - 1] + (wh_last & 0xFFFFu) * (wh_last >> 16);

@@ -50,16 +50,306 @@ __device__ unsigned long long g_int_stats[16];
 #endif
 
 
-__global__ void __launch_bounds__(256)
-integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
+// ---- ray-centric pixel pass (round 5) ----------------------------------------------------------------------------------------
+// The five sub-rays of a pixel are its centre and its four half-pixel corners (forward.cu:881-883, 920), and a corner is shared:
+// pixf.x + 0.5f of pixel p and pixf.x - 0.5f of pixel p + 1 are the same float (p + 1 exactly), so the four pixels around a corner
+// evaluate THE SAME ray bit for bit -- and a sub-ray's recurrence (t, alpha, T: forward.cu:918-975) depends on that ray and the tile
+// list only.  What couples the sub-rays of a pixel is an OR (`used`), a max (the depth channel) and the 1024-contributor cap.  A
+// tile has 16 x 16 centres + 17 x 17 corners = 545 distinct rays where the pixel-centric form evaluates 5 x 256 = 1280.
+//
+//   lane = RAY: 9 waves per tile -- waves 0-3 the centre rays (tile_pixel map), waves 4-7 the 16 x 16 corners that are the top-left
+//   corner of a pixel of the tile (same map), wave 8 the 33 corners of the tile's right column / bottom row.  Per staged batch:
+//     phase 1: the forward blend's cull scan (footprint conic at the lane's own ray -- exact, no half-pixel allowance --, packed fp32);
+//     phase 2: per-lane ordered consumption of the ray's candidates: ONE sub-ray evaluation of forward.cu:921-975 per trip (the
+//       pixel-centric form ran five, each behind its own divergent tests); accepted entries stay as the ray's 256-bit mask in LDS;
+//     assembly (thread = pixel, after the batch's barrier): used = OR of the pixel's five ray masks -> contributor words, count,
+//       last contributor, the uint16 matching of lists beyond 65535 entries -- exactly the old bookkeeping, now outside the hot loop.
+//   A ray is finished once T (1 - 1/255) < 1e-4 (see integrate_pixels_tile: nothing can be accepted any more), the tile once all
+//   its rays are.  Pixel channels: colour / alpha / final_T from the centre ray, depth = max over the five rays' deepest accepted t.
+//   The cap (forward.cu:986-990: a pixel stops for good at its 1024th used entry while its neighbours, who share its corner rays, go
+//   on) cannot be honoured ray by ray: a tile in which a pixel reaches it is abandoned (tile_cost = TILE_CAPPED) and rendered by the
+//   pixel-centric kernel behind this one (integrate_pixels_capped).  Every output bit is that of the pixel-centric form.
+constexpr int IR_CORNER0 = TILE_PIX;            // lanes 256..511: corner (i, j), i, j < 16 = top-left corner of pixel (i, j), at tile_thread(i, j)
+constexpr int IR_EDGE0 = 2 * TILE_PIX;          // lanes 512..528: corners (16, j), j = 0..16; lanes 529..544: corners (i, 16), i = 0..15
+constexpr int IR_RAYS = 2 * TILE_PIX + 33;
+constexpr int IR_THREADS = 576;                 // 9 wave64
+constexpr uint32_t TILE_CAPPED = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t corner_lane(uint32_t ci, uint32_t cj)
+{
+    if (ci < 16u && cj < 16u) return IR_CORNER0 + tile_thread(ci, cj);
+    return ci == 16u ? IR_EDGE0 + cj : IR_EDGE0 + 17u + ci;
+}
+
+#ifndef GOF_IR_WAVES
+#define GOF_IR_WAVES 7      // three workgroups of 9 waves per CU put 7 waves on three of its SIMDs: keep the registers at 512 / 7
+#endif
+__global__ void __launch_bounds__(IR_THREADS) __attribute__((amdgpu_waves_per_eu(GOF_IR_WAVES, 8)))
+integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
+               const SplatRec* __restrict__ rec, const float4* __restrict__ fconic, int W, int H,
+               float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+               float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles,
+               const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
+{
+    __shared__ uint32_t s_rmask[8][IR_THREADS];      // per ray: candidate bits of the staged batch, rewritten in place with the accepted ones
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_rmask[0][0]);      // longest list first (gof_common.h)
+    if (tile >= ntiles) return;
+    const uint32_t tx = tile % gx, ty = tile / gx;
+    const uint32_t tid = threadIdx.x;
+    const bool centre = tid < (uint32_t)TILE_PIX;
+
+    // staged entries: the forward blend's layout (operand pairs of the packed prelude, blend_forward.hip) + the footprint conic, SoA
+    __shared__ f4 s_rec[4][TILE_PIX];
+    __shared__ float s_blue[TILE_PIX];
+    __shared__ f4 s_cf[6][TILE_PIX / 4];
+    __shared__ float s_maxt[IR_THREADS];
+    __shared__ uint32_t s_abort, s_cost;
+#ifdef GOF_CULL_AUDIT
+    __shared__ uint32_t s_cand[8][IR_THREADS];
+#endif
+
+    // this lane's ray: the position in pixel units is an integer or an integer + 0.5, formed exactly as pixf + offset is (forward.cu:920)
+    uint32_t lx = 0, ly = 0;
+    bool active;
+    float posx, posy;
+    if (tid < (uint32_t)IR_EDGE0) {
+        tile_pixel(tid & 255u, lx, ly);
+        const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
+        if (centre) { active = px < (uint32_t)W && py < (uint32_t)H; posx = (float)px + 0.5f; posy = (float)py + 0.5f; }
+        else { active = px <= (uint32_t)W && py <= (uint32_t)H; posx = (float)px; posy = (float)py; }      // a corner inside or on the border of the image has a pixel of this tile inside
+    } else {
+        const uint32_t e = tid - (uint32_t)IR_EDGE0;
+        const uint32_t ci = e < 17u ? 16u : e - 17u, cj = e < 17u ? e : 16u;
+        const uint32_t px = tx * TILE_X + ci, py = ty * TILE_Y + cj;
+        active = tid < (uint32_t)IR_RAYS && px <= (uint32_t)W && py <= (uint32_t)H;
+        posx = (float)px; posy = (float)py;
+    }
+    const float rx = (float)(((double)posx - W / 2.) / (double)focal_x);
+    const float ry = (float)(((double)posy - H / 2.) / (double)focal_y);
+    const f2 RX = { rx, rx }, RY = { ry, ry }, RXY = { rx, ry };
+    // evaluation-error margin of the unit-normalised conic in Horner form: blend_forward.hip (7 eps B derived, 1e-6 B carried)
+#ifndef GOF_INT_RAY_MARGIN
+#define GOF_INT_RAY_MARGIN 1e-6f
+#endif
+    const float cone_margin = GOF_INT_RAY_MARGIN * fmaxf(1.0f, fmaxf(rx * rx, ry * ry));
+    const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
+
+    const uint2 range = gaussian_ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int nbatches = (total + TILE_PIX - 1) / TILE_PIX;
+    uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
+
+    // ray state
+    float T = 1.0f, maxt = 0.0f;
+    float C0 = 0, C1 = 0, C2 = 0, Calpha = 0;          // centre rays only
+    bool done = !active;
+    // pixel state (threads 0..255, assembly): the bookkeeping of forward.cu:976-990
+    const bool inside = centre && active;
+    const uint32_t c00 = corner_lane(lx, ly), c10 = corner_lane(lx + 1u, ly), c01 = corner_lane(lx, ly + 1u), c11 = corner_lane(lx + 1u, ly + 1u);
+    uint32_t last_contributor = 0, n_local = 0;
+    uint32_t last_matched = 0;      // uint16 emulation (forward.cu:983, 1145), see integrate_pixels_tile
+    bool match_stuck = false;
+    if (tid == 0) { s_abort = 0u; s_cost = 0u; }
+
+    for (int b = 0; ; b++) {
+        const int all_done = __syncthreads_and(done);      // every wave has finished batch b - 1: its ray masks are complete, s_rec / s_cf are free
+        if (b > 0 && centre) {
+            // ---- assembly of batch b - 1: the pixel's contributor words from its five rays' masks ----
+            const int bb = b - 1;
+            const int nb = min(TILE_PIX, total - bb * TILE_PIX);
+            const int nwords = (nb + 31) >> 5;
+            for (int w = 0; w < nwords; w++) {
+                uint32_t u = s_rmask[w][tid] | s_rmask[w][c00] | s_rmask[w][c10] | s_rmask[w][c01] | s_rmask[w][c11];
+                if (!inside) u = 0u;                               // (a pixel outside the image may sit next to a live border corner)
+                uint32_t word = u;
+                if (u) {
+                    const uint32_t pos0 = (uint32_t)bb * TILE_PIX + (uint32_t)w * 32u;      // bit k = 1-based list position pos0 + k + 1
+                    if (pos0 + 32u <= 0xFFFFu) {                  // stored exactly by the reference's uint16 ids: the second pass finds them where they are
+                        n_local += (uint32_t)__popc(u);
+                        last_contributor = pos0 + 32u - (uint32_t)__clz((int)u);
+                        last_matched = last_contributor;
+                    } else {
+                        word = 0u;
+                        uint32_t rest = u;
+                        while (rest) {
+                            const int bit = __ffs((int)rest) - 1;
+                            rest &= rest - 1u;
+                            const uint32_t contributor = pos0 + (uint32_t)bit + 1u;
+                            last_contributor = contributor;
+                            if (contributor <= 0xFFFFu) {
+                                word |= 1u << bit;
+                                last_matched = contributor;
+                            } else if (!match_stuck) {            // stored mod 2^16: matched at THAT position, if still ahead
+                                const uint32_t c16 = contributor & 0xFFFFu;
+                                if (c16 > last_matched) {
+                                    last_matched = c16;
+                                    uint32_t* vw = cm_tile + (size_t)((c16 - 1u) >> 5) * TILE_PIX + tid;   // this thread's own word of an earlier batch
+                                    *vw |= 1u << ((c16 - 1u) & 31u);
+                                } else match_stuck = true;
+                            }
+                            n_local += 1;
+                        }
+                    }
+                }
+                cm_tile[((size_t)bb * 8 + w) * TILE_PIX + tid] = word;
+            }
+            if (n_local >= (uint32_t)MAX_NUM_CONTRIBUTORS * 4) s_abort = 1u;      // the cap: this tile goes to the pixel-centric kernel
+        }
+        if (all_done || b == nbatches) break;
+
+        // ---- staging: waves 0-3 the records, waves 4-7 the footprint conics ----
+        const int toDo = total - b * TILE_PIX;
+        const int n = min(TILE_PIX, toDo);
+        if (tid < (uint32_t)IR_EDGE0) {
+            const uint32_t e = tid & 255u;
+            const uint32_t k = range.x + (uint32_t)b * TILE_PIX + e;
+            if (k < range.y) {
+                const uint32_t id = gaussian_list[k];
+                if (centre) {
+                    const float4* src = reinterpret_cast<const float4*>(&rec[id]);
+                    const float4 a = src[0], bq = src[1], c = src[2], d = src[3];
+                    s_rec[0][e] = f4{ a.x, a.y, a.y, a.w };
+                    s_rec[1][e] = f4{ a.z, bq.x, a.z, bq.z };
+                    s_rec[2][e] = f4{ bq.x, bq.w, bq.y, c.x };
+                    s_rec[3][e] = f4{ c.y, c.z, c.w, d.x };
+                    s_blue[e] = d.y;
+                } else {
+                    const float4 m0 = fconic[2 * (size_t)id], m1 = fconic[2 * (size_t)id + 1];     // {m00, m01, m11, m02}, {m12, m22, ., .}
+                    float* cf = reinterpret_cast<float*>(&s_cf[0][0]) + e;
+                    cf[0 * TILE_PIX] = m0.x; cf[1 * TILE_PIX] = 2.0f * m0.y; cf[2 * TILE_PIX] = m0.z;
+                    cf[3 * TILE_PIX] = 2.0f * m0.w; cf[4 * TILE_PIX] = 2.0f * m1.x; cf[5 * TILE_PIX] = m1.y;
+                }
+            }
+        }
+        __syncthreads();                                   // (also: the assembly of batch b - 1 has read the masks)
+        if (s_abort) break;
+        const int nw = (n + 31) >> 5;
+        if (__ballot(!done) == 0ull) {                     // every ray of this wave is finished: "nothing accepted" for the batch
+            for (int w = 0; w < nw; w++) s_rmask[w][tid] = 0u;
+            continue;
+        }
+
+        // ---- phase 1: cull scan, lane = RAY (blend_forward.hip: g = r^T M r - margin in Horner form, two entries per packed
+        // instruction, candidate <=> sign bit) ----
+        for (int w = 0; w < nw; w++) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int g4 = 7; g4 >= 0; g4--) {
+                const int q = w * 8 + g4;
+                const f4 m00 = s_cf[0][q], m01 = s_cf[1][q], m11 = s_cf[2][q], m02 = s_cf[3][q], m12 = s_cf[4][q], m22 = s_cf[5][q];
+                const f2 a_lo = pk_fma(m00.xy, RX, pk_fma(m01.xy, RY, m02.xy));
+                const f2 a_hi = pk_fma(m00.zw, RX, pk_fma(m01.zw, RY, m02.zw));
+                const f2 b_lo = pk_fma(m11.xy, RY, m12.xy);
+                const f2 b_hi = pk_fma(m11.zw, RY, m12.zw);
+                const f2 g_lo = pk_fma(RX, a_lo, pk_fma(RY, b_lo, m22.xy + NEG_MARGIN));
+                const f2 g_hi = pk_fma(RX, a_hi, pk_fma(RY, b_hi, m22.zw + NEG_MARGIN));
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_hi.y), 31);
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_hi.x), 31);
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_lo.y), 31);
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(g_lo.x), 31);
+            }
+            const int valid = n - w * 32;                                    // entries of this word the list covers (>= 1)
+            if (valid < 32) word &= (1u << valid) - 1u;                      // the tail of the LDS batch holds stale entries
+            if (done) word = 0u;
+#ifdef GOF_CULL_AUDIT
+            // developer-only audit build: the consumption walks EVERY entry and counts the pairs it accepts that the scan dropped ([11], must stay 0)
+            s_cand[w][tid] = word;
+            word = done ? 0u : (valid < 32 ? (1u << valid) - 1u : 0xFFFFFFFFu);
+#endif
+            s_rmask[w][tid] = word;
+            if ((tid & 63u) == 0u) ISTAT_ADD(9, min(32, valid));             // [9] (wave, entry) pairs scanned
+        }
+
+        // ---- phase 2: every lane consumes its own candidates in list order: forward.cu:921-975 for ONE sub-ray ----
+        int w = 0;
+        uint32_t cur = s_rmask[0][tid];
+        uint32_t cbits = 0;                                // accepted bits of word w (flushed when w advances)
+        for (;;) {
+            const bool more = !done && (cur != 0u || w + 1 < nw);
+            if (__ballot(more) == 0ull) break;
+            if ((tid & 63u) == 0u) ISTAT_ADD(8, 1);        // [8] wave trips of the candidate loop
+            if (!more) continue;
+            if (cur == 0u) { s_rmask[w][tid] = cbits; cbits = 0; w++; cur = s_rmask[w][tid]; }
+            if (cur == 0u) continue;
+            const int bit = __ffs((int)cur) - 1;
+            cur &= cur - 1u;
+            const int j = w * 32 + bit;
+            ISTAT_ADD(6, 1);                               // [6] candidates popped (ray, entry)
+            const f4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j];
+            const f2 n01 = (q0.xy * RX + q0.zw * RY) + q1.xy;               // normal[0], normal[1]
+            const f2 n2b = (q1.zw * RX + q2.xy * RY) + q2.zw;               // normal[2], BB / 2
+            const f2 rn = RXY * n01;
+            const float AA = (rn.x + rn.y) + n2b.x;
+            const float BB = 2 * n2b.y;
+            const float CC = q3.x, wgt = q3.y;
+            // one IEEE division: -BB/(2*AA) == -(BB/AA)/2 and BB/4 are exact power-of-two scalings (forward.cu:927-931)
+            const float q = BB / AA;
+            const float t = -q * 0.5f;
+            if (t < 0.2f) continue;                        // (double)t <= NEAR_PLANE, see integrate_pixels_tile
+            const double min_value = (double)(-q) * (double)(BB * 0.25f) + (double)CC;
+            float power = -0.5f * (float)min_value;
+            if (power > 0.0f) power = 0.0f;
+            const float alpha = fminf(0.99f, wgt * gexpf<true>(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) continue;
+#ifdef GOF_CULL_AUDIT
+            if (!((s_cand[w][tid] >> bit) & 1u)) ISTAT_ADD(11, 1);
+#endif
+            ISTAT_ADD(7, 1);                               // [7] accepted
+            if (centre) {
+                C0 += q3.z * alpha * T;
+                C1 += q3.w * alpha * T;
+                C2 += s_blue[j] * alpha * T;
+                Calpha += alpha * T;
+            }
+            if (t > maxt) maxt = t;
+            T = test_T;
+            cbits |= 1u << bit;
+            if (T * (1 - 1.0f / 255.0f) < 0.0001f) done = true;              // nothing can be accepted any more
+        }
+        s_rmask[w][tid] = cbits;
+        for (int q = w + 1; q < nw; q++) s_rmask[q][tid] = 0u;               // candidate words this ray never reached (it finished)
+    }
+
+    s_maxt[tid] = maxt;
+    __syncthreads();
+    if (s_abort) {                                         // (workgroup-uniform)
+        if (tid == 0) tile_cost[tile] = TILE_CAPPED;
+        return;
+    }
+    if (inside) {
+        const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
+        const uint32_t pix_id = (uint32_t)W * py + px;
+        const size_t HW = (size_t)W * H;
+        const float depth = fmaxf(fmaxf(maxt, fmaxf(s_maxt[c00], s_maxt[c10])), fmaxf(s_maxt[c01], s_maxt[c11]));
+        final_T[pix_id] = T;
+        n_contrib[pix_id] = last_contributor;
+        out_color[0 * HW + pix_id] = C0 + T * bg_color[0];
+        out_color[1 * HW + pix_id] = C1 + T * bg_color[1];
+        out_color[2 * HW + pix_id] = C2 + T * bg_color[2];
+        out_color[6 * HW + pix_id] = depth;
+        out_color[7 * HW + pix_id] = Calpha;
+    }
+    // what the point pass will walk in this tile (the deepest contributor position of its pixels): part of its dispatch cost
+    if (centre) {
+        uint32_t m = inside ? last_contributor : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if ((tid & 63u) == 0u) atomicMax(&s_cost, m);
+    }
+    __syncthreads();
+    if (tid == 0) tile_cost[tile] = s_cost;
+}
+
+// ---- pixel-centric form (rounds 1-4): thread = pixel, five sub-rays per thread.  Since round 5 the FALLBACK of integrate_rays for
+// tiles in which a pixel meets the reference's 1024-contributor cap (integrate_pixels_capped), and the whole pixel pass when
+// gof_set_integrate_pixel_pass(1) / GOF_INT_PIXELS=1 asks for it (integrate_pixels: A/B timing, and the tests run both forms).
+__device__ __forceinline__ void
+integrate_pixels_tile(const uint32_t tile, uint32_t& s_tile, const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
                  const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
                  float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles,
-                 const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
+                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t* __restrict__ tile_cost)
 {
-    __shared__ uint32_t s_tile;
-    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_tile);      // longest list first (gof_common.h)
-    if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
     uint32_t lx, ly;
@@ -299,6 +589,31 @@ integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __re
         __syncthreads();
         if (tid == 0) tile_cost[tile] = s_tile;
     }
+}
+
+__global__ void __launch_bounds__(256)
+integrate_pixels(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
+                 const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
+                 float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles,
+                 const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
+{
+    __shared__ uint32_t s_tile;
+    const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_tile);      // longest list first (gof_common.h)
+    if (tile >= ntiles) return;
+    integrate_pixels_tile(tile, s_tile, gaussian_ranges, gaussian_list, rec, bbox, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
+}
+// one workgroup per tile in blockIdx order: only the tiles integrate_rays gave up on (tile_cost == TILE_CAPPED) are rendered
+__global__ void __launch_bounds__(256)
+integrate_pixels_capped(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
+                 const SplatRec* __restrict__ rec, const float4* __restrict__ bbox, const float4* __restrict__ fconic, int W, int H,
+                 float focal_x, float focal_y, const float* __restrict__ bg_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                 float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles, uint32_t* __restrict__ tile_cost)
+{
+    __shared__ uint32_t s_tile;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ntiles || tile_cost[tile] != TILE_CAPPED) return;      // (workgroup-uniform)
+    integrate_pixels_tile(tile, s_tile, gaussian_ranges, gaussian_list, rec, bbox, fconic, W, H, focal_x, focal_y, bg_color, final_T, n_contrib, out_color, cmask, gx, tile_cost);
 }
 
 // copies what the point pass needs of the geometry workspace (64-byte records, front depths) into a compact buffer

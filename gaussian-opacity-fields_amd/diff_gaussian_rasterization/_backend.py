@@ -8,6 +8,7 @@ importing this module raises.
 """
 import ctypes as C
 import os
+import weakref
 import threading
 
 import torch
@@ -80,8 +81,8 @@ def _load():
     lib.gof_mtets_emit.argtypes = [i64, i64, vp, vp, vp, vp, vp, sz, vp, sz, i64, i64, vp, vp, vp, vp, vp, vp]
     lib.gof_debug_fetch.restype = i64
     lib.gof_debug_fetch.argtypes = [C.c_char_p, A, u32, vp, vp, vp, vp, sz, vp]
-    lib.gof_set_forward_exact.argtypes = lib.gof_set_tight_tile_rects.argtypes = [C.c_int]
-    lib.gof_set_forward_exact.restype = lib.gof_set_tight_tile_rects.restype = C.c_int
+    lib.gof_set_forward_exact.argtypes = lib.gof_set_tight_tile_rects.argtypes = lib.gof_set_integrate_pixel_pass.argtypes = [C.c_int]
+    lib.gof_set_forward_exact.restype = lib.gof_set_tight_tile_rects.restype = lib.gof_set_integrate_pixel_pass.restype = C.c_int
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
     for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
@@ -93,15 +94,19 @@ def _load():
 lib = _load()
 
 
-_grad_bucket = (0, 0, 0)      # (storage pointer, first byte, one past the last byte) of the latest backward's gradient allocation
+_grad_bucket = (None, 0, 0)   # (weak reference to the storage, first byte, one past the last byte) of the latest backward's gradient allocation
 
 
 def is_in_grad_bucket(t):
     """True if `t` lies in the gradient allocation of the most recent rasterizer backward (the segments of its parameter gradients).
     train_epilogue/activations.py writes the raw-parameter gradient over an incoming gradient only then: such a tensor is this
     library's own scratch, not a gradient autograd shares between nodes."""
-    sp, lo, hi = _grad_bucket
-    return sp != 0 and t.untyped_storage().data_ptr() == sp and lo <= t.data_ptr() and t.data_ptr() + t.numel() * t.element_size() <= hi
+    # identity AND liveness of the storage, not its address: once the bucket is freed the caching allocator may hand the same block to
+    # an unrelated gradient (a weak reference to a storage dies with the last tensor that uses it; torch keeps one Python object per
+    # live storage, so `is` compares storages)
+    ref, lo, hi = _grad_bucket
+    st = ref() if ref is not None else None
+    return st is not None and t.untyped_storage() is st and lo <= t.data_ptr() and t.data_ptr() + t.numel() * t.element_size() <= hi
 
 
 def _check(rc):
@@ -367,7 +372,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         tot += (n + 3) & ~3
     bucket = torch.empty(tot, **f)
     global _grad_bucket
-    _grad_bucket = (bucket.untyped_storage().data_ptr(), bucket.data_ptr(), bucket.data_ptr() + 4 * tot)     # what is_in_grad_bucket() recognises
+    _grad_bucket = (weakref.ref(bucket.untyped_storage()), bucket.data_ptr(), bucket.data_ptr() + 4 * tot)     # what is_in_grad_bucket() recognises
     g_means3D = bucket[offs[0]:offs[0] + sizes[0]].view(P, 3); g_opacity = bucket[offs[1]:offs[1] + sizes[1]].view(P, 1)
     g_scales = bucket[offs[2]:offs[2] + sizes[2]].view(P, 3); g_rot = bucket[offs[3]:offs[3] + sizes[3]].view(P, 4)
     if v.split_sh:        # gradients in the layout of the inputs: (dL_dfeatures_dc [P,1,3], dL_dfeatures_rest [P,15,3])
@@ -448,6 +453,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _mask_need[shape_key] = max(_mask_need.get(shape_key, 0), requested)
                 _staged_need[shape_key] = max(_staged_need.get(shape_key, 0), staged)
                 if requested > held:                  # masks are missing: the gradients just computed are incomplete -> forward again, then backward
+                    if track:
+                        # the abandoned backward must not count as a rasterizer backward of this step: the repeated one would make it
+                        # two on THIS rank only, take_sh_grad_source() would return None here and the source on the other ranks, and the
+                        # ranks would enter different collectives (dense all-reduce vs compressed all-gather)
+                        _sh_track["count"] -= 1
+                        _sh_track["src"] = None
                     raise MaskPoolTooSmall(requested, held)
                 if staged > rec_guess:                # records were dropped: the same backward again, with room for all of them
                     _stats["record_pool_redone_backwards"] += 1
@@ -726,6 +737,12 @@ def set_forward_exact(on):
     reference's own arithmetic (every output bit the oracle's); False (default) = the same arithmetic without its two fp64 divisions per pair (pair_nodiv_cc: decisions and channels 0-7 identical on every scene tested).  Process-wide;
     returns the previous setting."""
     return bool(lib.gof_set_forward_exact(1 if on else 0))
+
+
+def set_integrate_pixel_pass(on):
+    """Pixel pass of the opacity-field query (gof_set_integrate_pixel_pass, include/gof_hip.h): False (default) = ray-centric, every distinct
+    sub-ray of a tile once; True = pixel-centric (rounds 1-4).  Same outputs bit for bit.  Returns the previous setting."""
+    return bool(lib.gof_set_integrate_pixel_pass(1 if on else 0))
 
 
 def set_tight_tile_rects(on):

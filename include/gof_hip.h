@@ -96,6 +96,13 @@ int gof_set_forward_exact(int on);
  *      are dropped (R -21 % at 1M Gaussians @ 1600x1063).  Image, final_T, radii, the opacity-field query: unchanged bit for bit;
  *      gradients equal up to the summation order of the per-Gaussian gather; the intermediate lists are no longer the reference's. */
 int gof_set_tight_tile_rects(int on);
+/* Pixel pass of the opacity-field query, integrateCUDA's first half (forward.cu:886-993) (process-wide; returns the previous setting;
+ * initial value from the environment variable GOF_INT_PIXELS=1).
+ *   0 (default, round 5): ray-centric -- the centre and corner sub-rays of neighbouring pixels that are the same ray bit for bit
+ *      (pixf +- 0.5f is exact) are evaluated once per tile: 545 rays where thread = pixel evaluates 1280; tiles in which a pixel
+ *      meets the 1024-contributor cap (forward.cu:986-990) are rendered by the pixel-centric kernel behind it.
+ *   1: pixel-centric everywhere (rounds 1-4).  Every output bit is the same in both forms. */
+int gof_set_integrate_pixel_pass(int on);
 
 /* ---- workspace size queries (host only) ------------------------------------------------ */
 /* replaces required<GeometryState>(P)  (rasterizer_impl.cu:277, 188-204) */

@@ -14,7 +14,7 @@ plus, for the scene, the histogram of distance/scale (||mean_view|| / smallest s
 BB^2/(4 AA) is its square) over the visible Gaussians, and the same error figures restricted to the
 well-conditioned subset (ratio <= 30) of the Gaussians.  Forward: fraction of bit-identical elements per channel group.
 
-Writes gpurun_out/r03_parity_report.json (copied to profiles/ by hand).  GPU box only (test infrastructure: uses the oracle).
+Writes gpurun_out/r05_parity_report.json (copied to profiles/ by hand).  GPU box only (test infrastructure: uses the oracle).
     python tests/devtools/dev_parity_report.py [--quick]"""
 import json
 import os
@@ -81,6 +81,29 @@ def report_scene(name, sc, with_reference):
     fw["image_ch_0_1_2_6_7_8_max_abs"] = float(np.abs(pc[ex] - oc[ex]).max())
     fw["normals_ch_3_4_5_max_abs"] = float(np.abs(pc[3:6] - oc[3:6]).max())
     out["forward"] = fw
+    # round 5: the SHIPPED (default) forward mode and the verification mode, channel by channel against the oracle: fraction of
+    # bit-identical pixels, max |a - ref|, the same relative to the channel's maximum (north_star's "1e-4 relative"), and the 99.9th
+    # percentile of the element-wise relative error over the pixels with |ref| > 1e-3 max|ref|
+    def per_channel(img):
+        rows = {}
+        for ch in range(9):
+            a = img[ch].astype(np.float64).ravel(); b = oc[ch].astype(np.float64).ravel()
+            m = float(np.abs(b).max())
+            d = np.abs(a - b)
+            big = np.abs(b) > 1e-3 * m if m > 0 else np.zeros_like(b, bool)
+            rows[str(ch)] = {"bit_equal_fraction": float((bits(img[ch]) == bits(oc[ch])).mean()), "ref_max": m, "max_abs": float(d.max()),
+                             "max_abs_over_ref_max": float(d.max() / m) if m > 0 else 0.0,
+                             "p999_elem": float(np.percentile(d[big] / np.abs(b[big]), 99.9)) if big.any() else 0.0}
+        return rows
+    out["forward_default_mode_vs_oracle"] = per_channel(pc)
+    out["forward_verification_mode_vs_oracle"] = per_channel(res["exact"]["color"].cpu().numpy())
+    px = res["exact"]["color"].cpu().numpy()
+    d8 = np.abs(pc[8].astype(np.float64) - px[8])
+    out["default_vs_verification_mode"] = {"decisions_equal": bool(np.array_equal(fetch(res, "n_contrib"), fetch(res["exact"], "n_contrib")) and
+                                                                    np.array_equal(fetch(res, "contrib_hash"), fetch(res["exact"], "contrib_hash"))),
+                                           "ch_0_7_bit_equal_fraction": float((bits(pc[:8]) == bits(px[:8])).mean()),
+                                           "ch8_max_abs": float(d8.max()), "ch8_ref_max": float(np.abs(px[8]).max()),
+                                           "ch8_max_abs_over_ref_max": float(d8.max() / max(float(np.abs(px[8]).max()), 1e-300))}
     # backward
     dL = np.random.default_rng(17).normal(size=oc.shape).astype(np.float32)
     go = o.backward(dL)
@@ -128,6 +151,8 @@ def main():
         table["s1m"] = lambda: S.scene_frustum(1_000_000, seed=0)
         table["s1m_posed"] = lambda: S.scene_frustum(1_000_000, seed=0, pose_seed=0)
         table["s1m_clustered"] = lambda: S.scene_clustered(1_000_000, seed=0)
+        table["s1m_ks01"] = lambda: S.scene_frustum(1_000_000, seed=0, kernel_size=0.1)
+        table["s1m_posed_ks01"] = lambda: S.scene_frustum(1_000_000, seed=0, pose_seed=0, kernel_size=0.1)
     rep = {"tool": "tests/devtools/dev_parity_report.py", "gpu": torch.cuda.get_device_name(0),
            "definitions": {"max_norm": "max|a-ref| / max|ref|", "rel_l2": "||a-ref|| / ||ref||",
                            "p999_elem": "99.9th percentile of |a-ref|/|ref| over elements with |ref| > 1e-3 max|ref|",
@@ -139,7 +164,7 @@ def main():
         P = sc["means3D"].shape[0]
         rep["scenes"][name] = report_scene(name, sc, with_reference=rb.available("_nofma") and P >= 100)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r03_parity_report.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r05_parity_report.json"), "w") as f:
         json.dump(rep, f, indent=1)
     # summary: worst figure per tensor over all scenes
     worst = {}
@@ -150,6 +175,15 @@ def main():
                     key = "%s.%s.%s" % (grp, k, m)
                     if v[m] > worst.get(key, (0, ""))[0]:
                         worst[key] = (v[m], sn)
+    for sn, s in rep["scenes"].items():          # round 5: the shipped forward mode's distortion channel, relative to the channel's maximum
+        v = s["forward_default_mode_vs_oracle"]["8"]
+        for m in ("max_abs", "max_abs_over_ref_max", "p999_elem"):
+            key = "forward_default_mode_vs_oracle.ch8.%s" % m
+            if v[m] > worst.get(key, (0, ""))[0]:
+                worst[key] = (v[m], sn)
+    rep["worst"] = {k: {"value": v[0], "scene": v[1]} for k, v in worst.items()}
+    with open(os.path.join(ROOT, "gpurun_out", "r05_parity_report.json"), "w") as f:
+        json.dump(rep, f, indent=1)
     print(json.dumps({"worst": worst}, indent=1))
 
 

@@ -24,6 +24,8 @@ build_emu = pytest.importorskip("build_emu")
 if not os.path.exists(build_emu.CXX):
     pytest.skip("no host clang++ (%s) to build the emulated library" % build_emu.CXX, allow_module_level=True)
 import emu_binding as E  # noqa: E402
+if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", "_build", "BUILD_FAILED_build_emu")):
+    raise RuntimeError("__graft_entry__.build() recorded a failed build_emu run (tests/hipemu/_build/BUILD_FAILED_build_emu): these tests must not be skipped over it -- fix the host build and run build() again")
 
 @pytest.fixture(autouse=True)
 def _no_write_past_a_workspace():

@@ -22,6 +22,8 @@ build_ref_host = pytest.importorskip("build_ref_host")
 if not os.path.isdir(build_ref_host.REF) or not os.path.exists(build_ref_host.CXX):
     pytest.skip("no /root/reference (or no host clang++) here", allow_module_level=True)
 import ref_host_binding as RH  # noqa: E402
+if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", "_build", "BUILD_FAILED_build_ref_host")):
+    raise RuntimeError("__graft_entry__.build() recorded a failed build_ref_host run (tests/hipemu/_build/BUILD_FAILED_build_ref_host): these tests must not be skipped over it -- fix the host build and run build() again")
 
 
 def _pin_forward(sc, image_tol=2e-5):
