@@ -42,7 +42,8 @@ namespace gof {
 // [4] wave trips of the bit loop, [5] lane-trips with a bit to process; PIXEL pass: [6] candidates popped, [7] of them used by a sub-ray,
 // [8] wave trips of the candidate loop (the longest lane's, per mask word), [9] (wave, entry) iterations of the cull scan,
 // [10] the trips lanes advancing on their own over a batch's 8 words would take (host counts, 400k Gaussians @ 640x400: 0.83 of [8];
-// lane utilisation 0.45 -> 0.54 -- the rest is pixels that have finished while their wave has not)
+// lane utilisation 0.45 -> 0.54 -- the rest is pixels that have finished while their wave has not); integrate_rays: [6]-[9] per RAY, [11] (audit
+// build) pairs accepted outside the scan's candidates, [12]-[14] trips by wave kind, [15] staged batches
 __device__ unsigned long long g_int_stats[16];
 #define ISTAT_ADD(i, v) atomicAdd(&g_int_stats[i], (unsigned long long)(v))
 #else
@@ -57,8 +58,8 @@ __device__ unsigned long long g_int_stats[16];
 // list only.  What couples the sub-rays of a pixel is an OR (`used`), a max (the depth channel) and the 1024-contributor cap.  A
 // tile has 16 x 16 centres + 17 x 17 corners = 545 distinct rays where the pixel-centric form evaluates 5 x 256 = 1280.
 //
-//   lane = RAY: 9 waves per tile -- waves 0-3 the centre rays (tile_pixel map), waves 4-7 the 16 x 16 corners that are the top-left
-//   corner of a pixel of the tile (same map), wave 8 the 33 corners of the tile's right column / bottom row.  Per staged batch:
+//   lane = RAY: 9 waves per tile -- rays 0..255 the centre rays (tile_pixel map), 256..511 the 16 x 16 corners that are the top-left
+//   corner of a pixel of the tile (same map), 512..544 the 33 corners of the tile's right column / bottom row.  Per staged batch:
 //     phase 1: the forward blend's cull scan (footprint conic at the lane's own ray -- exact, no half-pixel allowance --, packed fp32);
 //     phase 2: per-lane ordered consumption of the ray's candidates: ONE sub-ray evaluation of forward.cu:921-975 per trip (the
 //       pixel-centric form ran five, each behind its own divergent tests); accepted entries stay as the ray's 256-bit mask in LDS;
@@ -66,23 +67,59 @@ __device__ unsigned long long g_int_stats[16];
 //       last contributor, the uint16 matching of lists beyond 65535 entries -- exactly the old bookkeeping, now outside the hot loop.
 //   A ray is finished once T (1 - 1/255) < 1e-4 (see integrate_pixels_tile: nothing can be accepted any more), the tile once all
 //   its rays are.  Pixel channels: colour / alpha / final_T from the centre ray, depth = max over the five rays' deepest accepted t.
+//   COMPACTION: the reference never lets T fall below 1e-4 (an entry that would is skipped, forward.cu:951-956), so a ray is only
+//   finished when T lands in [1e-4, 1.0039e-4) -- most rays of a tile finish within two or three batches, a few walk the whole list
+//   accepting ever smaller alphas: counted on the host, 23 of a wave's 64 lanes were still unfinished over the trips of phase 2.  A
+//   ray's state is small (T, deepest t, for a centre ray colour and alpha), so whenever the unfinished rays of the tile fit into
+//   fewer waves than hold rays now, every lane parks its ray's state in LDS (by ray number), the unfinished rays are numbered by a
+//   workgroup prefix sum and lane k adopts the k-th of them: the waves behind them have no ray, skip both phases and wait at the
+//   batch barrier.  Masks, state and results are addressed by RAY number, so nothing else knows which lane evaluates a ray.
 //   The cap (forward.cu:986-990: a pixel stops for good at its 1024th used entry while its neighbours, who share its corner rays, go
 //   on) cannot be honoured ray by ray: a tile in which a pixel reaches it is abandoned (tile_cost = TILE_CAPPED) and rendered by the
 //   pixel-centric kernel behind this one (integrate_pixels_capped).  Every output bit is that of the pixel-centric form.
-constexpr int IR_CORNER0 = TILE_PIX;            // lanes 256..511: corner (i, j), i, j < 16 = top-left corner of pixel (i, j), at tile_thread(i, j)
-constexpr int IR_EDGE0 = 2 * TILE_PIX;          // lanes 512..528: corners (16, j), j = 0..16; lanes 529..544: corners (i, 16), i = 0..15
+constexpr int IR_CORNER0 = TILE_PIX;            // rays 256..511: corner (i, j), i, j < 16 = top-left corner of pixel (i, j), at tile_thread(i, j)
+constexpr int IR_EDGE0 = 2 * TILE_PIX;          // rays 512..528: corners (16, j), j = 0..16; rays 529..544: corners (i, 16), i = 0..15
 constexpr int IR_RAYS = 2 * TILE_PIX + 33;
 constexpr int IR_THREADS = 576;                 // 9 wave64
+constexpr uint32_t IR_NO_RAY = IR_THREADS - 1;  // a lane without a ray: addresses a column / slot of the per-ray arrays that no ray owns
 constexpr uint32_t TILE_CAPPED = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t corner_lane(uint32_t ci, uint32_t cj)
 {
     if (ci < 16u && cj < 16u) return IR_CORNER0 + tile_thread(ci, cj);
     return ci == 16u ? IR_EDGE0 + cj : IR_EDGE0 + 17u + ci;
 }
+// ray r of tile (tx, ty): its position in pixel units -- an integer or an integer + 0.5, formed exactly as pixf + offset is
+// (forward.cu:920) -- as the ray direction; false if no pixel of the tile inside the image uses the ray
+__device__ __forceinline__ bool ray_of(uint32_t r, uint32_t tx, uint32_t ty, int W, int H, float focal_x, float focal_y, float& rx, float& ry)
+{
+    uint32_t ci, cj;
+    if (r < (uint32_t)IR_EDGE0) tile_pixel(r & 255u, ci, cj);
+    else { const uint32_t e = r - (uint32_t)IR_EDGE0; ci = e < 17u ? 16u : e - 17u; cj = e < 17u ? e : 16u; }
+    const uint32_t px = tx * TILE_X + ci, py = ty * TILE_Y + cj;
+    const bool is_centre = r < (uint32_t)TILE_PIX;
+    const float posx = is_centre ? (float)px + 0.5f : (float)px, posy = is_centre ? (float)py + 0.5f : (float)py;
+    rx = (float)(((double)posx - W / 2.) / (double)focal_x);
+    ry = (float)(((double)posy - H / 2.) / (double)focal_y);
+    // a corner inside or on the border of the image touches a pixel of this tile that lies inside
+    return is_centre ? (px < (uint32_t)W && py < (uint32_t)H) : (r < (uint32_t)IR_RAYS && px <= (uint32_t)W && py <= (uint32_t)H);
+}
 
 #ifndef GOF_IR_WAVES
-#define GOF_IR_WAVES 7      // three workgroups of 9 waves per CU put 7 waves on three of its SIMDs: keep the registers at 512 / 7
+#define GOF_IR_WAVES 7      // keep the registers at 512 / 7 (72): measured, profiles/r05_ab_call2_integrate_rays.txt
 #endif
+#ifndef GOF_IR_COMPACT
+#define GOF_IR_COMPACT 1    // developer A/B: 0 = rays stay on the lanes they start on
+#endif
+#ifndef GOF_IR_BATCH
+#define GOF_IR_BATCH 128    // tile-list entries staged per batch
+#endif
+#ifndef GOF_IR_EXIT
+#define GOF_IR_EXIT 1       // a wave beyond the stagers / pixel threads that holds no ray after a compaction leaves the kernel (its slot and registers go to the next workgroup)
+#endif
+constexpr int IR_BATCH = GOF_IR_BATCH;
+constexpr int IR_WORDS = IR_BATCH / 32;         // mask words of a batch
+constexpr int IR_KEEP_WAVES = (2 * IR_BATCH > TILE_PIX ? 2 * IR_BATCH : TILE_PIX) / 64;      // waves that stage (records: threads < IR_BATCH, conics: the next IR_BATCH) or own pixels
+static_assert(IR_BATCH == 64 || IR_BATCH == 128 || IR_BATCH == 256, "the staging roles assume 64, 128 or 256 entries per batch");
 __global__ void __launch_bounds__(IR_THREADS) __attribute__((amdgpu_waves_per_eu(GOF_IR_WAVES, 8)))
 integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __restrict__ gaussian_list,
                const SplatRec* __restrict__ rec, const float4* __restrict__ fconic, int W, int H,
@@ -90,79 +127,71 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
                float* __restrict__ out_color, uint32_t* __restrict__ cmask, uint32_t gx, uint32_t ntiles,
                const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, uint32_t* __restrict__ tile_cost)
 {
-    __shared__ uint32_t s_rmask[8][IR_THREADS];      // per ray: candidate bits of the staged batch, rewritten in place with the accepted ones
+    __shared__ uint32_t s_rmask[IR_WORDS][IR_THREADS];      // [word][ray]: candidate bits of the staged batch, rewritten in place with the accepted ones
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_queue + NXCD, ntiles, &s_rmask[0][0]);      // longest list first (gof_common.h)
     if (tile >= ntiles) return;
     const uint32_t tx = tile % gx, ty = tile / gx;
     const uint32_t tid = threadIdx.x;
-    const bool centre = tid < (uint32_t)TILE_PIX;
+    const bool pixel_thread = tid < (uint32_t)TILE_PIX;      // threads 0..255: the pixels of the tile (assembly, outputs)
 
     // staged entries: the forward blend's layout (operand pairs of the packed prelude, blend_forward.hip) + the footprint conic, SoA
-    __shared__ f4 s_rec[4][TILE_PIX];
-    __shared__ float s_blue[TILE_PIX];
-    __shared__ f4 s_cf[6][TILE_PIX / 4];
-    __shared__ float s_maxt[IR_THREADS];
+    __shared__ f4 s_rec[4][IR_BATCH];
+    __shared__ float s_blue[IR_BATCH];
+    __shared__ f4 s_cf[6][IR_BATCH / 4];
+    // a ray's state while no lane holds it (parked at a compaction, and at the end): by ray number
+    __shared__ float s_T[IR_THREADS], s_maxt[IR_THREADS];
+    __shared__ float s_C[4][TILE_PIX];               // centre rays: colour, alpha
+    __shared__ uint16_t s_list[IR_THREADS];          // the unfinished rays, numbered
+    __shared__ uint32_t s_wcount[IR_THREADS / 64];
+    __shared__ uint32_t s_live[2];                   // unfinished rays of the workgroup, by batch parity
     __shared__ uint32_t s_abort, s_cost;
 #ifdef GOF_CULL_AUDIT
-    __shared__ uint32_t s_cand[8][IR_THREADS];
+    __shared__ uint32_t s_cand[IR_WORDS][IR_THREADS];
 #endif
 
-    // this lane's ray: the position in pixel units is an integer or an integer + 0.5, formed exactly as pixf + offset is (forward.cu:920)
-    uint32_t lx = 0, ly = 0;
-    bool active;
-    float posx, posy;
-    if (tid < (uint32_t)IR_EDGE0) {
-        tile_pixel(tid & 255u, lx, ly);
-        const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
-        if (centre) { active = px < (uint32_t)W && py < (uint32_t)H; posx = (float)px + 0.5f; posy = (float)py + 0.5f; }
-        else { active = px <= (uint32_t)W && py <= (uint32_t)H; posx = (float)px; posy = (float)py; }      // a corner inside or on the border of the image has a pixel of this tile inside
-    } else {
-        const uint32_t e = tid - (uint32_t)IR_EDGE0;
-        const uint32_t ci = e < 17u ? 16u : e - 17u, cj = e < 17u ? e : 16u;
-        const uint32_t px = tx * TILE_X + ci, py = ty * TILE_Y + cj;
-        active = tid < (uint32_t)IR_RAYS && px <= (uint32_t)W && py <= (uint32_t)H;
-        posx = (float)px; posy = (float)py;
-    }
-    const float rx = (float)(((double)posx - W / 2.) / (double)focal_x);
-    const float ry = (float)(((double)posy - H / 2.) / (double)focal_y);
-    const f2 RX = { rx, rx }, RY = { ry, ry }, RXY = { rx, ry };
-    // evaluation-error margin of the unit-normalised conic in Horner form: blend_forward.hip (7 eps B derived, 1e-6 B carried)
-#ifndef GOF_INT_RAY_MARGIN
-#define GOF_INT_RAY_MARGIN 1e-6f
-#endif
-    const float cone_margin = GOF_INT_RAY_MARGIN * fmaxf(1.0f, fmaxf(rx * rx, ry * ry));
-    const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
+    // the ray this lane holds
+    uint32_t ray = tid;
+    float rx, ry;
+    if (!ray_of(ray, tx, ty, W, H, focal_x, focal_y, rx, ry)) ray = IR_NO_RAY;
+    bool done = ray == IR_NO_RAY;
+    float T = 1.0f, maxt = 0.0f;
+    float C0 = 0, C1 = 0, C2 = 0, Calpha = 0;          // centre rays only
 
     const uint2 range = gaussian_ranges[tile];
     const int total = (int)(range.y - range.x);
-    const int nbatches = (total + TILE_PIX - 1) / TILE_PIX;
+    const int nbatches = (total + IR_BATCH - 1) / IR_BATCH;
     uint32_t* const cm_tile = cmask + cmask_base(range.x, tile) * TILE_PIX;
 
-    // ray state
-    float T = 1.0f, maxt = 0.0f;
-    float C0 = 0, C1 = 0, C2 = 0, Calpha = 0;          // centre rays only
-    bool done = !active;
     // pixel state (threads 0..255, assembly): the bookkeeping of forward.cu:976-990
-    const bool inside = centre && active;
+    uint32_t lx, ly;
+    tile_pixel(tid & 255u, lx, ly);
+    const bool inside = pixel_thread && tx * TILE_X + lx < (uint32_t)W && ty * TILE_Y + ly < (uint32_t)H;
     const uint32_t c00 = corner_lane(lx, ly), c10 = corner_lane(lx + 1u, ly), c01 = corner_lane(lx, ly + 1u), c11 = corner_lane(lx + 1u, ly + 1u);
     uint32_t last_contributor = 0, n_local = 0;
     uint32_t last_matched = 0;      // uint16 emulation (forward.cu:983, 1145), see integrate_pixels_tile
     bool match_stuck = false;
-    if (tid == 0) { s_abort = 0u; s_cost = 0u; }
+    if (tid == 0) { s_abort = 0u; s_cost = 0u; s_live[0] = 0u; s_live[1] = 0u; }
+    int held_waves = IR_THREADS / 64;                  // waves that may hold a ray (workgroup-uniform)
+    int alive_waves = IR_THREADS / 64;                 // waves that have not left the kernel
+    __syncthreads();
 
     for (int b = 0; ; b++) {
-        const int all_done = __syncthreads_and(done);      // every wave has finished batch b - 1: its ray masks are complete, s_rec / s_cf are free
-        if (b > 0 && centre) {
+        // (not __syncthreads_count: waves may have left the kernel -- the hardware's barrier counts the surviving ones, a library reduction need not)
+        { const uint64_t lv = __ballot(!done); if ((tid & 63u) == 0u && lv) atomicAdd(&s_live[b & 1], (uint32_t)__popcll(lv)); }
+        __syncthreads();                                   // every wave has finished batch b - 1: the ray masks are complete, s_rec / s_cf are free
+        const int n_live = (int)s_live[b & 1];
+        if (tid == 0) s_live[(b + 1) & 1] = 0u;            // (last read before the previous batch's staging barrier, next added to behind this batch's)
+        if (b > 0 && pixel_thread) {
             // ---- assembly of batch b - 1: the pixel's contributor words from its five rays' masks ----
             const int bb = b - 1;
-            const int nb = min(TILE_PIX, total - bb * TILE_PIX);
+            const int nb = min(IR_BATCH, total - bb * IR_BATCH);
             const int nwords = (nb + 31) >> 5;
             for (int w = 0; w < nwords; w++) {
                 uint32_t u = s_rmask[w][tid] | s_rmask[w][c00] | s_rmask[w][c10] | s_rmask[w][c01] | s_rmask[w][c11];
                 if (!inside) u = 0u;                               // (a pixel outside the image may sit next to a live border corner)
                 uint32_t word = u;
                 if (u) {
-                    const uint32_t pos0 = (uint32_t)bb * TILE_PIX + (uint32_t)w * 32u;      // bit k = 1-based list position pos0 + k + 1
+                    const uint32_t pos0 = (uint32_t)bb * IR_BATCH + (uint32_t)w * 32u;      // bit k = 1-based list position pos0 + k + 1
                     if (pos0 + 32u <= 0xFFFFu) {                  // stored exactly by the reference's uint16 ids: the second pass finds them where they are
                         n_local += (uint32_t)__popc(u);
                         last_contributor = pos0 + 32u - (uint32_t)__clz((int)u);
@@ -190,21 +219,64 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
                         }
                     }
                 }
-                cm_tile[((size_t)bb * 8 + w) * TILE_PIX + tid] = word;
+                cm_tile[((size_t)bb * IR_WORDS + w) * TILE_PIX + tid] = word;
             }
             if (n_local >= (uint32_t)MAX_NUM_CONTRIBUTORS * 4) s_abort = 1u;      // the cap: this tile goes to the pixel-centric kernel
         }
-        if (all_done || b == nbatches) break;
+        if (n_live == 0 || b == nbatches) break;
 
-        // ---- staging: waves 0-3 the records, waves 4-7 the footprint conics ----
-        const int toDo = total - b * TILE_PIX;
-        const int n = min(TILE_PIX, toDo);
-        if (tid < (uint32_t)IR_EDGE0) {
-            const uint32_t e = tid & 255u;
-            const uint32_t k = range.x + (uint32_t)b * TILE_PIX + e;
+#if GOF_IR_COMPACT
+        // ---- compaction: the unfinished rays move to the lowest lanes when that empties at least one wave ----
+        if ((n_live + 63) / 64 < held_waves) {             // (workgroup-uniform)
+            s_T[ray] = T; s_maxt[ray] = maxt;              // park every held ray (a lane without one writes the unowned slot)
+            if (ray < (uint32_t)TILE_PIX) { s_C[0][ray] = C0; s_C[1][ray] = C1; s_C[2][ray] = C2; s_C[3][ray] = Calpha; }
+            const uint64_t live = __ballot(!done);
+            if ((tid & 63u) == 0u) s_wcount[tid >> 6] = (uint32_t)__popcll(live);
+            __syncthreads();                               // (the assembly above has read the masks)
+            // a ray nobody holds any more accepts nothing: its column stays zero from here on (all columns, by the threads that are left)
+            for (uint32_t c = tid; c < (uint32_t)IR_THREADS; c += 64u * (uint32_t)alive_waves)
+#pragma unroll
+                for (int w = 0; w < IR_WORDS; w++) s_rmask[w][c] = 0u;
+            uint32_t slot = (uint32_t)__popcll(live & ((1ull << (tid & 63u)) - 1ull));
+            for (uint32_t i = 0; i < (tid >> 6); i++) slot += s_wcount[i];
+            if (!done) s_list[slot] = (uint16_t)ray;
+            __syncthreads();
+            held_waves = (n_live + 63) / 64;
+#if GOF_IR_EXIT
+            alive_waves = max(IR_KEEP_WAVES, held_waves);
+            if ((int)(tid >> 6) >= alive_waves) return;                         // (whole waves; every ray they held is parked)
+#endif
+            if (tid < (uint32_t)n_live) {
+                ray = s_list[tid];
+                ray_of(ray, tx, ty, W, H, focal_x, focal_y, rx, ry);
+                T = s_T[ray]; maxt = s_maxt[ray];
+                if (ray < (uint32_t)TILE_PIX) { C0 = s_C[0][ray]; C1 = s_C[1][ray]; C2 = s_C[2][ray]; Calpha = s_C[3][ray]; }
+                done = false;
+            } else {
+                ray = IR_NO_RAY;
+                done = true;
+            }
+            if (tid == 0) ISTAT_ADD(5, 1);                 // [5] compactions
+        }
+#endif
+        const bool centre = ray < (uint32_t)TILE_PIX;
+        const f2 RX = { rx, rx }, RY = { ry, ry }, RXY = { rx, ry };
+        // evaluation-error margin of the unit-normalised conic in Horner form: blend_forward.hip (7 eps B derived, 1e-6 B carried)
+#ifndef GOF_INT_RAY_MARGIN
+#define GOF_INT_RAY_MARGIN 1e-6f
+#endif
+        const float cone_margin = GOF_INT_RAY_MARGIN * fmaxf(1.0f, fmaxf(rx * rx, ry * ry));
+        const f2 NEG_MARGIN = { -cone_margin, -cone_margin };
+
+        // ---- staging: threads 0 .. IR_BATCH - 1 the records, the next IR_BATCH the footprint conics ----
+        const int toDo = total - b * IR_BATCH;
+        const int n = min(IR_BATCH, toDo);
+        if (tid < 2u * IR_BATCH) {
+            const uint32_t e = tid & (uint32_t)(IR_BATCH - 1);
+            const uint32_t k = range.x + (uint32_t)b * IR_BATCH + e;
             if (k < range.y) {
                 const uint32_t id = gaussian_list[k];
-                if (centre) {
+                if (tid < (uint32_t)IR_BATCH) {
                     const float4* src = reinterpret_cast<const float4*>(&rec[id]);
                     const float4 a = src[0], bq = src[1], c = src[2], d = src[3];
                     s_rec[0][e] = f4{ a.x, a.y, a.y, a.w };
@@ -215,16 +287,17 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
                 } else {
                     const float4 m0 = fconic[2 * (size_t)id], m1 = fconic[2 * (size_t)id + 1];     // {m00, m01, m11, m02}, {m12, m22, ., .}
                     float* cf = reinterpret_cast<float*>(&s_cf[0][0]) + e;
-                    cf[0 * TILE_PIX] = m0.x; cf[1 * TILE_PIX] = 2.0f * m0.y; cf[2 * TILE_PIX] = m0.z;
-                    cf[3 * TILE_PIX] = 2.0f * m0.w; cf[4 * TILE_PIX] = 2.0f * m1.x; cf[5 * TILE_PIX] = m1.y;
+                    cf[0 * IR_BATCH] = m0.x; cf[1 * IR_BATCH] = 2.0f * m0.y; cf[2 * IR_BATCH] = m0.z;
+                    cf[3 * IR_BATCH] = 2.0f * m0.w; cf[4 * IR_BATCH] = 2.0f * m1.x; cf[5 * IR_BATCH] = m1.y;
                 }
             }
         }
         __syncthreads();                                   // (also: the assembly of batch b - 1 has read the masks)
         if (s_abort) break;
+        if (tid == 0) ISTAT_ADD(15, 1);
         const int nw = (n + 31) >> 5;
-        if (__ballot(!done) == 0ull) {                     // every ray of this wave is finished: "nothing accepted" for the batch
-            for (int w = 0; w < nw; w++) s_rmask[w][tid] = 0u;
+        if (__ballot(!done) == 0ull) {                     // every ray of this wave is finished (or it holds none): "nothing accepted" for the batch
+            for (int w = 0; w < nw; w++) s_rmask[w][ray] = 0u;
             continue;
         }
 
@@ -252,28 +325,32 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
             if (done) word = 0u;
 #ifdef GOF_CULL_AUDIT
             // developer-only audit build: the consumption walks EVERY entry and counts the pairs it accepts that the scan dropped ([11], must stay 0)
-            s_cand[w][tid] = word;
+            s_cand[w][ray] = word;
             word = done ? 0u : (valid < 32 ? (1u << valid) - 1u : 0xFFFFFFFFu);
 #endif
-            s_rmask[w][tid] = word;
+            s_rmask[w][ray] = word;
             if ((tid & 63u) == 0u) ISTAT_ADD(9, min(32, valid));             // [9] (wave, entry) pairs scanned
         }
 
-        // ---- phase 2: every lane consumes its own candidates in list order: forward.cu:921-975 for ONE sub-ray ----
+        // ---- phase 2: every lane consumes its ray's candidates in list order: forward.cu:921-975 for ONE sub-ray.  Written without
+        // branches around the arithmetic (the three `continue`s of the reference become one predicate): with ~40 rays per wave some lane
+        // takes every path anyway, and each divergent exit cost an exec-mask save / restore and a branch per trip ----
         int w = 0;
-        uint32_t cur = s_rmask[0][tid];
+        uint32_t cur = s_rmask[0][ray];
         uint32_t cbits = 0;                                // accepted bits of word w (flushed when w advances)
         for (;;) {
             const bool more = !done && (cur != 0u || w + 1 < nw);
             if (__ballot(more) == 0ull) break;
-            if ((tid & 63u) == 0u) ISTAT_ADD(8, 1);        // [8] wave trips of the candidate loop
-            if (!more) continue;
-            if (cur == 0u) { s_rmask[w][tid] = cbits; cbits = 0; w++; cur = s_rmask[w][tid]; }
-            if (cur == 0u) continue;
-            const int bit = __ffs((int)cur) - 1;
-            cur &= cur - 1u;
+#ifdef GOF_STATS
+            { const int live_now = __popcll(__ballot(!done)); if ((tid & 63u) == 0u) ISTAT_ADD(10, live_now); }       // [10] unfinished rays over the trips
+#endif
+            if ((tid & 63u) == 0u) { ISTAT_ADD(8, 1); ISTAT_ADD(tid < 256u ? 12 : (tid < 512u ? 13 : 14), 1); }      // [8] wave trips of the candidate loop; [12] / [13] / [14]: of waves 0-3, 4-7, 8
+            if (more && cur == 0u) { s_rmask[w][ray] = cbits; cbits = 0; w++; cur = s_rmask[w][ray]; }
+            const bool have = more && cur != 0u;
+            const int bit = have ? __ffs((int)cur) - 1 : 0;
+            cur &= cur - 1u;                               // (0 stays 0)
             const int j = w * 32 + bit;
-            ISTAT_ADD(6, 1);                               // [6] candidates popped (ray, entry)
+            if (have) ISTAT_ADD(6, 1);                     // [6] candidates popped (ray, entry)
             const f4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j];
             const f2 n01 = (q0.xy * RX + q0.zw * RY) + q1.xy;               // normal[0], normal[1]
             const f2 n2b = (q1.zw * RX + q2.xy * RY) + q2.zw;               // normal[2], BB / 2
@@ -284,34 +361,35 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
             // one IEEE division: -BB/(2*AA) == -(BB/AA)/2 and BB/4 are exact power-of-two scalings (forward.cu:927-931)
             const float q = BB / AA;
             const float t = -q * 0.5f;
-            if (t < 0.2f) continue;                        // (double)t <= NEAR_PLANE, see integrate_pixels_tile
             const double min_value = (double)(-q) * (double)(BB * 0.25f) + (double)CC;
             float power = -0.5f * (float)min_value;
             if (power > 0.0f) power = 0.0f;
             const float alpha = fminf(0.99f, wgt * gexpf<true>(power));
-            if (alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) continue;
+            // the reference's three exits (forward.cu:933, 949, 952), each in its own sense of the comparison (NaN falls through as there):
+            // (double)t <= NEAR_PLANE is t < 0.2f (see integrate_pixels_tile)
+            const bool ok = have & !(t < 0.2f) & !(alpha < 1.0f / 255.0f) & !(test_T < 0.0001f);
 #ifdef GOF_CULL_AUDIT
-            if (!((s_cand[w][tid] >> bit) & 1u)) ISTAT_ADD(11, 1);
+            if (ok && !((s_cand[w][ray] >> bit) & 1u)) ISTAT_ADD(11, 1);
 #endif
-            ISTAT_ADD(7, 1);                               // [7] accepted
+            if (ok) ISTAT_ADD(7, 1);                       // [7] accepted
             if (centre) {
-                C0 += q3.z * alpha * T;
-                C1 += q3.w * alpha * T;
-                C2 += s_blue[j] * alpha * T;
-                Calpha += alpha * T;
+                const float aT = alpha * T;
+                const float c0 = C0 + q3.z * alpha * T, c1 = C1 + q3.w * alpha * T, c2 = C2 + s_blue[j] * alpha * T, ca = Calpha + aT;
+                C0 = ok ? c0 : C0; C1 = ok ? c1 : C1; C2 = ok ? c2 : C2; Calpha = ok ? ca : Calpha;
             }
-            if (t > maxt) maxt = t;
-            T = test_T;
-            cbits |= 1u << bit;
-            if (T * (1 - 1.0f / 255.0f) < 0.0001f) done = true;              // nothing can be accepted any more
+            maxt = (ok && t > maxt) ? t : maxt;
+            T = ok ? test_T : T;
+            cbits |= ok ? 1u << bit : 0u;
+            if (ok && T * (1 - 1.0f / 255.0f) < 0.0001f) done = true;        // nothing can be accepted any more
         }
-        s_rmask[w][tid] = cbits;
-        for (int q = w + 1; q < nw; q++) s_rmask[q][tid] = 0u;               // candidate words this ray never reached (it finished)
+        s_rmask[w][ray] = cbits;
+        for (int q = w + 1; q < nw; q++) s_rmask[q][ray] = 0u;               // candidate words this ray never reached (it finished)
     }
 
-    s_maxt[tid] = maxt;
+    // results by ray number: every lane parks what it holds, the pixel threads collect
+    s_T[ray] = T; s_maxt[ray] = maxt;
+    if (ray < (uint32_t)TILE_PIX) { s_C[0][ray] = C0; s_C[1][ray] = C1; s_C[2][ray] = C2; s_C[3][ray] = Calpha; }
     __syncthreads();
     if (s_abort) {                                         // (workgroup-uniform)
         if (tid == 0) tile_cost[tile] = TILE_CAPPED;
@@ -321,17 +399,18 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
         const uint32_t px = tx * TILE_X + lx, py = ty * TILE_Y + ly;
         const uint32_t pix_id = (uint32_t)W * py + px;
         const size_t HW = (size_t)W * H;
-        const float depth = fmaxf(fmaxf(maxt, fmaxf(s_maxt[c00], s_maxt[c10])), fmaxf(s_maxt[c01], s_maxt[c11]));
-        final_T[pix_id] = T;
+        const float Tc = s_T[tid];
+        const float depth = fmaxf(fmaxf(s_maxt[tid], fmaxf(s_maxt[c00], s_maxt[c10])), fmaxf(s_maxt[c01], s_maxt[c11]));
+        final_T[pix_id] = Tc;
         n_contrib[pix_id] = last_contributor;
-        out_color[0 * HW + pix_id] = C0 + T * bg_color[0];
-        out_color[1 * HW + pix_id] = C1 + T * bg_color[1];
-        out_color[2 * HW + pix_id] = C2 + T * bg_color[2];
+        out_color[0 * HW + pix_id] = s_C[0][tid] + Tc * bg_color[0];
+        out_color[1 * HW + pix_id] = s_C[1][tid] + Tc * bg_color[1];
+        out_color[2 * HW + pix_id] = s_C[2][tid] + Tc * bg_color[2];
         out_color[6 * HW + pix_id] = depth;
-        out_color[7 * HW + pix_id] = Calpha;
+        out_color[7 * HW + pix_id] = s_C[3][tid];
     }
     // what the point pass will walk in this tile (the deepest contributor position of its pixels): part of its dispatch cost
-    if (centre) {
+    if (pixel_thread) {
         uint32_t m = inside ? last_contributor : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));

@@ -1,7 +1,8 @@
 """Audit of the forward blend's cull scan (library built with -DGOF_STATS -DGOF_CULL_AUDIT, lib/libgof_hip_audit.so, selected with
 GOF_HIP_LIB): the consumption walks EVERY list entry and counts the (pixel, entry) pairs the exact path accepts (t > 0.2 and
 alpha >= 1/255, before the pixel saturates) that the footprint-conic scan had not marked as candidates.  Prints one JSON line per
-scene: {"scene", "accepted_pairs", "candidates", "dropped_by_the_scan"} -- the last must be 0.
+scene: {"scene", "accepted_pairs", "candidates", "dropped_by_the_scan"} -- the last must be 0 -- and, since round 5, the same two counts
+for the ray-centric pixel pass of the opacity-field query ("integrate_accepted_pairs", "integrate_dropped_by_the_scan").
     GOF_HIP_LIB=.../libgof_hip_audit.so python tests/devtools/dev_cull_audit.py s1m stress_box ..."""
 import ctypes as C
 import json
@@ -37,4 +38,18 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         B.lib.gof_debug_fw_stats(out, 1)
         s = list(out)
-        print(json.dumps({"scene": name, "accepted_pairs": s[3], "candidates": s[1], "dropped_by_the_scan": s[6]}), flush=True)
+        row = {"scene": name, "accepted_pairs": s[3], "candidates": s[1], "dropped_by_the_scan": s[6]}
+        # round 5: the same audit of the opacity-field query's ray-centric pixel pass (integrate_rays: one ray per lane, the conic at the
+        # lane's own ray): [7] (ray, entry) pairs accepted, [11] of them outside the scan's candidates
+        if hasattr(B.lib, "gof_debug_int_stats"):
+            from diff_gaussian_rasterization import GaussianRasterizer
+            from gpu_common import settings_from
+            iout = (C.c_ulonglong * 16)()
+            B.lib.gof_debug_int_stats(iout, 1)
+            pts = sd["means3D"][:1000].contiguous()
+            GaussianRasterizer(settings_from(sd)).integrate(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"],
+                                                            scales=sd["scales"], rotations=sd["rotations"])
+            torch.cuda.synchronize()
+            B.lib.gof_debug_int_stats(iout, 1)
+            row["integrate_accepted_pairs"], row["integrate_dropped_by_the_scan"] = iout[7], iout[11]
+        print(json.dumps(row), flush=True)

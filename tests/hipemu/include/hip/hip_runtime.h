@@ -181,6 +181,8 @@ inline int hipemu_syncthreads_or(int p) { int r; hipemu::block_barrier(p, nullpt
 #define __syncthreads() hipemu_syncthreads()
 #define __syncthreads_and(p) hipemu_syncthreads_and(p)
 #define __syncthreads_or(p) hipemu_syncthreads_or(p)
+inline int hipemu_syncthreads_count(int p) { int r; hipemu::block_barrier_count(p, &r); return r; }
+#define __syncthreads_count(p) hipemu_syncthreads_count(p)
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 

@@ -15,8 +15,6 @@ typedef hipError_t cudaError_t;
 #define cudaSuccess hipSuccess
 #define cudaGetErrorString hipGetErrorString
 #define __trap abort
-inline int hipemu_syncthreads_count(int p) { int r; hipemu::block_barrier_count(p, &r); return r; }
-#define __syncthreads_count(p) hipemu_syncthreads_count(p)
 // what CUDA's headers give device code and a plain host compiler does not: float overloads of the C math functions in the global
 // namespace (exp(float) IS expf in the reference's kernels), mixed float / double min / max (resolved in double, as CUDA does),
 // double3, atomicAdd on a float with a double operand (converted, as CUDA's implicit conversion does)

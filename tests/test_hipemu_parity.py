@@ -140,6 +140,43 @@ def test_emulated_integrate_bit_exact(name):
     assert np.array_equal(bits(colp), bits(ocol))
 
 
+@pytest.mark.parametrize("which", ["at_the_cap", "below_the_cap"])
+def test_emulated_integrate_uint16_wrap_and_the_contributor_cap(which):
+    """lists beyond 65535 entries (the reference's uint16 contributor ids wrap, forward.cu:879, 983, 1145): a tile whose pixels meet the
+    1024-contributor cap -- the ray-centric pixel pass abandons it to the pixel-centric kernel -- and one that stays below it (the wrap
+    inside integrate_rays' assembly); both forms of the pixel pass, every output bit the oracle's"""
+    sc = TP.uint16_scene() if which == "at_the_cap" else TP.uint16_scene_below_the_cap()
+    pts = np.ascontiguousarray(S.tetra_points(sc)[::40], dtype=np.float32)
+    o = ob.OracleScene(sc)
+    oc, oal, ocol, orad = o.integrate(pts)
+    assert o.num_rendered() > 70_000 and (o.fetch("n_contrib").reshape(2, 16, 16)[0] > 65535).sum() >= 20
+    lib = E.load()
+    for mode in (0, 1):
+        prev = lib.gof_set_integrate_pixel_pass(mode)
+        try:
+            c, a, colp, rad = E.EmuScene(sc).integrate(pts)
+        finally:
+            lib.gof_set_integrate_pixel_pass(prev)
+        assert np.array_equal(rad, orad)
+        assert np.array_equal(bits(c), bits(oc)), (mode, [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)])
+        assert np.array_equal(bits(a), bits(oal)) and np.array_equal(bits(colp), bits(ocol)), mode
+
+
+@pytest.mark.parametrize("name", ["long_lists", "posed_stress_box", "strip_v"])
+def test_emulated_integrate_pixel_centric_form_gives_the_same_bits(name):
+    sc = TP.SCENES[name]()
+    pts = np.ascontiguousarray(S.tetra_points(sc)[:40_000], dtype=np.float32)
+    lib = E.load()
+    rays = E.EmuScene(sc).integrate(pts)
+    prev = lib.gof_set_integrate_pixel_pass(1)
+    try:
+        pix = E.EmuScene(sc).integrate(pts)
+    finally:
+        lib.gof_set_integrate_pixel_pass(prev)
+    for x, y in zip(rays, pix):
+        assert np.array_equal(bits(x), bits(y))
+
+
 def test_emulator_reports_divergent_cross_lane_use():
     """the emulator's own contract: lanes of one wave meeting at different cross-lane sites is an error it reports, not a silent
     mis-pairing (checked on the runtime directly: tests/hipemu/selftest.cpp)"""
@@ -259,7 +296,7 @@ def test_emulated_cull_audit_counts_no_dropped_pair():
     scenes = [TP.SCENES[k]() for k in ("stress_box", "posed_stress_box", "long_lists", "posed_long_lists", "posed_mod2", "posed_mod05_ks01", "small_ks01", "posed_ragged")]
     scenes += [TP._fuzz_scene(s) for s in range(24)]
     scenes.append(S.scene_frustum(40_000, W=320, H=208, focal=240.0, seed=7, sigma_px=0.4, zmin=5.0, zmax=80.0, pose_seed=9))     # far sub-pixel splats
-    total = 0
+    total = total_int = 0
     for sc in scenes:
         lib.gof_debug_fw_stats(out, 1)
         e = E.EmuScene(sc, lib=lib, exact=True)              # (the pairs the EXACT arithmetic accepts)
@@ -268,7 +305,14 @@ def test_emulated_cull_audit_counts_no_dropped_pair():
         s = list(out)
         assert s[6] == 0, ("pairs dropped by the cull scan", s[6], s[3])
         total += s[3]
-    assert total > 2_000_000          # accepted pairs examined
+        # round 5: the ray-centric pixel pass of the opacity-field query (integrate_rays: the conic at the lane's own ray)
+        iout = (C.c_ulonglong * 16)()
+        lib.gof_debug_int_stats(iout, 1)
+        e.integrate(np.ascontiguousarray(sc["means3D"][:500], dtype=np.float32))
+        lib.gof_debug_int_stats(iout, 1)
+        assert iout[11] == 0, ("(ray, entry) pairs dropped by integrate_rays' scan", iout[11], iout[7])
+        total_int += iout[7]
+    assert total > 2_000_000 and total_int > 2_000_000          # accepted pairs examined
 
 
 @pytest.mark.parametrize("order", ["reverse", "random:7"])

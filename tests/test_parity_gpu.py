@@ -522,6 +522,77 @@ def test_integrate_reproduces_the_uint16_contributor_ids_of_lists_beyond_65535_e
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
 
 
+def uint16_scene_below_the_cap():
+    """The same ~78 000-entry tile list, but only 6000 of its splats can reach alpha >= 1/255 (the others carry opacity 0.002): no
+    pixel meets the 1024-contributor cap, every pixel's contributors run past position 65535 -- the uint16 wrap inside the
+    RAY-centric pixel pass (integrate_rays' assembly; uint16_scene() is abandoned to the pixel-centric kernel at the cap)."""
+    sc = S.scene_frustum(80_000, W=16, H=16, focal=16.0, seed=21, sigma_px=0.25, zmin=2.0, zmax=4.0)
+    sc["opacities"][:] = 0.002
+    sc["opacities"][np.random.default_rng(5).choice(80_000, 6000, replace=False)] = 0.03
+    return sc
+
+
+class integrate_pixel_pass:
+    """with integrate_pixel_pass(1): ... -- the opacity-field query's pixel pass in its pixel-centric form (gof_set_integrate_pixel_pass,
+    include/gof_hip.h) for the calls inside; the previous form is restored."""
+
+    def __init__(self, mode, lib=None):
+        self.mode, self.lib = mode, lib
+
+    def __enter__(self):
+        if self.lib is None:
+            from diff_gaussian_rasterization import _backend as B
+            self.lib = B.lib
+        self.prev = self.lib.gof_set_integrate_pixel_pass(self.mode)
+
+    def __exit__(self, *exc):
+        self.lib.gof_set_integrate_pixel_pass(self.prev)
+
+
+def _integrate_outputs(sd, pts):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    r = GaussianRasterizer(settings_from(sd))
+    out = r.integrate(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in out]
+
+
+def test_integrate_uint16_wrap_below_the_cap_in_the_ray_centric_pass():
+    sc = uint16_scene_below_the_cap()
+    pts = np.ascontiguousarray(S.tetra_points(sc)[::40], dtype=np.float32)
+    o = ob.OracleScene(sc)
+    oc, oal, ocol, orad = o.integrate(pts)
+    last = o.fetch("n_contrib").reshape(2, 16, 16)[0]
+    assert o.num_rendered() > 70_000 and (last > 65535).sum() >= 200 and oc[7].max() < 0.9        # past the wrap, nowhere near the cap
+    sd = to_dev(sc)
+    for mode in (0, 1):
+        with integrate_pixel_pass(mode):
+            c, a, colp, radii = _integrate_outputs(sd, torch.from_numpy(pts).cuda())
+        assert np.array_equal(radii, orad)
+        assert np.array_equal(bits(c), bits(oc)), (mode, [int((bits(c[i]) != bits(oc[i])).sum()) for i in range(9)])
+        assert np.array_equal(bits(a), bits(oal)), (mode, int((bits(a) != bits(oal)).sum()))
+        assert np.array_equal(bits(colp), bits(ocol)), mode
+
+
+@pytest.mark.parametrize("name", ["long_lists", "ragged", "stress_box", "posed_clustered150k", "strip_v"])
+def test_integrate_pixel_centric_form_gives_the_ray_centric_forms_bits(name):
+    """gof_set_integrate_pixel_pass(1): the pixel pass of rounds 1-4 (thread = pixel, five sub-rays each) -- since round 5 the fallback
+    of the ray-centric pass at the 1024-contributor cap -- against the shipped form: every output bit, and the oracle's."""
+    sc = SCENES[name]()
+    pts = S.tetra_points(sc)
+    if len(pts) > 200_000:
+        pts = pts[np.random.default_rng(3).choice(len(pts), 200_000, replace=False)]
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    sd = to_dev(sc)
+    rays = _integrate_outputs(sd, torch.from_numpy(pts).cuda())
+    with integrate_pixel_pass(1):
+        pix = _integrate_outputs(sd, torch.from_numpy(pts).cuda())
+    for x, y in zip(rays, pix):
+        assert np.array_equal(bits(x), bits(y))
+    oc, oal, ocol, orad = ob.OracleScene(sc).integrate(pts)
+    assert np.array_equal(bits(pix[0]), bits(oc)) and np.array_equal(bits(pix[1]), bits(oal)) and np.array_equal(bits(pix[2]), bits(ocol))
+
+
 def test_fused_forward_matches_the_two_stage_forward_and_recovers_from_a_small_capacity():
     """gof_forward_fused (no mid-forward sync; binning workspace sized by a learnt capacity, device-side instance count):
     identical image / radii / state to the two-stage forward, gradients through the capacity-sized workspaces identical too,
@@ -1088,4 +1159,5 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     assert [x["scene"] for x in rows] == names
     for x in rows:
         assert x["dropped_by_the_scan"] == 0 and x["accepted_pairs"] > 0, x
+        assert x["integrate_dropped_by_the_scan"] == 0 and x["integrate_accepted_pairs"] > 0, x       # (round 5: integrate_rays' scan, one ray per lane)
     assert rows[0]["accepted_pairs"] > 100_000_000            # S1M: ~1.2e8 contributing pairs were examined
