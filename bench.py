@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-clustered", action="store_true", help="skip the heavy-tailed scene leg (S1M-clustered: what the tile scheduler is for)")
     ap.add_argument("--no-views", action="store_true", help="skip the leg that cycles 8 posed cameras inside its timed region")
     ap.add_argument("--no-reference", action="store_true", help="skip the leg that times the reference's own kernels (oracle/_ref) on this GPU")
+    ap.add_argument("--no-kernel-size-leg", action="store_true", help="skip the leg that times the headline scene with kernel_size 0.1")
+    ap.add_argument("--no-large-p", action="store_true", help="skip the multi-million-Gaussian legs (6M @ 1237x822, 5M @ 1600x1063: fwd+bwd and the full iteration)")
     return ap.parse_args()
 
 
@@ -257,6 +259,11 @@ def main():
             out["clustered"] = clustered_leg(dev, P, W, H, focal, args.kernel_size, out["ms_per_step"])
         if world == 1 and not args.no_views and P == 1_000_000:
             out["views"] = views_leg(dev, sc, out["ms_per_step"])
+        if world == 1 and not args.no_kernel_size_leg and P == 1_000_000 and args.kernel_size == 0.0:
+            import synthetic_scenes as S_
+            out["kernel_size_0p1"] = scene_leg(dev, S_.scene_frustum(P, W=W, H=H, focal=focal, seed=0, kernel_size=0.1), "S1M, kernel_size 0.1", out["ms_per_step"], steps=20, warmup=3)
+        if world == 1 and not args.no_large_p:
+            out["large_p"] = large_p_leg(dev, out["ms_per_step"])
         if world == 1 and not args.no_reference:
             out["reference_same_gpu"] = reference_leg(sd, dL, out["ms_per_step"])
         if world == 1 and not args.no_integrate:
@@ -447,6 +454,75 @@ def clustered_leg(dev, P, W, H, focal, kernel_size, s1m_ms, steps=20, warmup=3):
             "kernels_ms": {k: round(v["total_ms"] / max(1, v["calls"]), 4) for k, v in rep.items()}}
 
 
+def scene_leg(dev, sc, label, s1m_ms, steps=10, warmup=3, with_full_loop=False):
+    """fwd + bwd of one view of another synthetic scene through the autograd surface, OUTSIDE the headline's timed region: ms per step,
+    per-stage durations (the library's HIP events) with GB/s on SURVEY 8(d)'s algorithmic bytes, optionally the full training
+    iteration.  Used for `kernel_size_0p1` (BASELINE config 2 names kernel_size in {0.0, 0.1}: the 2D low-pass filter of
+    forward.cu:112-118 on the headline scene) and `large_p` (round 5: real captures hold millions of small Gaussians -- there
+    preprocess / SH / Adam traffic is the step, not the blends)."""
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    W, H, P = sc["W"], sc["H"], int(sc["means3D"].shape[0])
+    sd = to_dev(sc, dev)
+    params = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    rast = GaussianRasterizer(settings_from(sd))
+    dL = torch.randn((9, H, W), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        means2D.grad = None
+        color, _ = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                        scales=params["scales"], rotations=params["rotations"])
+        color.backward(dL)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    B.profile_enable(True)
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    rep = B.profile_report()
+    B.profile_enable(False)
+    st = stage_times(B, sd, dL, dev, rep, 4)
+    kern = {k: {kk: v[kk] for kk in ("avg_ms", "alg_MB", "GBps") if kk in v} for k, v in st["roofline"]["kernels"].items()}
+    for v in kern.values():
+        if "GBps" in v:
+            v["frac_of_8TBps"] = round(v["GBps"] / 8000.0, 3)
+    out = {"workload": "%s: %d Gaussians @ %dx%d, SH degree 3, kernel_size %.2f, fwd+bwd" % (label, P, W, H, sc["kernel_size"]),
+           "ms_per_step": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps, "num_rendered": st["R"],
+           "fwd_ms": round(st["fwd_ms"], 4), "bwd_ms": round(st["bwd_ms"], 4), "vs_s1m_ms_per_step": round(ms / s1m_ms, 3),
+           "workload_counts": st["roofline"]["workload"], "kernels": kern}
+    del params, means2D, rast
+    if with_full_loop:
+        fl = full_loop(sd, dev, W, H, steps=5, warmup=2)
+        out["full_loop"] = {k: fl[k] for k in ("ms_per_iter", "iters_per_s", "epilogue_kernels_ms", "adam_GBps") if k in fl}
+        out["full_loop"]["one_call_loss_split_sh_ms_per_iter"] = fl["one_call_loss_split_sh"]["ms_per_iter"]
+    del sd
+    torch.cuda.empty_cache()
+    return out
+
+
+def large_p_leg(dev, s1m_ms):
+    """Round 5: the regime of real scenes.  `bicycle_like`: 6M Gaussians at 1237x822 (Mip-NeRF360 bicycle, images_4: the resolution
+    of BASELINE config 3), median projected sigma 1.5 px; `s5m`: 5M Gaussians of the same size at the headline resolution."""
+    import synthetic_scenes as S
+    out = {}
+    for label, mk in (("bicycle_like_6M", lambda: S.scene_frustum(6_000_000, W=1237, H=822, focal=1237.0 * 0.75, seed=0, sigma_px=1.5)),
+                      ("s5m", lambda: S.scene_frustum(5_000_000, seed=0, sigma_px=1.5))):
+        try:
+            out[label] = scene_leg(dev, mk(), label, s1m_ms, steps=10, warmup=3, with_full_loop=True)
+        except Exception as e:      # an extra leg must never take the headline down
+            out[label] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def views_leg(dev, sc, s1m_ms, n_views=8, steps=40, warmup=8):
     """A training run renders a DIFFERENT camera every iteration (train.py:100-104): instance count (the sync-free forward's learnt
     capacity), tile costs and their order, L2 / MALL contents all change from step to step, where the headline renders one view over
@@ -520,7 +596,7 @@ def reference_leg(sd, dL, product_ms):
         return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
-def full_loop(sd, dev, W, H, steps=10, warmup=3):
+def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
     """SURVEY.md 8(d)(i) "full-loop variant": one complete training iteration of train.py:125-190, 263-265 on the same
     scene -- the parameter activations render() reads (scene/gaussian_model.py:157-194, HIP), rasterizer forward, the reference's loss
     (L1 + D-SSIM + depth-normal consistency + distortion), backward, Adam over the 59 floats per Gaussian -- with the
@@ -589,6 +665,8 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3):
         iteration()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    if only_inline:            # (tests/devtools/dev_full_loop_trace.py: a kernel trace of the unchanged train.py composition alone)
+        return {"ms_per_iter": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps}
     reset()
     for _ in range(warmup):
         iteration(True)

@@ -49,9 +49,15 @@ class forward_exact:
 # The forward blend's default mode (the reference's arithmetic without its two fp64 divisions per pair: csrc/gof_common.h,
 # pair_nodiv_cc) against the verification mode.  t, alpha and T are the exact arithmetic's up to a last bit of one pair in ~1e7, so:
 # every decision identical; colour / normal / depth / alpha channels and final_T bit-identical on all but a vanishing number of pixels
-# (measured: none anywhere, profiles/r04_forward_modes.md); the distortion channel, dist1 and dist2 carry the fp32 mapped depth's
-# 1-2 ulp: measured <= 2.5e-7 absolute, asserted at 2e-6 (mapped depth <= 1).
+# (measured: none anywhere: profiles/r05_parity_report.md, 36 scenes incl. S1M / posed / clustered at both kernel sizes); the
+# distortion channel, dist1 and dist2 carry the fp32 mapped depth's 1-2 ulp.  Measured on those 36 scenes (same report): channel 8
+# within 2.5e-7 ABSOLUTE everywhere, i.e. within 6.3e-5 of the channel's maximum on every scene whose distortion reaches 2e-3 (S1M:
+# 4.7e-5) -- north_star's "1e-4 relative" -- and up to 1.1e-3 of the maximum on the four scenes whose distortion is itself below 8e-4
+# (lego10k, tiny, posed_tiny, sub_tile): the channel is a cancelling sum m^2 A + dist2 - 2 m dist1 of O(alpha) terms
+# (forward.cu:553), so one fp32 ulp of a term (6e-8) is a fixed absolute, not a relative, quantity.  Asserted accordingly: channel 8
+# within max(1e-4 x the channel's maximum, 3e-7 absolute); everything else within FAST_MODE_TOL.
 FAST_MODE_TOL = 2e-6
+FAST_MODE_CH8_REL, FAST_MODE_CH8_ABS = 1e-4, 3e-7
 
 
 def assert_fast_mode_matches_exact(fast, exact):
@@ -72,6 +78,9 @@ def assert_fast_mode_matches_exact(fast, exact):
         if differ.any():
             assert np.isfinite(a[differ]).all() and np.isfinite(b[differ]).all(), ("channel", ch, "a non-finite value differs")
             d = np.abs(a[differ].astype(np.float64) - b[differ])
+            if ch == 8:
+                ch_max = float(np.abs(b[np.isfinite(b)]).max())
+                assert d.max() <= max(FAST_MODE_CH8_REL * ch_max, FAST_MODE_CH8_ABS), ("distortion channel", float(d.max()), ch_max)
             scale = 1.0 if ch == 8 else max(1.0, float(np.abs(b[np.isfinite(b)]).max()))
             assert d.max() <= FAST_MODE_TOL * scale, ("channel", ch, float(d.max()), scale)
     tf, tx = np.asarray(fast["final_T"], np.float32), np.asarray(exact["final_T"], np.float32)

@@ -983,10 +983,12 @@ def test_integrate_config5_gaussian_count_against_oracle():
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
 
 
-def test_full_size_s1m_against_oracle():
-    """BASELINE config 2 at FULL size (1M Gaussians, 1600x1063) against the oracle on the GPU box's host cores:
-    forward bit-exact (normals 2e-6), blend gradients within 1e-4."""
-    sc = S.scene_frustum(1_000_000, seed=0)
+@pytest.mark.parametrize("kernel_size", [0.0, 0.1])
+def test_full_size_s1m_against_oracle(kernel_size):
+    """BASELINE config 2 at FULL size (1M Gaussians, 1600x1063; both kernel sizes the configuration names: 0.0 and the 2D low-pass
+    filter of forward.cu:112-118 at 0.1) against the oracle on the GPU box's host cores: forward bit-exact (normals 2e-6), blend
+    gradients within 1e-4."""
+    sc = S.scene_frustum(1_000_000, seed=0, kernel_size=kernel_size)
     o, oc, orad, res = _forward_pair(sc)
     assert res["R"] == o.num_rendered() and np.array_equal(res["radii"].cpu().numpy(), orad)
     assert _same(fetch(res, "point_list"), o.fetch("point_list"))
