@@ -20,6 +20,7 @@ namespace gof {
 
 // ---- kernels / helpers defined in the other translation units -------------------------------------
 
+template <int MODE>
 __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                                const float* rotations, const float* opacities, const float* shs, const float* shs_rest, const float* cov3D_precomp,
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
@@ -451,11 +452,23 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     if (a->prefiltered) GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));   // only then written and read
     { GOF_PROFILE("preprocess_fwd", stream);
-    hipLaunchKernelGGL(preprocess_fwd, dim3((a->P + 255) / 256), dim3(256), 0, stream,
-                       a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,
-                       a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,
-                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, (a->prefiltered ? 1 : 0) | (g_tight_rects.load(std::memory_order_relaxed) ? 2 : 0), radii, g.depths, g.rec, g.conic, g.bbox, g.fconic,
-                       g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags); }
+    // SH rows through the LDS (preprocess.hip, modes 1 / 2: one aligned [P,16,3] tensor / the (_features_dc, _features_rest) pair): built in
+    // round 5 and measured SLOWER than the per-thread reads (S1M 0.122 vs 0.110 ms, 6M Gaussians 0.648 vs 0.588 ms: 50 KB of LDS leave
+    // three workgroups per CU and two more barriers; profiles/r05_ab_call4_preprocess_fwd.txt) -- compiled in only with -DGOF_K1_TILED=1
+#ifndef GOF_K1_TILED
+#define GOF_K1_TILED 0
+#endif
+    const int k1_mode = (!GOF_K1_TILED || a->colors_precomp) ? 0 : (a->shs_rest ? 2 : ((a->shs && a->M == 16 && (reinterpret_cast<uintptr_t>(a->shs) & 15) == 0) ? 1 : 0));
+#define GOF_K1_LAUNCH(MODE) hipLaunchKernelGGL(preprocess_fwd<MODE>, dim3((a->P + 255) / 256), dim3(256), 0, stream,                                        \
+                       a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,                          \
+                       a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,                             \
+                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, (a->prefiltered ? 1 : 0) | (g_tight_rects.load(std::memory_order_relaxed) ? 2 : 0), \
+                       radii, g.depths, g.rec, g.conic, g.bbox, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags)
+    if (k1_mode == 2) GOF_K1_LAUNCH(2);
+    else if (k1_mode == 1) GOF_K1_LAUNCH(1);
+    else GOF_K1_LAUNCH(0);
+#undef GOF_K1_LAUNCH
+    }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);

@@ -403,6 +403,36 @@ int gof_add_densification_stats(int64_t P, const float* viewspace_grad, const ui
     return GOF_OK;
 }
 
+// Y[i][n] = sum_j A[i][j] X[j][n] over n < N, A = the 3x3 block at M (element (i, j) at M[i * rs + j * cs]; transposed: (j, i)).
+// train.py:177-179 rotates the rendered normals into world space with `c2w[:3, :3] @ render_normal.reshape(3, -1)`: torch hands that
+// 3 x 3 x 1.7M product to a GEMM library (128 us forward + 125 us backward on MI355X: a tile shape built for large K); it is 40 MB
+// of streaming -- one launch of this kernel each way (train_epilogue/pose.py: SmallMatrix.__matmul__).
+__global__ void __launch_bounds__(256)
+rot3_apply_kernel(int64_t N, const float* __restrict__ M, int rs, int cs, int transpose, const float* __restrict__ X, float* __restrict__ Y)
+{
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) a[i][j] = transpose ? M[j * rs + i * cs] : M[i * rs + j * cs];
+    const float x0 = X[n], x1 = X[N + n], x2 = X[2 * N + n];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Y[(int64_t)i * N + n] = fmaf(a[i][2], x2, fmaf(a[i][1], x1, a[i][0] * x0));
+}
+int gof_rot3_apply(int64_t N, const float* M, int32_t row_stride, int32_t col_stride, int32_t transpose, const float* X, float* Y, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N < 0) { set_error("bad number of columns"); return GOF_E_INVALID; }
+    if (N == 0) return GOF_OK;
+    if (!M || !X || !Y) { set_error("rot3_apply: a pointer is NULL"); return GOF_E_INVALID; }
+    GOF_PROFILE("rot3_apply", stream);
+    hipLaunchKernelGGL(rot3_apply_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, M, (int)row_stride, (int)col_stride, (int)transpose, X, Y);
+    GOF_LAUNCH_CHECK(stream, 0);
+    return GOF_OK;
+}
+
 #define GOF_ACT_ENTRY(NAME, KERNEL, NULLCHECK, ...)                                                                  \
     {                                                                                                                \
         hipStream_t stream = static_cast<hipStream_t>(stream_);                                                      \

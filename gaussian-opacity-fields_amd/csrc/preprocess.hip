@@ -135,14 +135,17 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
 // zfront: a point of the level-set ellipsoid has view depth >= mu_z - sqrt(k / l_min) (Mahalanobis^2 >= l_min * dz^2), so a
 // query point whose depth (the clamp of t in integrate's point pass, forward.cu:1172-1178) is below zfront cannot reach
 // alpha >= 1/255 from this Gaussian; -1e30 = no statement.
-__device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float w, float focal_x, float focal_y, int W, int H, float4* fc)
+// (round 5, cost: this function was ~45 % of preprocess_fwd's 670 fp64 instructions, and the kernel is bound by them, not by HBM: the
+// level m0 from the fp32 logarithm -- its ~1e-6 relative error is 1e-5 of the 0.05 the level carries for exactly such things --, the
+// three 1 / l_c taken as s_c^2 + 1e-7, which is what l_c is the reciprocal of (`var_*`), and one reciprocal for the four box edges)
+__device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float w, float focal_x, float focal_y, int W, int H, float4* fc, double var_x, double var_y, double var_z)
 {
     fc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     fc[1] = make_float4(0.f, 0.f, 0.f, -1e30f);
     const float4 unbounded = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);
     const float4 empty = make_float4(1e30f, -1e30f, 1e30f, -1e30f);
     if (!(w > 0.0f)) return empty;                                  // alpha <= 0 < 1/255 everywhere
-    const double m0 = 2.0 * log(255.0 * (double)w);
+    const double m0 = 2.0 * (double)logf(255.0f * w);
     if (!(m0 > -0.05)) return empty;                                // w < 1/255: can never reach the threshold
     const double lx = I.Sx, ly = I.Sy, lz = I.Sz;                   // eigenvalues of Sigma' = 1 / (s^2 + 1e-7)
     const double lmax = fmax(lx, fmax(ly, lz)), lmin = fmin(lx, fmin(ly, lz));
@@ -169,7 +172,7 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     // view-space covariance Cov = A diag(1/l) A^T with A = Rt^T (rows of Rt are the Gaussian axes in view space):
     // Cov_ij = sum_c Rt[i][c] * Rt[j][c] / l_c   (Rt.m[col][row] = G2V[row][col])
     const M3& Rt = I.Rt;
-    const double ix = 1.0 / lx, iy = 1.0 / ly, iz = 1.0 / lz;
+    const double ix = var_x, iy = var_y, iz = var_z;       // 1 / l_c up to the rounding of l_c's own division
     // A = G2V 3x3 block: A[r][c] = Rt.m[r][c]?  Rt = mk3(G00,G10,G20, G01,G11,G21, G02,G12,G22) -> Rt.m[c][r] = G2V.m[r][c],
     // and G2V.m[c][r] is row r of the matrix A applied to column c, i.e. A[r][c] = G2V.m[c][r] = Rt.m[r][c].
     const double a00 = Rt.m[0][0], a01 = Rt.m[0][1], a02 = Rt.m[0][2];
@@ -207,14 +210,25 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     if (!(Dx >= 0.0) || !(Dy >= 0.0)) return unbounded;
     const double sx = sqrt(Dx), sy = sqrt(Dy);
     const double cx = mx * mz - Sxz, cy = my * mz - Syz;
-    const double u0 = (cx - sx) / czz, u1 = (cx + sx) / czz;
-    const double v0 = (cy - sy) / czz, v1 = (cy + sy) / czz;
+    const double iczz = 1.0 / czz;                     // (the edges are widened by 0.02 px below: an ulp of a product is nothing against that)
+    const double u0 = (cx - sx) * iczz, u1 = (cx + sx) * iczz;
+    const double v0 = (cy - sy) * iczz, v1 = (cy + sy) * iczz;
     // ray of pixel p: r = (p + 0.5 - W/2) / focal  ->  p = r * focal + W/2 - 0.5; widen by 0.02 px for the fp32 ray
     const double px0 = u0 * (double)focal_x + W / 2. - 0.5 - 0.02, px1 = u1 * (double)focal_x + W / 2. - 0.5 + 0.02;
     const double py0 = v0 * (double)focal_y + H / 2. - 0.5 - 0.02, py1 = v1 * (double)focal_y + H / 2. - 0.5 + 0.02;
     return make_float4((float)fmax(-1e9, ceil(px0)), (float)fmin(1e9, floor(px1)), (float)fmax(-1e9, ceil(py0)), (float)fmin(1e9, floor(py1)));
 }
 
+// SH rows of the workgroup's 256 Gaussians staged through the LDS (K1 and K9): one coefficient row per thread, 48 floats padded to 49
+// words (conflict-free per-thread reads); the global reads are 16-byte loads over the block's contiguous rows instead of 48 dword
+// loads per thread at a 192-byte stride (64 cache lines per load instruction: the address units, not the bytes, bounded K1 --
+// 3.4 TB/s on its algorithmic bytes until round 4)
+constexpr int K9_ROW = 49;
+
+// MODE 0: coefficients read per thread from global memory (any M, unaligned tensors, colors_precomp); 1: shs is one 16-byte aligned
+// [P,16,3] tensor; 2: shs = _features_dc [P,1,3], shs_rest = _features_rest [P,15,3] (GofRasterArgs.shs_rest) -- both through the LDS.
+// Only the rows of Gaussians that survive the culls are loaded, and only the coefficients the active degree reads.
+template <int MODE>
 #ifdef GOF_PRE_WAVES
 __attribute__((amdgpu_waves_per_eu(GOF_PRE_WAVES, 8)))
 #endif
@@ -232,22 +246,29 @@ preprocess_fwd(int P, int D, int M,
                uint2* __restrict__ rect_out, uint8_t* __restrict__ clamped,
                uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags)
 {
+    constexpr bool TILED = MODE != 0;
+    __shared__ float s_sh[TILED ? 256 * K9_ROW : 1];
+    __shared__ uint64_t s_vis[4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    const bool live = idx < P;
     int32_t my_radii = 0;
     uint32_t my_tiles = 0;
     uint2 my_rect = make_uint2(0u, 0u);
 
-    const V3 p_orig = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
-    const V3 p_view = transform_point_4x3(p_orig, cam.view);
-    // near cull only (auxiliary.h:189): the lateral frustum test is commented out in the reference
-    if (p_view.z <= 0.2f) {
-        if (mode_bits & 1) atomicOr(&flags[0], 1u);
-        radii[idx] = 0; tiles_touched[idx] = 0; rect_out[idx] = make_uint2(0u, 0u);
-        depth_key[idx] = 0xFFFFFFFFu; depth_val[idx] = (uint32_t)idx;
-        return;
-    }
-    do {
+    // ---- part 1: the culls (near plane, degenerate 2D covariance, empty tile rectangle) and everything they need ----
+    bool vis = false;
+    V3 p_orig = { 0, 0, 0 }, p_view = { 0, 0, 1 }, scale = { 0, 0, 0 };
+    float4 rot = { 0, 0, 0, 0 };
+    float coef = 0, conx = 0, cony = 0, conz = 0, my_radius = 0, pix = 0, piy = 0;
+    uint32_t minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (live) do {
+        p_orig = V3{ means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+        p_view = transform_point_4x3(p_orig, cam.view);
+        // near cull only (auxiliary.h:189): the lateral frustum test is commented out in the reference
+        if (p_view.z <= 0.2f) {
+            if (mode_bits & 1) atomicOr(&flags[0], 1u);
+            break;
+        }
         const float* pm = cam.proj;
         const float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
         const float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
@@ -255,8 +276,6 @@ preprocess_fwd(int P, int D, int M,
         const float p_w = 1.0f / (hw + 0.0000001f);
         const float projx = hx * p_w, projy = hy * p_w;
 
-        V3 scale = { 0, 0, 0 };
-        float4 rot = { 0, 0, 0, 0 };
         if (scales) scale = V3{ scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
         if (rotations) rot = reinterpret_cast<const float4*>(rotations)[idx];
 
@@ -295,32 +314,90 @@ preprocess_fwd(int P, int D, int M,
         M3 cov = mul(mul(transpose(T), transpose(Vrk)), T);
         const float det_0 = (float)fmax(1e-6, (double)(cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1]));
         const float det_1 = (float)fmax(1e-6, (double)((cov.m[0][0] + kernel_size) * (cov.m[1][1] + kernel_size) - cov.m[0][1] * cov.m[0][1]));
-        float coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+        coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
         if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = 0.0f;
         const float covx = cov.m[0][0] + kernel_size, covy = cov.m[0][1], covz = cov.m[1][1] + kernel_size;
 
         const float det = (covx * covz - covy * covy);
         if (det == 0.0f) break;
         const float det_inv = 1.f / det;
-        const float conx = covz * det_inv, cony = -covy * det_inv, conz = covx * det_inv;
+        conx = covz * det_inv; cony = -covy * det_inv; conz = covx * det_inv;
 
         const float mid = 0.5f * (covx + covz);
         const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
         const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-        const float pix = (float)((((double)projx + 1.0) * W - 1.0) * 0.5);
-        const float piy = (float)((((double)projy + 1.0) * H - 1.0) * 0.5);
-        uint32_t minx, miny, maxx, maxy;
+        my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        pix = (float)((((double)projx + 1.0) * W - 1.0) * 0.5);
+        piy = (float)((((double)projy + 1.0) * H - 1.0) * 0.5);
         get_rect(pix, piy, (int)my_radius, minx, miny, maxx, maxy, gx, gy);
         if ((maxx - minx) * (maxy - miny) == 0) break;
+        vis = true;
+    } while (0);
 
+    // ---- the surviving Gaussians' SH rows: global -> LDS, 16 bytes per lane, consecutive lanes consecutive addresses ----
+    const float* my_row = nullptr;
+    if (TILED) {
+        const uint64_t wv = __ballot(vis);
+        if ((threadIdx.x & 63u) == 0u) s_vis[threadIdx.x >> 6] = wv;
+        __syncthreads();
+        const int b0 = blockIdx.x * 256;
+        const int rows = min(256, P - b0);
+        const int nco = 3 * (D + 1) * (D + 1);                     // floats of a row the active degree reads (forward.cu:20-71)
+        auto row_visible = [&](int g) { return (s_vis[g >> 6] >> (g & 63)) & 1ull; };
+        if (MODE == 1) {
+            const float4* src = reinterpret_cast<const float4*>(shs + (size_t)b0 * 48);
+            for (int i = threadIdx.x; i < rows * 12; i += 256) {
+                const int f = i * 4, g = f / 48, k = f - g * 48;
+                if (k >= nco || !row_visible(g)) continue;
+                const float4 v = src[i];
+                float* d = &s_sh[g * K9_ROW + k];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            const float* dc = shs + (size_t)b0 * 3;
+            for (int i = threadIdx.x; i < rows * 3; i += 256) {
+                const int g = i / 3, k = i - g * 3;
+                if (row_visible(g)) s_sh[g * K9_ROW + k] = dc[i];
+            }
+            if (nco > 3) {
+                const float* rest = shs_rest + (size_t)b0 * 45;
+                const int n4 = (reinterpret_cast<uintptr_t>(rest) & 15) ? 0 : (rows * 45) >> 2;       // 16-byte loads when the tensor allows
+                const float4* src = reinterpret_cast<const float4*>(rest);
+                for (int i = threadIdx.x; i < n4; i += 256) {
+                    const int f0 = i * 4, g0 = f0 / 45, g1 = (f0 + 3) / 45;           // a 16-byte group may straddle two rows
+                    if ((!row_visible(g0) && !row_visible(g1)) || (f0 - g0 * 45 + 3 >= nco && g1 == g0)) continue;
+                    const float4 v = src[i];
+                    const float q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int f = f0 + e, g = f / 45, k = f - g * 45;
+                        s_sh[g * K9_ROW + 3 + k] = q[e];
+                    }
+                }
+                for (int f = n4 * 4 + threadIdx.x; f < rows * 45; f += 256) {
+                    const int g = f / 45, k = f - g * 45;
+                    if (row_visible(g)) s_sh[g * K9_ROW + 3 + k] = rest[f];
+                }
+            }
+        }
+        __syncthreads();
+        my_row = &s_sh[threadIdx.x * K9_ROW];
+    }
+
+    // ---- part 2: colour, view2gaussian, footprint, the record ----
+    if (vis) {
         SplatRec r;
         uint32_t cb = 0;
         if (colors_precomp == nullptr) {
             const V3 campos = { cam.campos[0], cam.campos[1], cam.campos[2] };
-            const float* sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
-            const float* shp = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
-            const V3 rgb = sh_to_rgb(D, p_orig, campos, sh0, shp, cb);
+            V3 rgb;
+            if (TILED) {
+                rgb = sh_to_rgb(D, p_orig, campos, my_row, my_row, cb);
+            } else {
+                const float* sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
+                const float* shp = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
+                rgb = sh_to_rgb(D, p_orig, campos, sh0, shp, cb);
+            }
             r.f[REC_RGB] = rgb.x; r.f[REC_RGB + 1] = rgb.y; r.f[REC_RGB + 2] = rgb.z;
         } else {
             r.f[REC_RGB] = colors_precomp[3 * (size_t)idx]; r.f[REC_RGB + 1] = colors_precomp[3 * (size_t)idx + 1]; r.f[REC_RGB + 2] = colors_precomp[3 * (size_t)idx + 2];
@@ -334,7 +411,8 @@ preprocess_fwd(int P, int D, int M,
             v2g_intermediates(scale, p_orig, rot, cam.view, I);
             const V3 t2 = I.t2;
             const double C = (double)(t2.x * t2.x) * I.Sx + (double)(t2.y * t2.y) * I.Sy + (double)(t2.z * t2.z) * I.Sz;
-            box = footprint_bbox(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H, fc);
+            box = footprint_bbox(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H, fc,      // (s_c^2 + 1e-7: the doubles v2g_intermediates divides by)
+                                 (double)scale.x * scale.x + 1e-7, (double)scale.y * scale.y + 1e-7, (double)scale.z * scale.z + 1e-7);
             const V3 B = mul(t2, I.SR);
             const M3 Sigma = mul(transpose(I.Rt), I.SR);
             r.f[0] = Sigma.m[0][0]; r.f[1] = Sigma.m[0][1]; r.f[2] = Sigma.m[0][2];
@@ -376,7 +454,8 @@ preprocess_fwd(int P, int D, int M,
         }
         my_tiles = (maxy - miny) * (maxx - minx);
         my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
-    } while (0);
+    }
+    if (!live) return;
     radii[idx] = my_radii;
     tiles_touched[idx] = my_tiles;
     rect_out[idx] = my_rect;
@@ -384,6 +463,15 @@ preprocess_fwd(int P, int D, int M,
     depth_key[idx] = my_radii > 0 ? __float_as_uint(p_view.z) : 0xFFFFFFFFu;
     depth_val[idx] = (uint32_t)idx;
 }
+template __global__ void preprocess_fwd<0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
+                                           const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
+                                           float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void preprocess_fwd<1>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
+                                           const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
+                                           float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void preprocess_fwd<2>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
+                                           const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
+                                           float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
 
 // ---------------------------------------------------------------------------------------------------
 // K9: backward of the per-Gaussian stage (backward.cu:593-631): view2gaussian backward
@@ -486,7 +574,6 @@ __device__ __forceinline__ void sh_backward(int deg, V3 pos, V3 campos, const fl
 // moves its 256 x 192 B tile through LDS with fully coalesced 16-byte accesses (rows padded to 49 floats: conflict-free), each
 // thread works on its own LDS row, and culled Gaussians / coefficients above the active degree leave zeros in the tile -- so the
 // host skips the 192 B/Gaussian memset of dL_dsh as well.
-constexpr int K9_ROW = 49;
 // MODE 0: rows read / written in place; 1: TILED; 2: TILED with DC and higher bands in separate tensors (shs = [P,1,3],
 // shs_rest = [P,15,3] and the same for the gradient): the LDS row is columns 0-2 | 3-47 of the two tiles.
 template <int MODE>

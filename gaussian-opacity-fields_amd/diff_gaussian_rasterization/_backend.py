@@ -231,16 +231,20 @@ class MaskPoolTooSmall(RuntimeError):
 
 
 def _exchange_starts_inside_backward():
-    """A data-parallel reducer starts its all-gather from inside the backward (set_sh_grad_ready_callback): a backward that had to
-    be repeated would come after the colour gradient has gone on the wire, and a read-back in front of the backward would idle the
-    GPU on every rank and step -- such frames get WORST-CASE pools instead (118 B per instance as in rounds 2-3, nothing to verify)."""
+    """A data-parallel reducer starts its all-gather from inside the backward (set_sh_grad_ready_callback), right after the blend
+    stage.  Until round 4 such frames ran on WORST-CASE pools (118 B per instance): a backward repeated after the colour gradient
+    has gone on the wire would be wrong, and a read-back in front of the backward idles every rank's GPU.  Round 5: the same
+    optimistic pools as on one GPU -- the blend stage is queued, the host then looks at the FORWARD's counters (on their way to pinned
+    memory since the forward's last kernel; the GPU is busy with the blend meanwhile), repeats the blend stage if its record pool was
+    too small (or raises MaskPoolTooSmall: forward again), and only then hands the colour gradient to the reducer
+    (rasterize_gaussians_backward)."""
     return _sh_track["on"] and _sh_track["ready_cb"] is not None
 
 
 def _mask_pool_subchunks(shape_key):
     """sub-chunks to size the fused forward's mask pool for: 1.25 x the largest request seen for this shape (None: not learnt yet,
     or switched off -> the worst case)"""
-    need = None if (FULL_MASK_POOL or _exchange_starts_inside_backward()) else _mask_need.get(shape_key)
+    need = None if FULL_MASK_POOL else _mask_need.get(shape_key)
     return None if need is None else int(need * 1.25) + 256
 _pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
 
@@ -318,7 +322,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 pin = _pinned[str(v.device)] = torch.zeros(4, dtype=torch.int32).pin_memory()
             # the frame's pool counters go to pinned host memory at the end of the forward (stored by its last kernel: no copy launch),
             # an event behind the call tells the backward when they are there (optimistic pools, rasterize_gaussians_backward)
-            no_counters = (FULL_MASK_POOL and FULL_BACKWARD_SCRATCH) or _exchange_starts_inside_backward()
+            no_counters = FULL_MASK_POOL and FULL_BACKWARD_SCRATCH
             words = None if no_counters else (_usage_free.pop() if _usage_free else torch.empty(USAGE_WORDS, dtype=torch.int32).pin_memory())      # (pinning costs tens of microseconds: recycled)
             rc = lib.gof_forward_fused(v.ref(), cap, _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
                                        _ptr(radii), _ptr(out_color), C.c_void_p(pin.data_ptr()), None if words is None else C.c_void_p(words.data_ptr()), _stream())
@@ -404,13 +408,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             full_pool = binningBuffer.numel() >= lib.gof_binning_bytes(int(R), W, H)
             staged_guess = _staged_need.get(shape_key)
             verify = None
-            early_exchange = _exchange_starts_inside_backward() and M > 0
-            if (FULL_BACKWARD_SCRATCH or early_exchange) and full_pool:
+            if FULL_BACKWARD_SCRATCH and full_pool:
                 nscratch = lib.gof_backward_scratch_bytes(P, int(R))          # a record per instance, a full mask pool: nothing can be missing
-            elif usage is not None and staged_guess is not None and not FULL_BACKWARD_SCRATCH and not early_exchange:
-                # (not when a data-parallel reducer starts its exchange from inside this backward: a repeated backward would come after
-                # the colour gradient has gone on the wire -- such a frame has worst-case pools (branch above) or, if its forward
-                # ran before the reducer was switched on, asks first)
+            elif usage is not None and staged_guess is not None and not FULL_BACKWARD_SCRATCH:
                 rec_guess = min(int(R), int(staged_guess * 1.25) + 4096)
                 nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), rec_guess)
                 verify = (usage, rec_guess)
@@ -423,7 +423,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _staged_need[shape_key] = max(_staged_need.get(shape_key, 0), staged)
                 if requested > held:
                     raise MaskPoolTooSmall(requested, held)
-                nscratch = lib.gof_backward_scratch_bytes(P, int(R)) if (FULL_BACKWARD_SCRATCH or early_exchange) else lib.gof_backward_scratch_bytes_for(P, int(R), staged)
+                nscratch = lib.gof_backward_scratch_bytes(P, int(R)) if FULL_BACKWARD_SCRATCH else lib.gof_backward_scratch_bytes_for(P, int(R), staged)
             scratch = v.bytes_tensor(nscratch) if nscratch else None
             call = (v.ref(), int(R), _ptr(radii), _ptr(geomBuffer), geomBuffer.numel(), _ptr(binningBuffer),
                     binningBuffer.numel(), _ptr(imageBuffer), imageBuffer.numel(), _ptr(dl),
@@ -436,14 +436,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _sh_track["count"] += 1
                 src = _sh_track["src"] = {"dL_dcolors": g_colors, "geom": geomBuffer, "radii": radii, "means3D": v.keep["means3D"],
                                           "campos": v.keep["campos"], "degree": int(degree), "M": M, "P": P}
-            if track and _sh_track["ready_cb"] is not None:
-                # the colour gradient is final after the blend stage: let the data-parallel reducer start its exchange while
-                # preprocess_bwd is still to run (dp/reducer.py)
-                _check(lib.gof_backward_blend(*call))
-                _sh_track["ready_cb"](src)
-                _check(lib.gof_backward_preprocess(*call))
-            else:
-                _check(lib.gof_backward(*call))
+            early = track and _sh_track["ready_cb"] is not None
+            # (a data-parallel reducer takes the colour gradient right after the blend stage, while preprocess_bwd is still to run
+            # (dp/reducer.py): only the blend stage is queued here, the rest follows behind the verification below)
+            _check((lib.gof_backward_blend if early else lib.gof_backward)(*call))
             if verify is not None:
                 (words, ev), rec_guess = verify
                 ev.synchronize()                      # the FORWARD's counters (long there: the GPU is busy with the backward just queued)
@@ -460,12 +456,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                         _sh_track["count"] -= 1
                         _sh_track["src"] = None
                     raise MaskPoolTooSmall(requested, held)
-                if staged > rec_guess:                # records were dropped: the same backward again, with room for all of them
+                if staged > rec_guess:                # records were dropped: the same backward (stage) again, with room for all of them
                     _stats["record_pool_redone_backwards"] += 1
                     nscratch = lib.gof_backward_scratch_bytes_for(P, int(R), staged)
                     scratch = v.bytes_tensor(nscratch)
                     call = call[:-3] + (_ptr(scratch), nscratch, _stream())
-                    _check(lib.gof_backward(*call))
+                    _check((lib.gof_backward_blend if early else lib.gof_backward)(*call))
+            if early:
+                # the colour gradient is final and verified: the reducer starts its exchange, preprocess_bwd runs beside it
+                _sh_track["ready_cb"](src)
+                _check(lib.gof_backward_preprocess(*call))
     return g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_v2g
 
 

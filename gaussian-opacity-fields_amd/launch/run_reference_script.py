@@ -17,7 +17,9 @@ What it does, in this order (nothing in the reference checkout is edited):
      optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups) and
      GaussianModel.compute_3D_filter (scene/gaussian_model.py:262-311, one launch over points x cameras) and
      GaussianModel.densify_and_prune (:685-707: device index lists + one row gather per tensor; GOF_TORCH_DENSIFY=1 keeps the reference's).
-     GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations;
+     GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations; scene.cameras.Camera.world_view_transform becomes a
+     train_epilogue.PoseMatrix (train.py:177-179: `.T.inverse()` computed once per camera, `c2w[:3, :3] @ normals` one streaming
+     launch instead of a GEMM; GOF_PLAIN_POSE=1 keeps the plain tensor);
   5. wraps gaussian_renderer.integrate (imported by name at extract_mesh.py:5) so that the Gaussian side of the opacity-field
      query (binning + pixel pass) runs once per view for the ~10 point sets extract_mesh.py queries against the unchanged model
      (diff_gaussian_rasterization.integrate_view_key; GOF_INTEGRATE_CACHE_GB bounds the HBM it may keep, 0 disables);
@@ -51,6 +53,20 @@ def rebind_train_epilogue():
         ref_depth.depths_to_points = T.depths_to_points
     except ImportError:
         pass
+    # train.py:177-179 inverts the camera pose and multiplies its 3x3 block with the normal image every iteration: the Camera's
+    # world_view_transform becomes a tensor that remembers its inverse and applies the block with one streaming launch
+    # (train_epilogue/pose.py); GOF_PLAIN_POSE=1 keeps the plain tensor
+    if os.environ.get("GOF_PLAIN_POSE") != "1":
+        try:
+            import scene.cameras as ref_cameras
+            _cam_init = ref_cameras.Camera.__init__
+
+            def _camera_init(self, *a, **k):
+                _cam_init(self, *a, **k)
+                self.world_view_transform = T.PoseMatrix.wrap(self.world_view_transform)
+            ref_cameras.Camera.__init__ = _camera_init
+        except Exception:
+            pass
     try:
         from scene.gaussian_model import GaussianModel
     except Exception:

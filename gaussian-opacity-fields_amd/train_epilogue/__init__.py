@@ -8,3 +8,4 @@ from .optim import FusedAdam                             # noqa: F401
 from .filter_3d import compute_3D_filter, filter_3d, camera_table, add_densification_stats   # noqa: F401
 from . import activations                                # noqa: F401,E402
 from .densify import densify_and_prune                  # noqa: F401,E402
+from .pose import PoseMatrix, SmallMatrix                # noqa: F401,E402

@@ -39,6 +39,8 @@ def _declare():
     lib.gof_train_loss_scratch_bytes.argtypes = [i32, i32]
     lib.gof_train_loss.argtypes = [i32, i32, vp, vp, W11, vp, f32, f32, C.c_double, C.c_double, C.c_double, vp, vp, vp, sz, vp]
     lib.gof_train_loss.restype = C.c_int
+    lib.gof_rot3_apply.argtypes = [C.c_int64, vp, i32, i32, i32, vp, vp, vp]
+    lib.gof_rot3_apply.restype = C.c_int
     for n in ("gof_ssim_forward", "gof_ssim_backward", "gof_depth_to_normal", "gof_depth_to_normal_backward", "gof_adam_step"):
         getattr(lib, n).restype = C.c_int
 
@@ -112,6 +114,16 @@ def depth_to_normal_backward(depth_hw, wvt, fx, fy, g_normals, g_points):
     with _same_device(depth_hw, wvt, g_normals, g_points):
         _check(lib.gof_depth_to_normal_backward(W, H, depth_hw.data_ptr(), wvt.data_ptr(), fx, fy, g_normals.data_ptr(),
                                                 g_points.data_ptr() if g_points is not None else None, out.data_ptr(), _stream()))
+    return out
+
+
+def rot3_apply(m33, x, transpose=False):
+    """Y [3,N] = A X, A = the 3x3 (possibly strided) float32 view m33, or its transpose (include/gof_train_hip.h: gof_rot3_apply)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    with _same_device(m33, x):
+        _check(lib.gof_rot3_apply(int(x.shape[1]), m33.data_ptr(), int(m33.stride(0)), int(m33.stride(1)), 1 if transpose else 0,
+                                  x.data_ptr(), out.data_ptr(), _stream()))
     return out
 
 

@@ -163,6 +163,12 @@ int gof_act_opacity_backward(int64_t P, const float* raw_opacity, const float* r
 int gof_act_rotation(int64_t P, const float* raw_rotation, float* out, void* stream);
 int gof_act_rotation_backward(int64_t P, const float* raw_rotation, const float* grad_out, float* grad_raw_rotation, void* stream);
 
+/* ---- train.py:177-179, `c2w[:3, :3] @ render_normal.reshape(3, -1)`: a 3x3 matrix applied to the columns of X [3, N] ----------
+ * Y [3, N] = A X with A(i, j) = M[i * row_stride + j * col_stride] (device memory; transpose != 0: A(i, j) = M[j * row_stride +
+ * i * col_stride], the backward w.r.t. X).  One streaming launch where torch's matmul runs a GEMM of tile shape 256x16x16 on a K = 3
+ * product (128 us each way at 1600x1063 on MI355X).  Bound by the launcher through train_epilogue.pose.SmallMatrix. */
+int gof_rot3_apply(int64_t N, const float* M, int32_t row_stride, int32_t col_stride, int32_t transpose, const float* X, float* Y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,8 +150,9 @@ def _worker_rccl(port, ret):
     for k in names:
         if not torch.equal(params[k].grad, local[k]):
             msg.append("dense: %s changed" % k)
-    # frames whose backward starts the exchange get worst-case pools (nothing to verify, nothing to repeat after the colour gradient
-    # has gone on the wire): no synchronising read-back in front of the backward on the sync-free forward's frames either
+    # frames whose backward starts the exchange run on the same optimistic pools as on one GPU (round 5): the blend stage is verified
+    # against the forward's counters BEFORE the colour gradient is handed to the reducer, so nothing is ever repeated after it has gone
+    # on the wire -- and there is no synchronising read-back in front of the backward on the sync-free forward's frames
     if not B._exchange_starts_inside_backward():
         msg.append("the reducer's ready-callback is not installed")
     q0 = B._stats["backward_queries"]
@@ -162,6 +163,9 @@ def _worker_rccl(port, ret):
     torch.cuda.synchronize()
     if B._stats["backward_queries"] != q0:
         msg.append("%d read-backs in front of backwards that start the exchange" % (B._stats["backward_queries"] - q0))
+    key = [k for k in B._capacity if k[1] == sd["means3D"].shape[0]]
+    if not key or B._mask_pool_subchunks(key[0]) is None:
+        msg.append("the frames of a data-parallel step still run on a worst-case mask pool")
     red._early = []
     B._sh_track.update(count=0, src=None)
     # packed fallback (gradients that are separate allocations), averaged: still the identity at one rank

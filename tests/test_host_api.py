@@ -97,3 +97,24 @@ def test_num_rendered_is_the_count_and_carries_the_layout_size():
     m = B.NumRendered(123)
     assert m.layout == 123 and B._layout_count(m) == 123 and B._layout_count(77) == 77       # a plain int (two-stage path, C callers) is its own layout
     assert B._round_capacity(8_837_593) >= int(8_837_593 * 1.25) and B._round_capacity(0) == 1 << 16
+
+
+def test_pose_matrix_remembers_its_inverse_and_is_a_plain_tensor_otherwise():
+    """train_epilogue.PoseMatrix (what the launcher makes of Camera.world_view_transform): train.py:177-179's `.T.inverse()` is
+    computed once and again after an in-place edit; `c2w[:3, :3] @ X` gives torch's product (on the host: torch's own matmul -- the
+    streaming kernel is for device tensors, tests/test_train_epilogue_gpu.py); every other operation returns plain tensors."""
+    import train_epilogue as T
+    g = torch.Generator().manual_seed(3)
+    w = torch.eye(4)
+    w[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    w[3, :3] = torch.tensor([0.3, -1.0, 2.0])
+    p = T.PoseMatrix.wrap(w.clone())
+    assert isinstance(p, torch.Tensor) and torch.equal(p, w) and T.PoseMatrix.wrap(p) is p
+    c2w = p.T.inverse()                                                     # train.py:177
+    assert torch.equal(c2w, w.T.inverse()) and p.T.inverse() is c2w       # the same object: nothing is recomputed
+    x = torch.randn(3, 5000, generator=g)
+    assert torch.equal(c2w[:3, :3] @ x, w.T.inverse()[:3, :3] @ x)         # :178
+    for r in (p + 1, p[:3, :3], p.T @ p, p.T.contiguous(), c2w * 2, torch.stack([p, p])):
+        assert type(r) is torch.Tensor
+    p.mul_(1.0)                                                             # an in-place edit invalidates the remembered inverse
+    assert p.T.inverse() is not c2w and torch.equal(p.T.inverse(), c2w)

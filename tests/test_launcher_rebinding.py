@@ -44,10 +44,15 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
     assert all(isinstance(v, property) for v in props.values())          # they are properties in the reference too
     orig = {"ssim": ref_loss.ssim, "l1": ref_loss.l1_loss, "d2n": ref_depth.depth_to_normal, "d2p": ref_depth.depths_to_points,
             "setup": GaussianModel.training_setup, "f3d": GaussianModel.compute_3D_filter, "stats": GaussianModel.add_densification_stats}
+    import scene.cameras as ref_cameras
+    orig["camera_init"] = ref_cameras.Camera.__init__
     L = _load_launcher()
     L.rebind_train_epilogue()
     import train_epilogue as T
     try:
+        # Camera.world_view_transform -> train_epilogue.PoseMatrix (train.py:177-179): the constructor is wrapped, its signature kept
+        assert ref_cameras.Camera.__init__ is not orig["camera_init"]
+        assert "world_view_transform" in inspect.getsource(orig["camera_init"])              # the attribute the wrapper replaces exists in the reference
         assert ref_loss.l1_loss is T.l1_loss and ref_loss.ssim is T.ssim and ref_depth.depth_to_normal is T.depth_to_normal and ref_depth.depths_to_points is T.depths_to_points
         assert GaussianModel.compute_3D_filter is T.compute_3D_filter and GaussianModel.add_densification_stats is T.add_densification_stats
         assert GaussianModel.training_setup is not orig["setup"]
@@ -68,6 +73,7 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
                          (T.compute_3D_filter, orig["f3d"]), (T.add_densification_stats, orig["stats"])):
             assert list(inspect.signature(new).parameters) == list(inspect.signature(old).parameters), (new, old)
     finally:
+        ref_cameras.Camera.__init__ = orig["camera_init"]
         ref_loss.ssim, ref_loss.l1_loss, ref_depth.depth_to_normal, ref_depth.depths_to_points = orig["ssim"], orig["l1"], orig["d2n"], orig["d2p"]
         GaussianModel.training_setup, GaussianModel.compute_3D_filter, GaussianModel.add_densification_stats = orig["setup"], orig["f3d"], orig["stats"]
         for k_, v_ in props.items():

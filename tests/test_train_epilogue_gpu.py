@@ -134,6 +134,39 @@ def test_depth_to_normal_matches_oracle(W, H):
         assert np.all(n == 0)
 
 
+@pytest.mark.parametrize("N", [4096, 1600 * 1063, 100003])
+def test_pose_matrix_block_applied_to_the_normal_image_matches_float64(N):
+    """train.py:177-179 with the launcher's PoseMatrix: c2w = (world_view_transform.T).inverse(); c2w[:3, :3] @ normals [3, N] runs
+    gof_rot3_apply (one streaming launch each way) -- forward and the gradient w.r.t. the normals against float64, 3 fp32 ulps of the
+    largest term (a dot product of three terms; torch's own GEMM is held to the same bar beside it)."""
+    import train_epilogue as T
+    g = torch.Generator().manual_seed(N)
+    w = torch.eye(4)
+    w[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    w[3, :3] = torch.randn(3, generator=g)
+    x = torch.randn(3, N, generator=g)
+    gy = torch.randn(3, N, generator=g)
+    a64 = np.linalg.inv(w.numpy().astype(np.float64).T)[:3, :3]
+    pose = T.PoseMatrix.wrap(w.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    c2w = pose.T.inverse()
+    assert type(c2w) is T.SmallMatrix and pose.T.inverse() is c2w
+    from diff_gaussian_rasterization import _backend as RB
+    RB.profile_enable(True)
+    y = c2w[:3, :3] @ xd
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    rep = RB.profile_report(); RB.profile_enable(False)
+    assert rep["rot3_apply"]["calls"] == 2                                  # the streaming kernel ran, forward and backward
+    _close(y.detach().cpu().numpy(), a64 @ x.numpy().astype(np.float64), 4e-7, "c2w[:3,:3] @ normals")
+    _close(xd.grad.cpu().numpy(), a64.T @ gy.numpy().astype(np.float64), 4e-7, "gradient w.r.t. the normals")
+    xt = x.to(DEV).requires_grad_(True)                                      # torch's product of the same operands
+    yt = w.to(DEV).T.inverse()[:3, :3] @ xt
+    yt.backward(gy.to(DEV))
+    _close(yt.detach().cpu().numpy(), y.detach().cpu().numpy(), 4e-7, "vs torch matmul")
+    _close(xt.grad.cpu().numpy(), xd.grad.cpu().numpy(), 4e-7, "vs torch matmul, gradient")
+
+
 def test_train_loss_composition_matches_oracle():
     """train.py:150-186 composed from the product mirrors (GPU) and from the oracle (CPU): loss and d loss / d rendering."""
     import train_epilogue as T
