@@ -36,7 +36,8 @@ KERNEL_SOURCES = {
     "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_rects": "binning.hip",
     "point_keys": "binning.hip", "gather_sorted_points": "binning.hip",
     "os_hist": "radix.hip", "os_pass": "radix.hip", "rs_hist": "radix.hip", "rs_scatter": "radix.hip", "scan_block": "radix.hip",
-    "integrate_pixels": "integrate.hip", "integrate_points": "integrate.hip",
+    "integrate_pixels": "integrate.hip", "integrate_points": "integrate.hip", "integrate_rays": "integrate.hip", "integrate_pixels_capped": "integrate.hip",
+    "rot3_apply_kernel": "gaussian_model_ops.hip",
 }
 SHARED_HEADERS = ("gof_common.h", "gof_status.h")
 

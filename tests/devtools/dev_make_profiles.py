@@ -93,7 +93,7 @@ json.dump(data, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_s1m.json" % 
 md = os.path.join(ROOT, "profiles", "%s_bench_s1m_kernel_stats_%s.md" % (rnd, tag))
 with open(md, "w") as o:
     o.write("# rocprofv3 summaries, round %s, kernels of commit-state '%s' (blend kernel sources sha16 %s)\n\n" % (rnd[1:], tag, data["_kernel_sha16"]))
-    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop --no-clustered --no-views --no-reference`\n"
+    o.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop --no-clustered --no-views --no-reference --no-kernel-size-leg --no-large-p`\n"
             "(S1M: 1M Gaussians, 1600x1063, R = 8 837 593)\n\n")
     o.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -122,7 +122,7 @@ with open(md, "w") as o:
     o.write("\n## VALU instruction mix of the blend kernels (SQ_INSTS_VALU_* pass)\n\n| kernel | " + " | ".join(
         n.replace("SQ_INSTS_VALU_", "") for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
                                                  "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) + " |\n|---|" + "---|" * 8 + "\n")
-    for k in ("blend_forward", "blend_backward", "integrate_pixels", "integrate_points"):
+    for k in ("blend_forward", "blend_backward", "integrate_rays", "integrate_pixels", "integrate_points"):
         c = data.get(k, {}).get("counters", {})
         if c.get("SQ_INSTS_VALU_ADD_F32") is not None:
             o.write("| %s | " % k + " | ".join("%.3e" % c.get(n, 0) for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
