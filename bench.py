@@ -23,7 +23,7 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 
-PMC_FILE = "r04_pmc_traffic_s1m.json"
+PMC_FILE = "r05_pmc_traffic_s1m.json"
 FLOP_PER_PAIR_FWD = 85       # forward.cu:504-575 per contributing pair
 FLOP_PER_PAIR_BWD = 190      # backward.cu:771-952 per contributing pair, incl. its 19 accumulating adds
 
@@ -252,6 +252,10 @@ def main():
                                # all-reduce (compute stream waiting for the communication stream), expand = SH expansion kernel,
                                # bucket_pack / bucket_unpack = copies of gradients outside the rasterizer's allocation (none here)
                                "per_rank_phases_ms": exchange_phases,
+                               # optimistic pools on the data-parallel path (round 5): frames of rank 0 that had to be repeated because a
+                               # pool sized from earlier frames was too small (forward again / blend stage again), and synchronising
+                               # read-backs in front of a backward (the first frame of the shape only)
+                               "pools_rank0": {k: B._stats[k] for k in ("mask_pool_redone_frames", "record_pool_redone_backwards", "backward_queries", "fused_redone_frames")},
                                "what": "exposed time of GradientAllReducer.all_reduce() per step (max over ranks), from stream events around it; "
                                        "the all-gather of the colour gradient starts inside the backward and overlaps preprocess_bwd"}
         if world == 1 and not args.no_full_loop:
