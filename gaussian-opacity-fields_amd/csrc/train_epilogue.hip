@@ -454,20 +454,31 @@ adam_kernel(AdamArgs a, float w1, float beta2, float w2, float eps)
     const uint64_t start = (uint64_t)(blockIdx.x - b0) * ADAM_BLOCK_ELEMS;
     const bool vec = ((((uintptr_t)t.param) | ((uintptr_t)t.grad) | ((uintptr_t)t.exp_avg) | ((uintptr_t)t.exp_avg_sq)) & 15) == 0;
     if (vec && start + ADAM_BLOCK_ELEMS <= t.n) {
+        // all sixteen 16-byte loads of the thread first, then the arithmetic and the twelve stores: the four tensors come through
+        // plain pointers of a struct (they may alias as far as the compiler knows), so a store of one iteration kept the loads of the
+        // next behind it -- 64 bytes per lane in flight instead of 256 (round 5: 5.0 -> see profiles/r05_*; same bits)
+        float4 p[4], g[4], m[4], v[4];
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const uint64_t i = start + (uint64_t)(it * 256 + threadIdx.x) * 4;
-            float4 p = *reinterpret_cast<const float4*>(t.param + i);
-            const float4 g = *reinterpret_cast<const float4*>(t.grad + i);
-            float4 m = *reinterpret_cast<const float4*>(t.exp_avg + i);
-            float4 v = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
-            adam_one(p.x, g.x, m.x, v.x, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            adam_one(p.y, g.y, m.y, v.y, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            adam_one(p.z, g.z, m.z, v.z, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            adam_one(p.w, g.w, m.w, v.w, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            *reinterpret_cast<float4*>(t.param + i) = p;
-            *reinterpret_cast<float4*>(t.exp_avg + i) = m;
-            *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v;
+            p[it] = *reinterpret_cast<const float4*>(t.param + i);
+            g[it] = *reinterpret_cast<const float4*>(t.grad + i);
+            m[it] = *reinterpret_cast<const float4*>(t.exp_avg + i);
+            v[it] = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            adam_one(p[it].x, g[it].x, m[it].x, v[it].x, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
+            adam_one(p[it].y, g[it].y, m[it].y, v[it].y, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
+            adam_one(p[it].z, g[it].z, m[it].z, v[it].z, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
+            adam_one(p[it].w, g[it].w, m[it].w, v[it].w, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const uint64_t i = start + (uint64_t)(it * 256 + threadIdx.x) * 4;
+            *reinterpret_cast<float4*>(t.param + i) = p[it];
+            *reinterpret_cast<float4*>(t.exp_avg + i) = m[it];
+            *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v[it];
         }
     } else {
         for (uint64_t i = start + threadIdx.x; i < start + ADAM_BLOCK_ELEMS && i < t.n; i += 256) {
