@@ -32,7 +32,7 @@ FLOP_PER_PAIR_BWD = 190      # backward.cu:771-952 per contributing pair, incl. 
 KERNEL_SOURCES = {
     "blend_forward": "blend_forward.hip", "blend_forward_exact": "blend_forward.hip",
     "blend_backward": "blend_backward.hip", "gather_tile_partials": "blend_backward.hip",
-    "preprocess_fwd": "preprocess.hip", "preprocess_bwd": "preprocess.hip", "preprocess_points": "preprocess.hip",
+    "preprocess_fwd": "preprocess.hip", "preprocess_fwd_heavy": "preprocess.hip", "preprocess_bwd": "preprocess.hip", "preprocess_points": "preprocess.hip",
     "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_rects": "binning.hip",
     "point_keys": "binning.hip", "gather_sorted_points": "binning.hip",
     "os_hist": "radix.hip", "os_pass": "radix.hip", "rs_hist": "radix.hip", "rs_scatter": "radix.hip", "scan_block": "radix.hip",
@@ -316,6 +316,12 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
     # bytes this design moves on top of 8(d)'s list: the contributor masks (1 bit per pixel and visited entry = 32 B per entry),
     # written by the forward, read by the backward, and the 32 B footprint conic per entry the forward's cull scan reads
     extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": (32 + 72) * r_staged_bwd}   # masks read; partial record + slot word written
+    if "preprocess_fwd_heavy" in kernel_times:
+        # round 5: the sync-free forward runs the per-Gaussian kernel in two stages -- "preprocess_fwd" = the culls + what binning reads
+        # (40 B read, 24 B written per Gaussian), "preprocess_fwd_heavy" = the rest (8(d)'s 355 B less those 24) on a second stream
+        # BESIDE the binning chain: its time is not part of the forward's critical path (fwd_ms below leaves it out)
+        alg_bytes["preprocess_fwd"] = P * 64
+        alg_bytes["preprocess_fwd_heavy"] = P * (236 + 119 - 24)
     kernels = {}
     for name, rec in kernel_times.items():
         avg_ms = rec["total_ms"] / max(1, rec["calls"])

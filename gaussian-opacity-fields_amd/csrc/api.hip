@@ -20,7 +20,7 @@ namespace gof {
 
 // ---- kernels / helpers defined in the other translation units -------------------------------------
 
-template <int MODE>
+template <int MODE, int STAGE>
 __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                                const float* rotations, const float* opacities, const float* shs, const float* shs_rest, const float* cov3D_precomp,
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
@@ -444,14 +444,52 @@ size_t gof_binning_bytes_for(uint32_t R, int32_t W, int32_t H, uint32_t mask_sub
 size_t gof_point_binning_bytes(uint32_t NI, int32_t W, int32_t H) { return bin_layout(NI, W, H, nullptr, nullptr, BIN_POINTS) + ALIGN; }
 size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullptr, nullptr) + ALIGN; }
 
+// ---- a second stream per (thread, device) for the part of the per-Gaussian stage that binning does not wait for ----------------------
+// preprocess_fwd is bound by its fp64 arithmetic at four waves per SIMD, and only the blend reads what most
+// of it writes: the sync-free forward runs the culls + binning inputs first (stage 1), then the rest (stage 2) on this stream beside
+// the depth sort, scan, emission, tile sort and ranges, and the caller's stream waits for it in front of the blend.  The fork and the
+// join are events between the two streams: to the caller (and to torch's caching allocator) everything stays ordered on ITS stream.
+// GOF_K1_SPLIT=0 in the environment keeps the one-kernel form.
+namespace {
+struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
+AuxStream* aux_stream()
+{
+    static const bool enabled = [] { const char* e = getenv("GOF_K1_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!enabled) return nullptr;
+    static thread_local AuxStream per_device[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    AuxStream& a = per_device[dev];
+    if (a.failed) return nullptr;
+    if (!a.fork) {
+        // lowest priority: the binning chain on the caller's stream is the critical path (a chain of short, latency-bound launches);
+        // stage 2 should take the execution slots they leave, not the other way round
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        static const int prio_env = [] { const char* e = getenv("GOF_K1_SPLIT_PRIORITY"); return e ? atoi(e) : 0x7fffffff; }();      // (developer A/B)
+        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, prio_env == 0x7fffffff ? least : prio_env) != hipSuccess || hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); a.failed = true; return nullptr; }
+    }
+    return &a;
+}
+// makes `stream` wait for the second stream's work of this call: explicitly in front of the first consumer, and on every other way out
+struct AuxJoin {
+    hipStream_t stream = nullptr;
+    hipEvent_t pending = nullptr;
+    void now() { if (pending) { (void)hipStreamWaitEvent(stream, pending, 0); pending = nullptr; } }
+    ~AuxJoin() { now(); }
+};
+}
+
 // preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
+// join (nullable): the caller can take stage 2 of the per-Gaussian kernel on the second stream; it must call join->now() in front of
+// the first launch that reads the records / conics / footprints / depths / clamp flags
 static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream,
-                          uint32_t* total_host_mapped = nullptr)
+                          uint32_t* total_host_mapped = nullptr, AuxJoin* join = nullptr)
 {
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     if (a->prefiltered) GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));   // only then written and read
-    { GOF_PROFILE("preprocess_fwd", stream);
     // SH rows through the LDS (preprocess.hip, modes 1 / 2: one aligned [P,16,3] tensor / the (_features_dc, _features_rest) pair): built in
     // round 5 and measured SLOWER than the per-thread reads (S1M 0.122 vs 0.110 ms, 6M Gaussians 0.648 vs 0.588 ms: 50 KB of LDS leave
     // three workgroups per CU and two more barriers; profiles/r05_ab_call4_preprocess_fwd.txt) -- compiled in only with -DGOF_K1_TILED=1
@@ -459,16 +497,34 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
 #define GOF_K1_TILED 0
 #endif
     const int k1_mode = (!GOF_K1_TILED || a->colors_precomp) ? 0 : (a->shs_rest ? 2 : ((a->shs && a->M == 16 && (reinterpret_cast<uintptr_t>(a->shs) & 15) == 0) ? 1 : 0));
-#define GOF_K1_LAUNCH(MODE) hipLaunchKernelGGL(preprocess_fwd<MODE>, dim3((a->P + 255) / 256), dim3(256), 0, stream,                                        \
+    const int k1_bits = (a->prefiltered ? 1 : 0) | (g_tight_rects.load(std::memory_order_relaxed) ? 2 : 0);
+#define GOF_K1_LAUNCH(MODE, STAGE, STREAM) hipLaunchKernelGGL((preprocess_fwd<MODE, STAGE>), dim3((a->P + 255) / 256), dim3(256), 0, STREAM,                 \
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,                          \
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,                             \
-                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, (a->prefiltered ? 1 : 0) | (g_tight_rects.load(std::memory_order_relaxed) ? 2 : 0), \
+                       d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, k1_bits,                                                                             \
                        radii, g.depths, g.rec, g.conic, g.bbox, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags)
-    if (k1_mode == 2) GOF_K1_LAUNCH(2);
-    else if (k1_mode == 1) GOF_K1_LAUNCH(1);
-    else GOF_K1_LAUNCH(0);
-#undef GOF_K1_LAUNCH
+    // (tight tile rectangles take their tiles_touched from stage 2's footprint box: one kernel then)
+    AuxStream* const aux = (join && k1_mode == 0 && !(k1_bits & 2) && !a->debug) ? aux_stream() : nullptr;
+    { GOF_PROFILE("preprocess_fwd", stream);
+    if (aux) GOF_K1_LAUNCH(0, 1, stream);
+    else if (k1_mode == 2) GOF_K1_LAUNCH(2, 0, stream);
+    else if (k1_mode == 1) GOF_K1_LAUNCH(1, 0, stream);
+    else GOF_K1_LAUNCH(0, 0, stream); }
+    // (measured, profiles/r05_ab_call5_split_preprocess.txt: S1M 2.459 -> 2.434 ms per step, 6M Gaussians 4.18 -> 4.13, means over three
+    // boxes each -- the two streams share the CUs, the depth sort runs 0.108 -> 0.166 ms beside stage 2; forking BEHIND the depth sort
+    // instead loses: 2.468 / 4.18.  The device offers no priority below the caller's stream's to put stage 2 on.)
+    if (aux) {
+        GOF_HIP_CHECK(hipGetLastError());
+        GOF_HIP_CHECK(hipEventRecord(aux->fork, stream));
+        GOF_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+        { GOF_PROFILE("preprocess_fwd_heavy", aux->s);
+          GOF_K1_LAUNCH(0, 2, aux->s); }
+        GOF_HIP_CHECK(hipGetLastError());
+        GOF_HIP_CHECK(hipEventRecord(aux->join, aux->s));
+        join->stream = stream;
+        join->pending = aux->join;
     }
+#undef GOF_K1_LAUNCH
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
@@ -555,7 +611,8 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     uint32_t* const count_mapped = device_view_of_pinned(num_rendered_pinned_host);
     uint32_t* const usage_mapped = device_view_of_pinned(usage_pinned_host);
     *num_rendered_pinned_host = 0xFFFFFFFFu;
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream, count_mapped);
+    AuxJoin heavy;                       // (its destructor joins on every way out of this call)
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream, count_mapped, &heavy);
     if (rc) return rc;
     static thread_local hipEvent_t ev = nullptr;
     if (!ev) GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -567,6 +624,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     } else {
         hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr);
     }
+    heavy.now();                         // records, conics and footprints are stage 2's: the blend is their first reader
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
     order_tiles_for_backward(d, im, stream, usage_mapped);
