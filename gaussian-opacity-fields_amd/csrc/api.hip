@@ -95,8 +95,8 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, int acc_min, uint32_t gx, uint32_t ntiles,
                                  const uint32_t* tile_order, uint32_t* tile_queue);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
-__global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, uint32_t* minxy_sorted, uint32_t* wh_sorted, uint32_t* counts,
-                             const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
+__global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, const uint32_t* keys_sorted, uint32_t* minxy_sorted, uint32_t* wh_sorted,
+                             uint32_t* counts, const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float4* pos, float2* pt_ray, float* pt_depth, int W, int H,
                                      float focal_x, float focal_y);
 
@@ -527,8 +527,8 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
 #undef GOF_K1_LAUNCH
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
+    uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
-    uint32_t *kr = nullptr, *vr = nullptr;
     GOF_HIP_CHECK(radix_sort_pairs_u32(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream));
     if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
     GOF_LAUNCH_CHECK(stream, a->debug);
@@ -536,7 +536,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     { GOF_PROFILE("scan_tiles", stream);
     // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
     // scanned in place
-    hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, g.dkey_b, g.dval_b, g.order_off,
+    hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b, g.order_off,
                        radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles);
     GOF_HIP_CHECK(device_scan_u32_to_host(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
                                           total_dev_out, stream, total_host_mapped)); }

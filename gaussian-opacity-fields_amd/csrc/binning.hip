@@ -37,9 +37,9 @@ uint32_t higher_msb(uint32_t n)
 // tile rectangle preprocess_fwd packed): the rectangle words, and the instance count for the scan.  (Gathering tiles_touched in
 // both scan passes and radii + the record's pixel position again in the emission cost three 64-byte sectors per Gaussian.)
 __global__ void __launch_bounds__(256)
-gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, uint32_t* __restrict__ minxy_sorted,
-             uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ counts, const uint32_t* __restrict__ sort_error,
-             uint2* __restrict__ ranges, uint32_t ntiles)
+gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys_sorted,
+             uint32_t* __restrict__ minxy_sorted, uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ counts,
+             const uint32_t* __restrict__ sort_error, uint2* __restrict__ ranges, uint32_t ntiles)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     // the tile ranges must be zero before tile_ranges fills them in (cudaMemset of rasterizer_impl.cu:365): cleared here, on the way,
@@ -55,7 +55,9 @@ gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restr
         counts[i] = (i == n - 1u) ? GOF_SORT_FAILED_COUNT : 0u;
         return;
     }
-    const uint2 r = rect[order[i]];
+    // a culled Gaussian (sort key 0xFFFFFFFF: they sort last) has the empty rectangle: its random read is skipped -- a camera of a real
+    // capture culls most of the scene (the sorted keys are read in order: 4 coalesced bytes against a 64-byte sector)
+    const uint2 r = (keys_sorted && keys_sorted[i] == 0xFFFFFFFFu) ? make_uint2(0u, 0u) : rect[order[i]];
     minxy_sorted[i] = r.x;
     wh_sorted[i] = r.y;
     counts[i] = (r.y & 0xFFFFu) * (r.y >> 16);
