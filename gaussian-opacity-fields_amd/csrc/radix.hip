@@ -312,7 +312,14 @@ uint32_t rs_units(size_t n) { return (uint32_t)((n + RS_BLOCK - 1) / RS_BLOCK); 
 constexpr int OS_MAX_PASSES = 4;
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PREFIX = 2u << 30, OS_VALUE = (1u << 30) - 1u;
 constexpr uint32_t OS_SPIN_LIMIT = 1u << 18;
-constexpr uint32_t OS_MAX_UNITS = 512;                       // tiles of RS_BLOCK items: up to 2M pairs
+#ifndef GOF_OS_MAX_UNITS
+#define GOF_OS_MAX_UNITS 512
+#endif
+constexpr uint32_t OS_MAX_UNITS = GOF_OS_MAX_UNITS;          // tiles of RS_BLOCK items: up to 2M pairs
+#ifndef GOF_OS_LOOKBACK
+#define GOF_OS_LOOKBACK 8
+#endif
+constexpr int OS_LOOKBACK = GOF_OS_LOOKBACK;                 // predecessor descriptors requested per look-back round trip (os_pass)
 constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
 
 __global__ void __launch_bounds__(256)
@@ -396,23 +403,35 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
         uint32_t excl = 0;
         if (tile > 0) {
             __hip_atomic_store(my, OS_FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Look-back, OS_LOOKBACK predecessors per round trip: the descriptors of tiles j, j - 1, ... are requested together and
+            // consumed in order up to the first one that is not published yet (or the first PREFIX).  A descriptor is a device-scope
+            // load (~1 us: it is another XCD's store), and when the tiles of a pass start together every one of them finds AGGREGATEs
+            // on its nearest predecessors -- one load per round trip made the chain the pass's duration (29 us per pass at 245 tiles,
+            // and the reason the single-kernel passes lost beyond 512 tiles).
             int j = (int)tile - 1;
             uint32_t spins = 0;
-            while (j >= 0) {
-                const uint32_t v = __hip_atomic_load(desc + (size_t)j * RS_DIGITS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 30) == 0u) {
-                    ++spins;
-                    if (spins > OS_SPIN_LIMIT || ((spins & 1023u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        atomicExch(err, 1u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool done = false;
+            while (j >= 0 && !done) {
+                uint32_t v[OS_LOOKBACK];
+#pragma unroll
+                for (int k = 0; k < OS_LOOKBACK; k++)
+                    v[k] = (j - k >= 0) ? __hip_atomic_load(desc + (size_t)(j - k) * RS_DIGITS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                int used = 0;
+#pragma unroll
+                for (int k = 0; k < OS_LOOKBACK; k++) {
+                    if (done || used != k || j - k < 0 || (v[k] >> 30) == 0u) continue;      // (consumed strictly in order)
+                    excl += v[k] & OS_VALUE;
+                    used = k + 1;
+                    if (v[k] & OS_FLAG_PREFIX) done = true;
                 }
-                excl += v & OS_VALUE;
-                if (v & OS_FLAG_PREFIX) break;
-                j--;
-                spins = 0;
+                j -= used;
+                if (used) { spins = 0; continue; }
+                ++spins;
+                if (spins > OS_SPIN_LIMIT || ((spins & 1023u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    atomicExch(err, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
         }
         __hip_atomic_store(my, OS_FLAG_PREFIX | ((excl + tot) & OS_VALUE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -522,3 +522,23 @@ def test_emulated_tight_tile_rectangles_variant_changes_no_output():
         for a, b in zip(E.EmuScene(sc).integrate(pts)[:3], E.EmuScene(sc, tight=True).integrate(pts)[:3]):
             assert np.array_equal(bits(a), bits(b))
     assert shrunk >= len(scenes) - 1
+
+
+@pytest.mark.parametrize("name", ["lego10k", "posed_ragged", "posed_clustered150k"])
+def test_emulated_single_kernel_radix_passes_with_long_look_back_chains(name):
+    """os_pass (radix.hip) requests OS_LOOKBACK predecessor descriptors per look-back round trip and consumes them in order.  The default
+    build runs few tiles per pass at these scene sizes; this variant sorts in tiles of 256 items and sends EVERY sort -- depth, tile and
+    the query points' -- through the single-kernel passes (hundreds to thousands of tiles per pass, several look-back rounds per tile):
+    lists, keys, ranges and the opacity query must stay the oracle's bits."""
+    lib = E.load(extra_flags=("-DGOF_RS_CHUNK=64", "-DGOF_OS_MAX_UNITS=1048576"), tag="chains")
+    sc = TP.SCENES[name]()
+    o = ob.OracleScene(sc)
+    oc, orad = o.forward()
+    e = E.EmuScene(sc, lib=lib)
+    pc, prad = e.forward()
+    assert np.array_equal(prad, orad) and e.R == o.num_rendered()
+    for arr in TP.INT_ARRAYS:
+        assert TP._same(e.fetch(arr), o.fetch(arr)), arr
+    pts = np.ascontiguousarray(S.tetra_points(sc)[:30000], dtype=np.float32)
+    for a, b in zip(E.EmuScene(sc, lib=lib).integrate(pts)[:3], E.EmuScene(sc).integrate(pts)[:3]):
+        assert np.array_equal(bits(a), bits(b))
