@@ -50,6 +50,9 @@ size_t rs_tmp_words(size_t n);
 const uint32_t* radix_sort_error_flag(const uint32_t* tmp, size_t n, int end_bit);
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
+hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
+                                  uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
+                                  size_t zero_words_behind);
 int radix_passes(int end_bit);
 uint32_t emit_instances_grid(uint32_t slots, int P);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
@@ -97,6 +100,10 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 __global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, const uint32_t* keys_sorted, uint32_t* minxy_sorted, uint32_t* wh_sorted,
                              uint32_t* counts, const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
+uint32_t gather_scan_tiles(size_t n);
+size_t gather_scan_state_words(size_t n);
+__global__ void gather_scan_rects(uint32_t n, const uint2* rect, const uint32_t* order, const uint32_t* keys_sorted, uint32_t* minxy_sorted, uint32_t* wh_sorted,
+                                  uint32_t* order_off, const uint32_t* sort_error, uint2* ranges, uint32_t ntiles, uint32_t* state, uint32_t* total_host);
 __global__ void gather_sorted_points(uint32_t NI, const uint32_t* sorted_ids, const float4* pos, float2* pt_ray, float* pt_depth, int W, int H,
                                      float focal_x, float focal_y);
 
@@ -211,7 +218,7 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     g.inst_first = g.dkey_a;        // (the sorted depth keys are dead once the depth sort has delivered the order: emit_instances writes over them)
     carve(p, g.dkey_b, n);
     carve(p, g.dval_b, n);
-    carve(p, g.sort_tmp, rs_tmp_words(n) + scan_tmp_words(n));
+    carve(p, g.sort_tmp, rs_tmp_words(n) + (scan_tmp_words(n) > gather_scan_state_words(n) ? scan_tmp_words(n) : gather_scan_state_words(n)));
     if (out) *out = g;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -527,19 +534,29 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
 #undef GOF_K1_LAUNCH
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
+    // (the state words of the fused gather + scan behind it lie right behind the sort's scratch: the sort's own memset clears them too)
+    static const bool fused_scan = [] { const char* e = getenv("GOF_FUSED_SCAN"); return !(e && e[0] == '0'); }();      // (developer A/B: 0 = gather_rects + the three-kernel scan)
+    uint32_t* const scan_state = g.sort_tmp + rs_tmp_words((size_t)a->P);
     uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
-    GOF_HIP_CHECK(radix_sort_pairs_u32(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream));
+    GOF_HIP_CHECK(radix_sort_pairs_u32_z(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream, nullptr,
+                                         fused_scan ? gather_scan_state_words((size_t)a->P) : 0));
     if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)
     { GOF_PROFILE("scan_tiles", stream);
     // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
     // scanned in place
+    if (fused_scan) {
+        hipLaunchKernelGGL(gather_scan_rects, dim3(gather_scan_tiles((size_t)a->P)), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b,
+                           g.order_off, radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles, scan_state, total_host_mapped);
+        GOF_HIP_CHECK(hipGetLastError());
+        *total_dev_out = scan_state + 1;
+    } else {
     hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b, g.order_off,
                        radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles);
-    GOF_HIP_CHECK(device_scan_u32_to_host(g.order_off, nullptr, g.order_off, (size_t)a->P, false, g.sort_tmp + rs_tmp_words((size_t)a->P),
-                                          total_dev_out, stream, total_host_mapped)); }
+    GOF_HIP_CHECK(device_scan_u32_to_host(g.order_off, nullptr, g.order_off, (size_t)a->P, false, scan_state,
+                                          total_dev_out, stream, total_host_mapped)); } }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }

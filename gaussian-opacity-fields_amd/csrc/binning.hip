@@ -63,6 +63,123 @@ gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restr
     counts[i] = (r.y & 0xFFFFu) * (r.y >> 16);
 }
 
+// gather_rects + the exclusive scan of the counts in ONE launch (replaces cub::DeviceScan::InclusiveSum of rasterizer_impl.cu:332 together
+// with the gather in front of it; until round 5: gather_rects, scan_block_sums, scan_apply = three launches, 31 us on the critical path
+// of a 1M-Gaussian frame, of which the kernels' own work is a third).  A workgroup takes a ticket (= its tile of GS_BLOCK consecutive
+// positions of the depth order: every tile with a smaller ticket is running or done, so waiting for them cannot deadlock), gathers
+// the rectangles exactly as gather_rects, scans its counts (wave by wave: a wave owns 1024 consecutive positions, 16 coalesced steps
+// of 64), publishes its total as an AGGREGATE descriptor, and wave 0 looks back over 64 predecessors per round trip -- their
+// descriptors in one load instruction, consumed in order up to the first PREFIX -- until it knows the sum in front of its tile;
+// then the tile publishes its PREFIX and stores its offsets.  Descriptors are 64-bit (flag << 32 | value): the value is an instance
+// count, and the failure sentinel of a timed-out depth sort (GOF_SORT_FAILED_COUNT, gof_status.h) must survive the scan unchanged.
+// state (u32 words, zeroed in front of the launch): [0] ticket, [1] grand total (the device-side instance count), [2] raised by a tile
+// whose look-back poll expired, [4..] descriptors.
+#ifndef GOF_GS_ITEMS
+#define GOF_GS_ITEMS 16
+#endif
+constexpr int GS_ITEMS = GOF_GS_ITEMS;                 // per lane
+constexpr uint32_t GS_BLOCK = 256u * GS_ITEMS;         // positions per workgroup
+constexpr uint32_t GS_SPIN_LIMIT = 1u << 18;
+uint32_t gather_scan_tiles(size_t n) { return (uint32_t)((n + GS_BLOCK - 1) / GS_BLOCK); }
+size_t gather_scan_state_words(size_t n) { return 4 + 2 * (size_t)gather_scan_tiles(n) + 2; }
+__device__ __forceinline__ unsigned long long* gather_scan_desc(uint32_t* state)
+{
+    return reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(state + 4) + 7u) & ~(uintptr_t)7u);
+}
+__global__ void __launch_bounds__(256)
+gather_scan_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys_sorted,
+                  uint32_t* __restrict__ minxy_sorted, uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ order_off,
+                  const uint32_t* __restrict__ sort_error, uint2* __restrict__ ranges, uint32_t ntiles, uint32_t* __restrict__ state,
+                  uint32_t* __restrict__ total_host)
+{
+    __shared__ uint32_t s_tile, s_base;
+    __shared__ uint32_t s_wtot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (the tile ranges cleared on the way, as gather_rects does)
+    for (uint32_t t = blockIdx.x * 256u + tid; t < ntiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
+    if (tid == 0) s_tile = atomicAdd(&state[0], 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const bool failed = sort_error && *sort_error != 0u;          // the depth sort timed out: as gather_rects
+    const uint32_t wbase = tile * GS_BLOCK + wave * (64u * GS_ITEMS);
+    uint32_t ord[GS_ITEMS], cnt[GS_ITEMS];
+    uint2 r[GS_ITEMS];
+#pragma unroll
+    for (int s = 0; s < GS_ITEMS; s++) {
+        const uint32_t i = wbase + 64u * s + lane;
+        ord[s] = 0xFFFFFFFFu;                          // no rectangle to read: past the end, a failed sort, or a culled Gaussian (key 0xFFFFFFFF)
+        if (i < n && !failed && !(keys_sorted && keys_sorted[i] == 0xFFFFFFFFu)) ord[s] = order[i];
+    }
+#pragma unroll
+    for (int s = 0; s < GS_ITEMS; s++) r[s] = (ord[s] != 0xFFFFFFFFu) ? rect[ord[s]] : make_uint2(0u, 0u);
+    uint32_t run = 0;                                  // (wave-uniform) sum of the wave's counts so far
+#pragma unroll
+    for (int s = 0; s < GS_ITEMS; s++) {
+        const uint32_t i = wbase + 64u * s + lane;
+        uint32_t c = (r[s].y & 0xFFFFu) * (r[s].y >> 16);
+        if (failed) c = (i == n - 1u) ? GOF_SORT_FAILED_COUNT : 0u;
+        if (i < n) { minxy_sorted[i] = r[s].x; wh_sorted[i] = r[s].y; } else c = 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, o); if (lane >= (uint32_t)o) inc += up; }
+        cnt[s] = run + inc - c;                        // exclusive within the wave
+        run += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) s_wtot[wave] = run;
+    __syncthreads();
+    const uint32_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+    const uint32_t total = (t0 + t1) + (t2 + t3);
+    const uint32_t wave_excl = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+    if (wave == 0) {
+        unsigned long long* const desc = gather_scan_desc(state);
+        constexpr unsigned long long AGG = 1ull << 32, PREFIX = 2ull << 32;
+        if (tile > 0 && lane == 0) __hip_atomic_store(desc + tile, AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0, spins = 0;
+        int j = (int)tile - 1;
+        bool expired = false;
+        while (j >= 0) {
+            const int idx = j - (int)lane;
+            // (a lane past tile 0 stands for "PREFIX 0": the walk always ends at a PREFIX)
+            const unsigned long long v = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PREFIX;
+            const uint32_t flag = (uint32_t)(v >> 32);
+            const unsigned long long ready = __ballot(flag != 0u);
+            const int nready = (ready == ~0ull) ? 64 : (int)__builtin_ctzll(~ready);             // published descriptors, counted from the nearest predecessor
+            const unsigned long long pref = __ballot(flag == 2u) & (nready == 64 ? ~0ull : ((1ull << nready) - 1ull));
+            const int upto = pref ? (int)__builtin_ctzll(pref) + 1 : nready;                      // lanes [0, upto) are consumed
+            uint32_t val = ((int)lane < upto) ? (uint32_t)v : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) val += (uint32_t)__shfl_xor((int)val, o);
+            excl += val;
+            if (pref) break;
+            j -= upto;
+            if (upto) { spins = 0; continue; }
+            if (++spins > GS_SPIN_LIMIT) { expired = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        // a poll that expired (GPU heavily oversubscribed): this tile's offsets are wrong.  It says so in state[2] BEFORE it publishes;
+        // the last tile, whose own look-back cannot end before every predecessor has published, then writes the failure sentinel as
+        // the grand total: the call fails instead of rendering from wrong offsets (as after a timed-out radix pass, radix.hip)
+        if (expired && lane == 0) __hip_atomic_store(&state[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(desc + tile, PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = excl;
+            if (tile == gridDim.x - 1u) {
+                uint32_t grand = excl + total;
+                if (__hip_atomic_load(&state[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) grand = GOF_SORT_FAILED_COUNT;
+                state[1] = grand;
+                if (total_host) __hip_atomic_store(total_host, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t base = s_base + wave_excl;
+#pragma unroll
+    for (int s = 0; s < GS_ITEMS; s++) {
+        const uint32_t i = wbase + 64u * s + lane;
+        if (i < n) order_off[i] = base + cnt[s];
+    }
+}
+
 // Instance emission in depth order (replaces duplicateWithKeys, rasterizer_impl.cu:70-111).
 //
 // The OUTPUT is what is divided among the waves, not the Gaussians: wave k writes the slots [k EMIT_SLOTS, (k + 1) EMIT_SLOTS) of the

@@ -479,8 +479,11 @@ size_t rs_tmp_words(size_t n)
 // Stable sort of (key, value) pairs on key bits [0, end_bit), 8 bits per pass.  Buffers a* hold the input; the
 // result ends up in (*keys_res, *vals_res), which alias either a* or b*.  n_dev (nullable): the item count lives on the device
 // (sync-free forward); n is then the CAPACITY the launches are sized for and every kernel clamps to min(n, *n_dev).
-hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
-                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev)
+// zero_words_behind: that many u32 words right behind the sort's scratch (tmp + rs_tmp_words(n)) are cleared as well -- by the memset the
+// single-kernel passes need anyway where it ends there, by one of its own otherwise (the caller's next kernel keeps its state there).
+hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
+                                  uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
+                                  size_t zero_words_behind)
 {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     const int npass = (end_bit + 7) / 8;
@@ -495,8 +498,11 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
             uint32_t* tickets = tmp + OS_MAX_PASSES * RS_DIGITS;
             uint32_t* err = tickets + 8;
             uint32_t* desc = tmp + OS_HDR;
-            hipError_t e = hipMemsetAsync(tmp, 0, ((size_t)OS_HDR + (size_t)npass * hwords) * sizeof(uint32_t), stream);
+            size_t zero_words = (size_t)OS_HDR + (size_t)npass * hwords;
+            if (zero_words_behind && zero_words == rs_tmp_words(n)) { zero_words += zero_words_behind; zero_words_behind = 0; }
+            hipError_t e = hipMemsetAsync(tmp, 0, zero_words * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
+            if (zero_words_behind) { e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
             hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase, n_dev);
             hipLaunchKernelGGL(os_scan_hist, dim3(1), block, 0, stream, gbase, npass);
             for (int p = 0; p < npass; p++) {
@@ -510,6 +516,7 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
             *vals_res = vi;
             return hipGetLastError();
         }
+        if (zero_words_behind) { hipError_t e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
         uint32_t* hist = tmp;
         uint32_t* scan_tmp = tmp + hwords;
         for (int shift = 0; shift < end_bit; shift += 8) {
@@ -522,9 +529,15 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
             t = vi; vi = vo; vo = t;
         }
     }
+    else if (zero_words_behind) { hipError_t e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
     *keys_res = ki;
     *vals_res = vi;
     return hipGetLastError();
+}
+hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
+                                uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev)
+{
+    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0);
 }
 int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
 

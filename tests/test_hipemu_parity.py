@@ -528,9 +528,10 @@ def test_emulated_tight_tile_rectangles_variant_changes_no_output():
 def test_emulated_single_kernel_radix_passes_with_long_look_back_chains(name):
     """os_pass (radix.hip) requests OS_LOOKBACK predecessor descriptors per look-back round trip and consumes them in order.  The default
     build runs few tiles per pass at these scene sizes; this variant sorts in tiles of 256 items and sends EVERY sort -- depth, tile and
-    the query points' -- through the single-kernel passes (hundreds to thousands of tiles per pass, several look-back rounds per tile):
+    the query points' -- through the single-kernel passes (hundreds to thousands of tiles per pass, several look-back rounds per tile),
+    and the fused rectangle gather + scan (binning.hip: gather_scan_rects, 64 predecessors per round trip) in tiles of 256 positions:
     lists, keys, ranges and the opacity query must stay the oracle's bits."""
-    lib = E.load(extra_flags=("-DGOF_RS_CHUNK=64", "-DGOF_OS_MAX_UNITS=1048576"), tag="chains")
+    lib = E.load(extra_flags=("-DGOF_RS_CHUNK=64", "-DGOF_OS_MAX_UNITS=1048576", "-DGOF_GS_ITEMS=1"), tag="chains")
     sc = TP.SCENES[name]()
     o = ob.OracleScene(sc)
     oc, orad = o.forward()
