@@ -310,12 +310,12 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
         "blend_forward": 72 * r_visited_fwd + 60 * N,                # 8(d): 60 B state + 12 B colour per visited entry, 60 B per pixel
         "blend_backward": 72 * r_staged_bwd + 96 * N + 76 * p_visible,   # 8(d): 72 B per staged entry, 60 + 36 B per pixel, accumulators once
         "preprocess_bwd": p_visible * (316 + 232),
-        "gather_tile_partials": 68 * r_staged_bwd + 4 * R + 8 * P + 68 * P,   # partial records + slot words + counts/offsets read, 17 floats per Gaussian written
+        "gather_tile_partials": 64 * r_staged_bwd + 4 * R + 8 * P + 4 * P + 68 * P,   # partial records + slot words + counts/offsets + blend weight read, 17 floats per Gaussian written
         "backward_memsets": 4 * R,                                         # the slot words (a record pool instead of a record per instance, round 4)
     }
     # bytes this design moves on top of 8(d)'s list: the contributor masks (1 bit per pixel and visited entry = 32 B per entry),
     # written by the forward, read by the backward, and the 32 B footprint conic per entry the forward's cull scan reads
-    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": (32 + 72) * r_staged_bwd}   # masks read; partial record + slot word written
+    extra_bytes = {"blend_forward": (32 + 32) * r_visited_fwd, "blend_backward": (32 + 68) * r_staged_bwd}   # masks read; partial record + slot word written
     if "preprocess_fwd_heavy" in kernel_times:
         # round 5: the sync-free forward runs the per-Gaussian kernel in two stages -- "preprocess_fwd" = the culls + what binning reads
         # (40 B read, 24 B written per Gaussian), "preprocess_fwd_heavy" = the rest (8(d)'s 355 B less those 24) on a second stream
@@ -386,7 +386,7 @@ def stage_times(B, sd, dL, dev, kernel_times, steps):
 def workspace_report(B, P, W, H, R, staged):
     """Bytes of the caller-owned workspaces of one forward + backward, and what an INSTANCE (one (tile, Gaussian) pair of the sorted
     list) costs.  Binning workspace: sort state 16 B + contributor masks 32 B.  Backward scratch (round 4): a slot word per instance
-    + a 68-byte partial gradient record per STAGED instance (the pool is sized from gof_backward_query: `staged` of R) -- rounds 2-3
+    + a 64-byte partial gradient record per STAGED instance (the pool is sized from gof_backward_query: `staged` of R) -- rounds 2-3
     held a record per instance, 69 B.  The reference's BinningState holds 24 B (rasterizer_impl.h:60-70): a stated deviation
     (DESIGN.md section 7): masks and records buy the backward without re-derived decisions and without atomics."""
     lib = B.lib

@@ -76,10 +76,10 @@ __global__ void order_tiles(uint32_t ntiles, const uint2* ranges, const uint32_t
 __global__ void blend_backward(const uint2* ranges, const uint32_t* point_list, const SplatRec* rec, const float4* conic, MaskPool masks,
                                int W, int H, float focal_x, float focal_y, const float* bg_color, const float* final_Ts,
                                const uint32_t* n_contrib, const float* dL_dpixels, const uint2* rect, const uint32_t* inst_off,
-                               float4* part16, float* part17, uint32_t* slot_of, uint32_t* rec_cursor, uint32_t rec_cap,
+                               float4* part16, uint32_t* slot_of, uint32_t* rec_cursor, uint32_t rec_cap,
                                uint32_t gx, uint32_t ntiles, const uint32_t* tile_order,
                                uint32_t* tile_queue, const uint32_t* tile_lens);
-__global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float* part17,
+__global__ void gather_tile_partials(int P, const uint32_t* inst_off, const uint32_t* tiles_touched, const float4* part16, const float4* conic_w,
                                      const uint32_t* slot_of, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolors, float* dL_dv2g);
 __global__ void integrate_pixels(const uint2* gaussian_ranges, const uint32_t* gaussian_list, const SplatRec* rec, const float4* bbox,
                                  const float4* fconic, int W, int H, float focal_x, float focal_y, const float* bg_color, float* final_T,
@@ -691,10 +691,10 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
 // backward scratch (the number of a Gaussian's first instance comes from the forward: GeomWs::inst_first, written by emit_instances --
 // until round 4 the backward scanned tiles_touched itself, two launches and 14 us per step):
 // the backward's queue heads + the record pool's cursor, then per tile instance (R of them) a slot word (slot + 1 of the instance's
-// partial gradient record, 0 = none), and the record POOL: per record the 17th partial gradient f32 and the 64-byte line of the other
+// partial gradient record, 0 = none), and the record POOL: per record one 64-byte line of 16 partial gradients (the 17th follows from them per Gaussian: gather_tile_partials)
 // 16.  The pool holds `records` records: R for the worst case (every instance staged), or the number the forward actually staged
-// (gof_backward_query: ~30 % of R at S1M) -- 4 + 68 x 0.3 B per instance instead of 69.
-struct BwdScratch { uint32_t* queue; uint32_t* slot_of; float* part17; float4* part16; };
+// (gof_backward_query: ~30 % of R at S1M) -- 4 + 64 x 0.3 B per instance instead of 68.
+struct BwdScratch { uint32_t* queue; uint32_t* slot_of; float4* part16; };
 constexpr size_t BWD_QUEUE_BYTES = 256;      // the backward's tile-queue heads ([0..7]) and the record pool's cursor ([BWD_REC_CURSOR]) sit right in front of the slot words: one memset clears both
 constexpr int BWD_REC_CURSOR = 16;
 constexpr uint32_t BWD_REC_SLACK = 0;        // (a tile takes exactly its staged entries: the sum is what gof_backward_query reports)
@@ -706,7 +706,6 @@ static size_t bwd_scratch_layout(int32_t P, uint32_t R, uint32_t records, void* 
     (void)P;
     carve(p, t.queue, BWD_QUEUE_BYTES / 4 + (size_t)R + 1);
     t.slot_of = t.queue + BWD_QUEUE_BYTES / 4;
-    carve(p, t.part17, (size_t)records + 1);
     carve(p, t.part16, 4 * ((size_t)records + 1));
     if (o) *o = t;
     return reinterpret_cast<size_t>(p) - p0;
@@ -721,7 +720,7 @@ static uint32_t bwd_scratch_records(int32_t P, uint32_t R, size_t bytes)
 {
     const size_t fixed = bwd_scratch_layout(P, R, 0, nullptr, nullptr) + ALIGN;
     if (bytes < fixed) return 0;
-    size_t n = (bytes - fixed) / 68 + 16;                   // (the pool arrays of the zero-record layout already hold one record and their alignment padding)
+    size_t n = (bytes - fixed) / 64 + 16;                   // (the pool arrays of the zero-record layout already hold one record and their alignment padding)
     if (n > (size_t)R + BWD_REC_SLACK) n = (size_t)R + BWD_REC_SLACK;
     while (n > 0 && bwd_scratch_layout(P, R, (uint32_t)n, nullptr, nullptr) + ALIGN > bytes) n--;      // (the two pool arrays are 256-byte aligned each)
     return (uint32_t)n;
@@ -785,13 +784,13 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         GOF_PROFILE("blend_backward", stream);
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
-                           im.n_contrib, dL_dout, g.rect, g.inst_first, ws.part16, ws.part17, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, d.gx, d.ntiles,
+                           im.n_contrib, dL_dout, g.rect, g.inst_first, ws.part16, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, d.gx, d.ntiles,
                            bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);
       // R == 0: tiles_touched is 0 everywhere, the kernel writes zeros
-      hipLaunchKernelGGL(gather_tile_partials, dim3((unsigned)(((size_t)a->P * 4 + 255) / 256)), dim3(256), 0, stream, a->P, g.inst_first, g.tiles_touched, ws.part16, ws.part17,
+      hipLaunchKernelGGL(gather_tile_partials, dim3((unsigned)(((size_t)a->P * 4 + 255) / 256)), dim3(256), 0, stream, a->P, g.inst_first, g.tiles_touched, ws.part16, g.conic,
                          ws.slot_of, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dview2gaussian);
       GOF_LAUNCH_CHECK(stream, a->debug); }
     }

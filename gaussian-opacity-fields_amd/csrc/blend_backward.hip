@@ -16,8 +16,8 @@
 //         s_slab[wave][16][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
 //         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
 //         entry and wave kept the LDS busy ~70 % of the time);
-//      4. after the batch, thread j adds the slabs of the waves that visited entry j (in wave order) and STORES the 16 sums (and the 17th value derived from the opacity sum) as
-//         the partial gradient of that (tile, Gaussian) instance -- plain stores into a 68-byte record of a POOL (one record per
+//      4. after the batch, thread j adds the slabs of the waves that visited entry j (in wave order) and STORES the 16 sums as
+//         the partial gradient of that (tile, Gaussian) instance -- plain stores into a 64-byte record (one line) of a POOL (one record per
 //         staged instance; a wave takes its batch's slots with one atomic on the pool's cursor), whose slot + 1 goes into a word
 //         indexed by an instance number e in which the instances of one Gaussian, and of consecutive Gaussians, are consecutive.  No
 //         global atomic at all: gather_tile_partials (below) then adds the records of every Gaussian in ascending e.  The reference's 17
@@ -147,7 +147,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                     const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                     const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-                    float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
+                    float4* __restrict__ part16, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
                     uint32_t rec_cap, uint32_t gx)
 {
     TILE_CLOCK_START();
@@ -531,7 +531,9 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 float4* dst = part16 + (size_t)slot * 4;
 #pragma unroll
                 for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
-                part17[slot] = -0.5f * s_rec[3][tid].y * total(6);      // dL_dv2g[9], see the gradient block
+                // (dL_dv2g[9] = -0.5 wgt x the total of value 6, wgt a constant of the Gaussian: formed once per Gaussian by
+                // gather_tile_partials from its sum of value 6 -- until round 5 a 17th value per record, in an array of its own: a
+                // second random sector per record for the flush and for the gather)
                 slot_of[s_inst[tid]] = slot + 1u;
             }
         }
@@ -556,7 +558,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
                const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,
                const float* __restrict__ bg_color, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                const float* __restrict__ dL_dpixels, const uint2* __restrict__ rect, const uint32_t* __restrict__ inst_off,
-               float4* __restrict__ part16, float* __restrict__ part17, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
+               float4* __restrict__ part16, uint32_t* __restrict__ slot_of, uint32_t* __restrict__ rec_cursor,
                uint32_t rec_cap, uint32_t gx, uint32_t ntiles,
                const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ tile_queue, const uint32_t* __restrict__ tile_lens)
 {
@@ -564,7 +566,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
     const uint32_t tile = pop_tile(tile_order, tile_queue, tile_lens, ntiles, &s_tile);
     if (tile >= ntiles) return;
     blend_backward_tile(tile, ranges, point_list, rec, conic, masks, W, H, focal_x, focal_y, bg_color, final_Ts, n_contrib, dL_dpixels, rect,
-                        inst_off, part16, part17, slot_of, rec_cursor, rec_cap, gx);
+                        inst_off, part16, slot_of, rec_cursor, rec_cap, gx);
 }
 
 // Sum of the partial gradient records of every Gaussian over its tile instances, in ascending instance order (deterministic):
@@ -578,7 +580,7 @@ blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ po
 // (Adding 0.0f for an absent record leaves every bit of the sum unchanged, so the result is that of the plain ordered loop.)
 __global__ void __launch_bounds__(256)
 gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_t* __restrict__ tiles_touched,
-                     const float4* __restrict__ part16, const float* __restrict__ part17, const uint32_t* __restrict__ slot_of,
+                     const float4* __restrict__ part16, const float4* __restrict__ conic_w, const uint32_t* __restrict__ slot_of,
                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dv2g)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -588,7 +590,6 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
     const uint32_t g = (uint32_t)i;
     const uint32_t n = live ? tiles_touched[g] : 0u;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float acc17 = 0.f;
     constexpr uint32_t BIG = 64;          // Gaussians covering more tiles than this are summed by the whole wave (a near, huge splat can
                                           // cover thousands of tiles: left to its own quad it alone determined the kernel's duration)
     const size_t e0 = n ? inst_off[g] : 0;
@@ -603,10 +604,9 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
 #define GOF_GATHER_TRIP_V(E0, K0, va, vb)                                                                            \
     {                                                                                                                  \
         float4 r[8];                                                                                                   \
-        float r17[8];                                                                                                  \
         GOF_GATHER_LOAD(E0, K0, 0, va, 0x00) GOF_GATHER_LOAD(E0, K0, 1, va, 0x55) GOF_GATHER_LOAD(E0, K0, 2, va, 0xAA) GOF_GATHER_LOAD(E0, K0, 3, va, 0xFF) \
         GOF_GATHER_LOAD(E0, K0, 4, vb, 0x00) GOF_GATHER_LOAD(E0, K0, 5, vb, 0x55) GOF_GATHER_LOAD(E0, K0, 6, vb, 0xAA) GOF_GATHER_LOAD(E0, K0, 7, vb, 0xFF) \
-        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc.x += r[j].x; acc.y += r[j].y; acc.z += r[j].z; acc.w += r[j].w; acc17 += r17[j]; }            \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc.x += r[j].x; acc.y += r[j].y; acc.z += r[j].z; acc.w += r[j].w; }                            \
     }
 #define GOF_GATHER_LOAD(E0, K0, J, V, CTRL)                                                                          \
         {                                                                                                              \
@@ -614,7 +614,6 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
             const bool ok = sl != 0u;                                                                                  \
             const size_t e = (size_t)(sl - 1u);                                                                        \
             r[J] = ok ? part16[e * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);                                           \
-            r17[J] = (ok && q == 0u) ? part17[e] : 0.f;                                                                \
         }
     if (n && n <= BIG) {
         // the slot words of the NEXT trip are requested before this trip's records: a trip then waits for one memory round trip,
@@ -638,12 +637,12 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
         big &= big - 1ull;
         const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)n, owner);
         const size_t be0 = ((size_t)(uint32_t)__builtin_amdgcn_readlane((int)(e0 >> 32), owner) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e0, owner);
-        float4 keep = acc; float keep17 = acc17;
-        acc = make_float4(0.f, 0.f, 0.f, 0.f); acc17 = 0.f;
+        float4 keep = acc;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t k0 = 8u * (lane >> 2); k0 < bn; k0 += 8u * 16u) GOF_GATHER_TRIP(be0, bn, k0)
-        float v5[5] = { acc.x, acc.y, acc.z, acc.w, acc17 };
+        float v5[4] = { acc.x, acc.y, acc.z, acc.w };
 #pragma unroll
-        for (int c = 0; c < 5; c++) {
+        for (int c = 0; c < 4; c++) {
             float x = v5[c];
             x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4  (quads of the row)
             x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -653,18 +652,20 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
         }
         const bool mine = (int)(lane & ~3u) == owner;
         acc = mine ? make_float4(v5[0], v5[1], v5[2], v5[3]) : keep;
-        acc17 = mine ? v5[4] : keep17;
     }
 #undef GOF_GATHER_LOAD
 #undef GOF_GATHER_TRIP_V
 #undef GOF_GATHER_TRIP
-    // record layout (blend_backward's flush): [colour 0-2, mean2D 0 | mean2D 1-2, opacity, v2g 0 | v2g 1-4 | v2g 5-8], 17th = v2g 9
+    // record layout (blend_backward's flush): [colour 0-2, mean2D 0 | mean2D 1-2, opacity, v2g 0 | v2g 1-4 | v2g 5-8]
+    // v2g 9 = dL_dmin_value summed over the pairs = -0.5 wgt (G dL_dalpha) summed = -0.5 wgt x the opacity sum (value 6, lane 1 of the
+    // quad), wgt = opacity x the 3D filter's coefficient, which preprocess_fwd leaves in the spare word of the Gaussian's 2D conic
+    const float opac_sum = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc.z), 0x55, 0xf, 0xf, false));     // quad_perm [1,1,1,1]
     if (!live) return;
     const size_t o = (size_t)g;
     if (q == 0u) {
         dL_dcolors[o * 3 + 0] = acc.x; dL_dcolors[o * 3 + 1] = acc.y; dL_dcolors[o * 3 + 2] = acc.z;
         dL_dmean2D[o * 3 + 0] = acc.w;
-        dL_dv2g[o * 10 + 9] = acc17;
+        dL_dv2g[o * 10 + 9] = n ? -0.5f * conic_w[o].w * opac_sum : 0.f;      // (a culled Gaussian's conic is never written)
     } else if (q == 1u) {
         dL_dmean2D[o * 3 + 1] = acc.x; dL_dmean2D[o * 3 + 2] = acc.y;
         dL_dopacity[o] = acc.z;

@@ -301,7 +301,7 @@ uint32_t rs_units(size_t n) { return (uint32_t)((n + RS_BLOCK - 1) / RS_BLOCK); 
 // ---------------------------------------------------------------------------------------------------
 // "onesweep" passes: ONE kernel per digit instead of histogram + 3 scan kernels + scatter.
 //   os_hist      -- one read of the keys builds the global digit histograms of ALL passes (LDS atomics, then 256 global atomics
-//                   per block and pass); os_scan_hist turns each into exclusive digit bases.
+//                   per block and pass); every tile of a pass scans the pass's 256 counts into digit bases itself.
 //   os_pass      -- a block takes a ticket (logical tile id = scheduling order, so every predecessor is resident), ranks its tile
 //                   exactly like rs_scatter, publishes its per-digit counts as (AGGREGATE | count) descriptors, thread d walks the
 //                   predecessors' descriptors of digit d backwards until it meets an inclusive PREFIX (decoupled look-back),
@@ -322,6 +322,27 @@ constexpr uint32_t OS_MAX_UNITS = GOF_OS_MAX_UNITS;          // tiles of RS_BLOC
 constexpr int OS_LOOKBACK = GOF_OS_LOOKBACK;                 // predecessor descriptors requested per look-back round trip (os_pass)
 constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
 
+// Counting with few LDS atomics where the digits of a wave are few: the high bytes of depth keys take a handful of values (sign,
+// exponent), those of tile ids one or two -- a same-address ds_add serialises its lanes (~3.5 cycles each).  Up to four groups of
+// equal digits are peeled off with one ballot each and counted by one lane; what is left (digits spread over the bins: few conflicts)
+// is counted lane by lane.
+__device__ __forceinline__ void os_count(uint32_t* __restrict__ h, uint32_t d, bool valid)
+{
+    uint64_t rem = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll 1
+    for (int g = 0; g < 4 && rem; g++) {
+        const int first = (int)__builtin_ctzll(rem);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+        const uint64_t m = __ballot(valid && d == d0) & rem;
+        const uint32_t c = (uint32_t)__popcll(m);
+        if (c < 8u) break;                                  // (wave-uniform) not a crowded digit: the rest goes lane by lane
+        if (lane == (uint32_t)first) atomicAdd(&h[d0], c);
+        rem &= ~m;
+    }
+    if ((rem >> lane) & 1ull) atomicAdd(&h[d], 1u);
+}
+// one block per RS_BLOCK keys (grid-stride beyond 1024 blocks): all of a thread's loads of a round are in flight together
 __global__ void __launch_bounds__(256)
 os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase, const uint32_t* __restrict__ n_dev)
 {
@@ -329,24 +350,21 @@ os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __re
     __shared__ uint32_t s_h[OS_MAX_PASSES][RS_DIGITS];
     for (int p = 0; p < npass; p++) s_h[p][threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t k = keys[i];
-        for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(k >> (8 * p)) & 0xFFu], 1u);
+    for (uint32_t base = blockIdx.x * RS_BLOCK; base < n; base += gridDim.x * RS_BLOCK) {      // (block-uniform)
+        uint32_t k[RS_BLOCK / 256];
+#pragma unroll
+        for (int s = 0; s < RS_BLOCK / 256; s++) { const uint32_t i = base + s * 256 + threadIdx.x; k[s] = i < n ? keys[i] : 0u; }
+#pragma unroll
+        for (int s = 0; s < RS_BLOCK / 256; s++) {
+            const uint32_t i = base + s * 256 + threadIdx.x;
+            if (base + s * 256 < n)                          // (block-uniform: whole rows past the end are skipped)
+                for (int p = 0; p < npass; p++) os_count(s_h[p], (k[s] >> (8 * p)) & 0xFFu, i < n);
+        }
     }
     __syncthreads();
     for (int p = 0; p < npass; p++) {
         const uint32_t c = s_h[p][threadIdx.x];
         if (c) atomicAdd(&gbase[p * RS_DIGITS + threadIdx.x], c);
-    }
-}
-__global__ void __launch_bounds__(256)
-os_scan_hist(uint32_t* __restrict__ gbase, int npass)
-{
-    __shared__ uint32_t s_wave[4];
-    for (int p = 0; p < npass; p++) {
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(gbase[p * RS_DIGITS + threadIdx.x], &total, s_wave);
-        gbase[p * RS_DIGITS + threadIdx.x] = ex;
     }
 }
 
@@ -372,6 +390,7 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
     const uint32_t tile = s_tile;
     const uint32_t blk_begin = tile * RS_BLOCK;
     const uint32_t begin = blk_begin + wave * RS_CHUNK;
+    const uint32_t hist_d = gbase[threadIdx.x];  // (requested early: needed behind the look-back)
 
     uint32_t key[RS_STEPS], val[RS_STEPS];
     uint16_t rnk[RS_STEPS], cnt[RS_STEPS];       // rank among same-digit lanes of the step; group size (leader only)
@@ -438,7 +457,12 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
         uint32_t blk_total;
         const uint32_t start = block_exclusive_scan(tot, &blk_total, s_scan);
         s_bstart[d] = start;
-        s_gbase[d] = gbase[d] + excl;
+        // gbase: the RAW global count of every digit of this pass (os_hist); its exclusive scan = where the digit's run starts is
+        // formed here, by every tile for itself (256 values: one block scan) -- a single-workgroup launch between the histogram and
+        // the first pass did it until round 5 (os_scan_hist: 12 us on the critical path for 1024 additions)
+        uint32_t all;
+        const uint32_t digit_base = block_exclusive_scan(hist_d, &all, s_scan);
+        s_gbase[d] = digit_base + excl;
         s_cur[0][d] = start; s_cur[1][d] = start + c0; s_cur[2][d] = start + c0 + c1; s_cur[3][d] = start + c0 + c1 + c2;
     }
     __syncthreads();
@@ -504,7 +528,6 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
             if (e != hipSuccess) return e;
             if (zero_words_behind) { e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
             hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase, n_dev);
-            hipLaunchKernelGGL(os_scan_hist, dim3(1), block, 0, stream, gbase, npass);
             for (int p = 0; p < npass; p++) {
                 hipLaunchKernelGGL(os_pass, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, 8 * p, gbase + p * RS_DIGITS,
                                    desc + (size_t)p * hwords, tickets + p, err, n_dev);

@@ -170,13 +170,13 @@ int gof_forward_fused(const GofRasterArgs* args, uint32_t capacity,
 
 /* ---- backward (replaces _C.rasterize_gaussians_backward, rasterize_points.cu:124-211) --- */
 /* Scratch the backward needs besides the outputs: per tile instance (num_rendered of them) one slot word, and a POOL of
- * 68-byte partial gradient records -- one per (tile, Gaussian) instance the per-pixel backward actually stages -- which the
+ * 64-byte partial gradient records -- one per (tile, Gaussian) instance the per-pixel backward actually stages -- which the
  * per-Gaussian gather adds up (no atomics).  num_rendered = the value the backward is called with.
  *   gof_backward_scratch_bytes(P, R):                a pool of R records: always enough (every instance staged).
  *   gof_backward_query(...):                         [0] the number of entries the forward of this frame staged (~30 % of R at 1M
  *                                                    Gaussians @ 1600x1063), read from the image workspace; [1], [2]: the forward's
  *                                                    contributor-mask pool, see gof_binning_bytes_for.  SYNCHRONISES `stream`.
- *   gof_backward_scratch_bytes_for(P, R, staged):    the size for a pool of exactly that many records (4 + 68 x staged / R bytes per
+ *   gof_backward_scratch_bytes_for(P, R, staged):    the size for a pool of exactly that many records (4 + 64 x staged / R bytes per
  *                                                    instance instead of 72).
  * The backward derives the pool's capacity from the scratch_bytes it is given.  A pool smaller than what the frame stages (impossible
  * with either size above) drops the records that do not fit: see gof_forward_usage_async for the caller that sizes it from earlier frames. */
