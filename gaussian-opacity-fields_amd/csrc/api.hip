@@ -52,11 +52,12 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                   uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
-                                  size_t zero_words_behind);
+                                  size_t zero_words_behind, bool hist_done);
+uint32_t* radix_single_kernel_begin(uint32_t* tmp, size_t n, int end_bit, hipStream_t stream);
 int radix_passes(int end_bit);
 uint32_t emit_instances_grid(uint32_t slots, int P);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first);
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first, uint32_t* digit_hist, int npass);
 __global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev, const uint32_t* sort_error,
@@ -340,12 +341,12 @@ static inline Dims dims_of(const GofRasterArgs* a)
 // Sort (tile, id) instances by tile; the instances were emitted into the buffer pair chosen so that the
 // result of the final pass lands in (b.tiles, b.vals).
 static int sort_by_tile(const BinWs& b, uint32_t n, uint32_t* tiles_in, uint32_t* vals_in, int tile_bits, hipStream_t stream,
-                        const uint32_t* n_dev = nullptr)
+                        const uint32_t* n_dev = nullptr, bool hist_done = false)
 {
     uint32_t* tiles_other = (tiles_in == b.tiles) ? b.tiles_alt : b.tiles;
     uint32_t* vals_other = (vals_in == b.vals) ? b.vals_alt : b.vals;
     uint32_t *kr = nullptr, *vr = nullptr;
-    GOF_HIP_CHECK(radix_sort_pairs_u32(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev));
+    GOF_HIP_CHECK(radix_sort_pairs_u32_z(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev, 0, hist_done));
     if (kr != b.tiles || vr != b.vals) { set_error("internal: sort result in the wrong buffer"); return GOF_E_DEVICE; }
     return GOF_OK;
 }
@@ -361,13 +362,17 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         const bool odd = radix_passes(tile_bits) & 1;
         uint32_t* t_in = odd ? b.tiles_alt : b.tiles;
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
+        // where the tile sort runs as single-kernel passes, its scratch is cleared in FRONT of the emission and the emission counts the
+        // digits of every tile id it writes: the sort starts without its histogram launch (a read of all keys)
+        static const bool emit_counts = [] { const char* e = getenv("GOF_EMIT_HIST"); return !(e && e[0] == '0'); }();      // (developer A/B)
+        uint32_t* const digit_hist = emit_counts ? radix_single_kernel_begin(b.sort_tmp, R, tile_bits, stream) : nullptr;
         { GOF_PROFILE("emit_instances", stream);
         // one wave per EMIT_SLOTS output slots (R: the instance count, or the workspace's capacity when only the device knows the count)
         hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R, a->P)), dim3(256), 0, stream, a->P, g.dval_a,
-                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first); }
+                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first, digit_hist, radix_passes(tile_bits)); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
-        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev);
+        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev, digit_hist != nullptr);
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
@@ -540,7 +545,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
     GOF_HIP_CHECK(radix_sort_pairs_u32_z(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream, nullptr,
-                                         fused_scan ? gather_scan_state_words((size_t)a->P) : 0));
+                                         fused_scan ? gather_scan_state_words((size_t)a->P) : 0, false));
     if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)

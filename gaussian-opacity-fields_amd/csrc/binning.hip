@@ -210,8 +210,15 @@ uint32_t emit_instances_grid(uint32_t slots, int P)
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
                const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity,
-               uint32_t* __restrict__ inst_first)
+               uint32_t* __restrict__ inst_first, uint32_t* __restrict__ digit_hist, int npass)
 {
+    // digit_hist (nullable): the global digit histograms of the tile sort's single-kernel passes (radix.hip: radix_single_kernel_begin), pass k
+    // at [256 k]: every tile id is counted as it is written -- the sort then starts without a histogram launch and without a read of the keys
+    __shared__ uint32_t s_h[4][256];
+    if (digit_hist) {
+        for (int k = 0; k < npass; k++) s_h[k][threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     if (inst_first)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)P; i += gridDim.x * 256u) {
@@ -225,7 +232,7 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     const uint32_t total = order_off[P - 1] + (wh_last & 0xFFFFu) * (wh_last >> 16);
     const uint32_t limit = min(total, capacity);       // capacity < the instance count only in the sync-free forward (then redone)
     const uint64_t p0_wide = (uint64_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * EMIT_SLOTS;
-    if (p0_wide >= (uint64_t)limit) return;             // (wave-uniform)
+    if (p0_wide < (uint64_t)limit) {                    // (wave-uniform; no early return: the histogram's barrier below is the workgroup's)
     const uint32_t p0 = (uint32_t)p0_wide;
     const uint32_t p1 = (uint32_t)min((uint64_t)limit, p0_wide + EMIT_SLOTS);
     // 1. the last position i of the order with order_off[i] <= p0 (offsets are non-decreasing, order_off[0] = 0 <= p0; a run of equal
@@ -271,14 +278,26 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
             }
             const uint32_t o_off = (uint32_t)__shfl((int)off, l), o_w = (uint32_t)__shfl((int)w, l), o_minx = (uint32_t)__shfl((int)minx, l),
                            o_miny = (uint32_t)__shfl((int)miny, l), o_idx = (uint32_t)__shfl((int)idx, l);
+            uint32_t t = 0;
             if (p < end) {
                 const uint32_t k = p - o_off;
                 const uint32_t y = k / o_w, x = k - y * o_w;
-                tiles[p] = (o_miny + y) * gx + (o_minx + x);
+                t = (o_miny + y) * gx + (o_minx + x);
+                tiles[p] = t;
                 gids[p] = o_idx;
             }
+            if (digit_hist)
+                for (int k = 0; k < npass; k++) os_count(s_h[k], (t >> (8 * k)) & 0xFFu, p < end);
         }
         if (group_end >= p1 || g0 + 64u >= (uint32_t)P) break;      // (wave-uniform)
+    }
+    }
+    if (digit_hist) {
+        __syncthreads();
+        for (int k = 0; k < npass; k++) {
+            const uint32_t c = s_h[k][threadIdx.x];
+            if (c) atomicAdd(&digit_hist[256 * k + threadIdx.x], c);
+        }
     }
 }
 

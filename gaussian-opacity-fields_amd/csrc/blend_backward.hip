@@ -75,6 +75,11 @@ static_assert(BATCH == 32 || BATCH == 64 || BATCH == 128, "BATCH must be 32, 64 
 #error "GOF_BW_REDUCE: 0 (register swaps) or 2 (LDS panel, two halves)"
 #endif
 constexpr int RED_STRIDE = 68;
+// GOF_BW_STAGE: who stages a batch's records -- 0 (shipped): one thread per entry (wave 0 at 64 entries per batch); 1: a quad of lanes
+// per entry, all four waves (measured: profiles/r05_ab_call6_*.txt)
+#ifndef GOF_BW_STAGE
+#define GOF_BW_STAGE 0
+#endif
 
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] wave iterations of the entry loop, [1] (row, iteration) pairs with
@@ -253,6 +258,35 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         __syncthreads();
         const uint32_t p0 = (uint32_t)kb * BATCH;
         const int n = (int)min((uint32_t)BATCH, max_last - p0);
+#if GOF_BW_STAGE == 1
+        {
+            // staging by all four waves (round 5, A/B): a QUAD of lanes per entry, lane q loads the q-th 16-byte quarter of the record (one
+            // 64-byte line per quad) and its share of the entry's other words -- a fourth of the loads per wave and no wave idling at the
+            // barrier behind wave 0's gathers; the pair layout's mixed words travel between the quad's lanes by DPP
+            const uint32_t e = tid >> 2, q = tid & 3u;
+            const bool live = (int)e < n;
+            const uint32_t id = live ? point_list[range.x + p0 + e] : 0u;
+            const float4 ch = live ? reinterpret_cast<const float4*>(&rec[id])[q] : make_float4(0.f, 0.f, 0.f, 0.f);      // a | b | c | d
+            float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 rc = make_uint2(0u, 0u);
+            uint32_t io = 0u;
+            if (live && q == 0u) co = conic[id];
+            if (live && q == 1u) { rc = rect[id]; io = inst_off[id]; }
+            // words of the neighbouring quarters: from lane q - 1 (quad_perm [0,0,1,2]) and lane q + 1 (quad_perm [1,2,3,3])
+            const float prev_z = dpp_get<0x90>(ch.z);       // q = 1: a.z
+            const float next_x = dpp_get<0xF9>(ch.x);       // q = 1: c.x, q = 2: d.x
+            if (live) {
+                if (q == 0u) { s_rec[0][e] = f4{ ch.x, ch.y, ch.y, ch.w }; s_rec[5][e] = f4{ co.x, co.z, co.y, co.y }; }
+                else if (q == 1u) {
+                    s_rec[1][e] = f4{ prev_z, ch.x, prev_z, ch.z };
+                    s_rec[2][e] = f4{ ch.x, ch.w, ch.y, next_x };
+                    s_inst[e] = io + (ty - (rc.x >> 16)) * (rc.y & 0xFFFFu) + (tx - (rc.x & 0xFFFFu));
+                }
+                else if (q == 2u) s_rec[3][e] = f4{ ch.y, ch.z, ch.w, next_x };
+                else s_rec[4][e] = f4{ ch.y, 0.f, ch.z, ch.w };
+            }
+        }
+#else
         {
             // staging: one thread per entry reads the 64-byte record + the 2D conic and writes the pair layout
             if ((int)tid < n) {
@@ -272,6 +306,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 s_inst[tid] = inst_off[id] + (ty - (rc.x >> 16)) * (rc.y & 0xFFFFu) + (tx - (rc.x & 0xFFFFu));
             }
         }
+#endif
         // the pixel's contributor words of this batch: read by their own thread only -- registers, not LDS
         uint32_t cmw[BATCH / 32];
         {

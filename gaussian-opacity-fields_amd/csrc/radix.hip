@@ -322,26 +322,6 @@ constexpr uint32_t OS_MAX_UNITS = GOF_OS_MAX_UNITS;          // tiles of RS_BLOC
 constexpr int OS_LOOKBACK = GOF_OS_LOOKBACK;                 // predecessor descriptors requested per look-back round trip (os_pass)
 constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
 
-// Counting with few LDS atomics where the digits of a wave are few: the high bytes of depth keys take a handful of values (sign,
-// exponent), those of tile ids one or two -- a same-address ds_add serialises its lanes (~3.5 cycles each).  Up to four groups of
-// equal digits are peeled off with one ballot each and counted by one lane; what is left (digits spread over the bins: few conflicts)
-// is counted lane by lane.
-__device__ __forceinline__ void os_count(uint32_t* __restrict__ h, uint32_t d, bool valid)
-{
-    uint64_t rem = __ballot(valid);
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll 1
-    for (int g = 0; g < 4 && rem; g++) {
-        const int first = (int)__builtin_ctzll(rem);
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-        const uint64_t m = __ballot(valid && d == d0) & rem;
-        const uint32_t c = (uint32_t)__popcll(m);
-        if (c < 8u) break;                                  // (wave-uniform) not a crowded digit: the rest goes lane by lane
-        if (lane == (uint32_t)first) atomicAdd(&h[d0], c);
-        rem &= ~m;
-    }
-    if ((rem >> lane) & 1ull) atomicAdd(&h[d], 1u);
-}
 // one block per RS_BLOCK keys (grid-stride beyond 1024 blocks): all of a thread's loads of a round are in flight together
 __global__ void __launch_bounds__(256)
 os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase, const uint32_t* __restrict__ n_dev)
@@ -507,7 +487,7 @@ size_t rs_tmp_words(size_t n)
 // single-kernel passes need anyway where it ends there, by one of its own otherwise (the caller's next kernel keeps its state there).
 hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                   uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
-                                  size_t zero_words_behind)
+                                  size_t zero_words_behind, bool hist_done)
 {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     const int npass = (end_bit + 7) / 8;
@@ -522,12 +502,14 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
             uint32_t* tickets = tmp + OS_MAX_PASSES * RS_DIGITS;
             uint32_t* err = tickets + 8;
             uint32_t* desc = tmp + OS_HDR;
+            if (!hist_done) {            // (else: radix_single_kernel_begin cleared the scratch and the caller's producer kernel counted the digits)
             size_t zero_words = (size_t)OS_HDR + (size_t)npass * hwords;
             if (zero_words_behind && zero_words == rs_tmp_words(n)) { zero_words += zero_words_behind; zero_words_behind = 0; }
             hipError_t e = hipMemsetAsync(tmp, 0, zero_words * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
             if (zero_words_behind) { e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
             hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase, n_dev);
+            }
             for (int p = 0; p < npass; p++) {
                 hipLaunchKernelGGL(os_pass, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, 8 * p, gbase + p * RS_DIGITS,
                                    desc + (size_t)p * hwords, tickets + p, err, n_dev);
@@ -560,7 +542,17 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev)
 {
-    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0);
+    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0, false);
+}
+// Clears the scratch of a sort of n pairs on end_bit bits and returns where its global digit histograms lie (pass p: RS_DIGITS words at
+// [p * RS_DIGITS]) if that sort runs as single-kernel passes, else nullptr (nothing was queued; sort without hist_done).
+uint32_t* radix_single_kernel_begin(uint32_t* tmp, size_t n, int end_bit, hipStream_t stream)
+{
+    const int npass = (end_bit + 7) / 8;
+    if (n == 0 || npass <= 0 || rs_units(n) > OS_MAX_UNITS || npass > OS_MAX_PASSES) return nullptr;
+    const size_t hwords = (size_t)RS_DIGITS * rs_units(n);
+    if (hipMemsetAsync(tmp, 0, ((size_t)OS_HDR + (size_t)npass * hwords) * sizeof(uint32_t), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return tmp;
 }
 int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
 
