@@ -33,13 +33,14 @@ KERNEL_SOURCES = {
     "blend_forward": "blend_forward.hip", "blend_forward_exact": "blend_forward.hip",
     "blend_backward": "blend_backward.hip", "gather_tile_partials": "blend_backward.hip",
     "preprocess_fwd": "preprocess.hip", "preprocess_fwd_heavy": "preprocess.hip", "preprocess_bwd": "preprocess.hip", "preprocess_points": "preprocess.hip",
-    "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_rects": "binning.hip",
+    "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_rects": "binning.hip", "gather_scan_rects": "binning.hip",
     "point_keys": "binning.hip", "gather_sorted_points": "binning.hip",
     "os_hist": "radix.hip", "os_pass": "radix.hip", "rs_hist": "radix.hip", "rs_scatter": "radix.hip", "scan_block": "radix.hip",
     "integrate_pixels": "integrate.hip", "integrate_points": "integrate.hip", "integrate_rays": "integrate.hip", "integrate_pixels_capped": "integrate.hip",
     "rot3_apply_kernel": "gaussian_model_ops.hip",
 }
 SHARED_HEADERS = ("gof_common.h", "gof_status.h")
+EXTRA_HEADERS = {"radix.hip": ("gof_digit_count.h",)}      # headers only these translation units include
 
 
 def kernel_sha16(kernel=None):
@@ -48,7 +49,7 @@ def kernel_sha16(kernel=None):
     import hashlib
     h = hashlib.sha256()
     files = ("blend_forward.hip", "blend_backward.hip") if kernel is None else (KERNEL_SOURCES.get(kernel, kernel + ".hip"),)
-    for f in tuple(files) + SHARED_HEADERS:
+    for f in tuple(files) + SHARED_HEADERS + tuple(h for src in files for h in EXTRA_HEADERS.get(src, ())):
         path = os.path.join(ROOT, "gaussian-opacity-fields_amd", "csrc", f)
         if os.path.exists(path):
             h.update(open(path, "rb").read())

@@ -52,12 +52,11 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                   uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
-                                  size_t zero_words_behind, bool hist_done);
-uint32_t* radix_single_kernel_begin(uint32_t* tmp, size_t n, int end_bit, hipStream_t stream);
+                                  size_t zero_words_behind);
 int radix_passes(int end_bit);
 uint32_t emit_instances_grid(uint32_t slots, int P);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first, uint32_t* digit_hist, int npass);
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first);
 __global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev, const uint32_t* sort_error,
@@ -340,13 +339,15 @@ static inline Dims dims_of(const GofRasterArgs* a)
 
 // Sort (tile, id) instances by tile; the instances were emitted into the buffer pair chosen so that the
 // result of the final pass lands in (b.tiles, b.vals).
+// grid of a tile_ranges launch over up to n items (grid-stride kernel): at most 64 workgroups per CU
+static inline uint32_t tile_ranges_grid(uint32_t n) { const uint32_t b = (n + 255u) / 256u; return b < 16384u ? (b ? b : 1u) : 16384u; }
 static int sort_by_tile(const BinWs& b, uint32_t n, uint32_t* tiles_in, uint32_t* vals_in, int tile_bits, hipStream_t stream,
-                        const uint32_t* n_dev = nullptr, bool hist_done = false)
+                        const uint32_t* n_dev = nullptr)
 {
     uint32_t* tiles_other = (tiles_in == b.tiles) ? b.tiles_alt : b.tiles;
     uint32_t* vals_other = (vals_in == b.vals) ? b.vals_alt : b.vals;
     uint32_t *kr = nullptr, *vr = nullptr;
-    GOF_HIP_CHECK(radix_sort_pairs_u32_z(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev, 0, hist_done));
+    GOF_HIP_CHECK(radix_sort_pairs_u32(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev));
     if (kr != b.tiles || vr != b.vals) { set_error("internal: sort result in the wrong buffer"); return GOF_E_DEVICE; }
     return GOF_OK;
 }
@@ -362,17 +363,16 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         const bool odd = radix_passes(tile_bits) & 1;
         uint32_t* t_in = odd ? b.tiles_alt : b.tiles;
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
-        // where the tile sort runs as single-kernel passes, its scratch is cleared in FRONT of the emission and the emission counts the
-        // digits of every tile id it writes: the sort starts without its histogram launch (a read of all keys)
-        static const bool emit_counts = [] { const char* e = getenv("GOF_EMIT_HIST"); return !(e && e[0] == '0'); }();      // (developer A/B)
-        uint32_t* const digit_hist = emit_counts ? radix_single_kernel_begin(b.sort_tmp, R, tile_bits, stream) : nullptr;
+        // (measured and dropped, round 5, profiles/r05_ab_call6_binning.txt: the emission counting the tile sort's digits as it writes the
+        // tile ids -- no histogram launch, no read of the keys for it -- doubled emit_instances, 0.040 -> 0.084 ms at S1M; and the tile
+        // sort as single-kernel passes at all lost to histogram / scan / scatter beyond 2 M pairs: 0.38 vs 0.23 ms)
         { GOF_PROFILE("emit_instances", stream);
         // one wave per EMIT_SLOTS output slots (R: the instance count, or the workspace's capacity when only the device knows the count)
         hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R, a->P)), dim3(256), 0, stream, a->P, g.dval_a,
-                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first, digit_hist, radix_passes(tile_bits)); }
+                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
-        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev, digit_hist != nullptr);
+        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev);
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
@@ -382,7 +382,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
     if (!n_dev) GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (R > 0) {
         GOF_PROFILE("tile_ranges", stream);
-        hipLaunchKernelGGL(tile_ranges, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev,
+        hipLaunchKernelGGL(tile_ranges, dim3(tile_ranges_grid(R)), dim3(256), 0, stream, R, b.tiles, im.ranges, 0, n_dev,
                            radix_sort_error_flag(b.sort_tmp, (size_t)R, tile_bits), async_status_word());
         GOF_LAUNCH_CHECK(stream, dbg);
     }
@@ -462,33 +462,52 @@ size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullpt
 // the depth sort, scan, emission, tile sort and ranges, and the caller's stream waits for it in front of the blend.  The fork and the
 // join are events between the two streams: to the caller (and to torch's caching allocator) everything stays ordered on ITS stream.
 // GOF_K1_SPLIT=0 in the environment keeps the one-kernel form.
+#ifndef GOF_K1_SPLIT_DEFAULT
+#define GOF_K1_SPLIT_DEFAULT 1
+#endif
 namespace {
+// GOF_K1_SPLIT: 0 = one kernel; 1 = stage 2 on the library's second stream, the binning chain stays on the caller's;
+// 2 = the other way round: the binning chain (depth sort ... tile order: short, latency-bound launches, the forward's critical path) runs
+// on the library's stream created with the device's HIGHEST priority, stage 2 on the caller's stream -- the device offers no priority
+// BELOW the caller's to push stage 2 down with, but one above it to lift the chain with
+int k1_split_mode()
+{
+    static const int mode = [] { const char* e = getenv("GOF_K1_SPLIT"); return e ? atoi(e) : GOF_K1_SPLIT_DEFAULT; }();
+    return mode;
+}
 struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
 AuxStream* aux_stream()
 {
-    static const bool enabled = [] { const char* e = getenv("GOF_K1_SPLIT"); return !(e && e[0] == '0'); }();
-    if (!enabled) return nullptr;
+    if (k1_split_mode() == 0) return nullptr;
     static thread_local AuxStream per_device[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     AuxStream& a = per_device[dev];
     if (a.failed) return nullptr;
     if (!a.fork) {
-        // lowest priority: the binning chain on the caller's stream is the critical path (a chain of short, latency-bound launches);
-        // stage 2 should take the execution slots they leave, not the other way round
         int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; greatest = 0; }
         static const int prio_env = [] { const char* e = getenv("GOF_K1_SPLIT_PRIORITY"); return e ? atoi(e) : 0x7fffffff; }();      // (developer A/B)
-        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, prio_env == 0x7fffffff ? least : prio_env) != hipSuccess || hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+        const int prio = prio_env != 0x7fffffff ? prio_env : (k1_split_mode() == 2 ? greatest : least);
+        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); a.failed = true; return nullptr; }
     }
     return &a;
 }
-// makes `stream` wait for the second stream's work of this call: explicitly in front of the first consumer, and on every other way out
+// makes `stream` (the caller's) wait for the library stream's work of this call: explicitly in front of the first consumer, and on every
+// other way out.  record_on: (mode 2) the library's stream carries the binning chain, whose last launch is only known to the caller of
+// forward_stage1 -- the join event is recorded on it when the join is asked for
 struct AuxJoin {
     hipStream_t stream = nullptr;
     hipEvent_t pending = nullptr;
-    void now() { if (pending) { (void)hipStreamWaitEvent(stream, pending, 0); pending = nullptr; } }
+    hipStream_t record_on = nullptr;
+    void now()
+    {
+        if (!pending) return;
+        if (record_on) (void)hipEventRecord(pending, record_on);
+        (void)hipStreamWaitEvent(stream, pending, 0);
+        pending = nullptr;
+    }
     ~AuxJoin() { now(); }
 };
 }
@@ -496,8 +515,9 @@ struct AuxJoin {
 // preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
 // join (nullable): the caller can take stage 2 of the per-Gaussian kernel on the second stream; it must call join->now() in front of
 // the first launch that reads the records / conics / footprints / depths / clamp flags
+// chain_stream (with join): the stream the caller queues the rest of the binning chain on (the caller's, or in mode 2 the library's)
 static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream,
-                          uint32_t* total_host_mapped = nullptr, AuxJoin* join = nullptr)
+                          uint32_t* total_host_mapped = nullptr, AuxJoin* join = nullptr, hipStream_t* chain_stream = nullptr)
 {
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
@@ -525,17 +545,21 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     // (measured, profiles/r05_ab_call5_split_preprocess.txt: S1M 2.459 -> 2.434 ms per step, 6M Gaussians 4.18 -> 4.13, means over three
     // boxes each -- the two streams share the CUs, the depth sort runs 0.108 -> 0.166 ms beside stage 2; forking BEHIND the depth sort
     // instead loses: 2.468 / 4.18.  The device offers no priority below the caller's stream's to put stage 2 on.)
+    const bool chain_on_aux = aux && chain_stream && k1_split_mode() == 2;
     if (aux) {
         GOF_HIP_CHECK(hipGetLastError());
         GOF_HIP_CHECK(hipEventRecord(aux->fork, stream));
         GOF_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));
-        { GOF_PROFILE("preprocess_fwd_heavy", aux->s);
-          GOF_K1_LAUNCH(0, 2, aux->s); }
+        hipStream_t const heavy_stream = chain_on_aux ? stream : aux->s;
+        { GOF_PROFILE("preprocess_fwd_heavy", heavy_stream);
+          GOF_K1_LAUNCH(0, 2, heavy_stream); }
         GOF_HIP_CHECK(hipGetLastError());
-        GOF_HIP_CHECK(hipEventRecord(aux->join, aux->s));
         join->stream = stream;
         join->pending = aux->join;
+        if (chain_on_aux) { join->record_on = aux->s; *chain_stream = aux->s; }
+        else GOF_HIP_CHECK(hipEventRecord(aux->join, aux->s));
     }
+    if (chain_on_aux) stream = aux->s;            // from here on: the binning chain
 #undef GOF_K1_LAUNCH
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
@@ -545,7 +569,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
     GOF_HIP_CHECK(radix_sort_pairs_u32_z(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream, nullptr,
-                                         fused_scan ? gather_scan_state_words((size_t)a->P) : 0, false));
+                                         fused_scan ? gather_scan_state_words((size_t)a->P) : 0));
     if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)
@@ -634,19 +658,20 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     uint32_t* const usage_mapped = device_view_of_pinned(usage_pinned_host);
     *num_rendered_pinned_host = 0xFFFFFFFFu;
     AuxJoin heavy;                       // (its destructor joins on every way out of this call)
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream, count_mapped, &heavy);
+    hipStream_t cs = stream;             // the stream of the binning chain: the caller's, or (GOF_K1_SPLIT=2) the library's high-priority one
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream, count_mapped, &heavy, &cs);
     if (rc) return rc;
     static thread_local hipEvent_t ev = nullptr;
     if (!ev) GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    if (!count_mapped) GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GOF_HIP_CHECK(hipEventRecord(ev, stream));
+    if (!count_mapped) GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    GOF_HIP_CHECK(hipEventRecord(ev, cs));
     if (capacity > 0) {
-        rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
+        rc = bin_gaussians(a, d, capacity, g, b, im, radii, cs, total_dev);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, cs, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr);
     }
-    heavy.now();                         // records, conics and footprints are stage 2's: the blend is their first reader
+    heavy.now();                         // the two streams meet: records, conics and footprints are stage 2's, lists and ranges the chain's -- the blend is their first reader
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
     order_tiles_for_backward(d, im, stream, usage_mapped);
@@ -1026,7 +1051,7 @@ static int integrate_points_impl(const GofRasterArgs* a, uint32_t R, int32_t PN,
     }
     GOF_HIP_CHECK(hipMemsetAsync(im.point_ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
     if (NI > 0) {
-        hipLaunchKernelGGL(tile_ranges, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr,
+        hipLaunchKernelGGL(tile_ranges, dim3(tile_ranges_grid(NI)), dim3(256), 0, stream, NI, pb.tiles, im.point_ranges, 8, nullptr,
                            radix_sort_error_flag(pb.sort_tmp, (size_t)NI, (int)higher_msb(d.ntiles) + 8), async_status_word());
         GOF_LAUNCH_CHECK(stream, a->debug);
         hipLaunchKernelGGL(gather_sorted_points, dim3((NI + 255) / 256), dim3(256), 0, stream, NI, pb.vals, w.pos, pb.pt_xy, pb.pt_depth, a->W, a->H,

@@ -107,8 +107,12 @@ gather_scan_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __
 #pragma unroll
     for (int s = 0; s < GS_ITEMS; s++) {
         const uint32_t i = wbase + 64u * s + lane;
-        ord[s] = 0xFFFFFFFFu;                          // no rectangle to read: past the end, a failed sort, or a culled Gaussian (key 0xFFFFFFFF)
-        if (i < n && !failed && !(keys_sorted && keys_sorted[i] == 0xFFFFFFFFu)) ord[s] = order[i];
+        // no rectangle to read (0xFFFFFFFF): past the end, a failed sort, or a culled Gaussian (sort key 0xFFFFFFFF: gather_rects).  Key
+        // and id are requested together -- one round trip, not two: this kernel is a chain of dependent loads
+        const bool ok = i < n && !failed;
+        const uint32_t key = (ok && keys_sorted) ? keys_sorted[i] : 0u;
+        const uint32_t id = ok ? order[i] : 0xFFFFFFFFu;
+        ord[s] = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : id;
     }
 #pragma unroll
     for (int s = 0; s < GS_ITEMS; s++) r[s] = (ord[s] != 0xFFFFFFFFu) ? rect[ord[s]] : make_uint2(0u, 0u);
@@ -210,15 +214,8 @@ uint32_t emit_instances_grid(uint32_t slots, int P)
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
                const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity,
-               uint32_t* __restrict__ inst_first, uint32_t* __restrict__ digit_hist, int npass)
+               uint32_t* __restrict__ inst_first)
 {
-    // digit_hist (nullable): the global digit histograms of the tile sort's single-kernel passes (radix.hip: radix_single_kernel_begin), pass k
-    // at [256 k]: every tile id is counted as it is written -- the sort then starts without a histogram launch and without a read of the keys
-    __shared__ uint32_t s_h[4][256];
-    if (digit_hist) {
-        for (int k = 0; k < npass; k++) s_h[k][threadIdx.x] = 0u;
-        __syncthreads();
-    }
     const uint32_t lane = threadIdx.x & 63u;
     if (inst_first)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)P; i += gridDim.x * 256u) {
@@ -232,7 +229,7 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     const uint32_t total = order_off[P - 1] + (wh_last & 0xFFFFu) * (wh_last >> 16);
     const uint32_t limit = min(total, capacity);       // capacity < the instance count only in the sync-free forward (then redone)
     const uint64_t p0_wide = (uint64_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * EMIT_SLOTS;
-    if (p0_wide < (uint64_t)limit) {                    // (wave-uniform; no early return: the histogram's barrier below is the workgroup's)
+    if (p0_wide >= (uint64_t)limit) return;             // (wave-uniform)
     const uint32_t p0 = (uint32_t)p0_wide;
     const uint32_t p1 = (uint32_t)min((uint64_t)limit, p0_wide + EMIT_SLOTS);
     // 1. the last position i of the order with order_off[i] <= p0 (offsets are non-decreasing, order_off[0] = 0 <= p0; a run of equal
@@ -278,26 +275,14 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
             }
             const uint32_t o_off = (uint32_t)__shfl((int)off, l), o_w = (uint32_t)__shfl((int)w, l), o_minx = (uint32_t)__shfl((int)minx, l),
                            o_miny = (uint32_t)__shfl((int)miny, l), o_idx = (uint32_t)__shfl((int)idx, l);
-            uint32_t t = 0;
             if (p < end) {
                 const uint32_t k = p - o_off;
                 const uint32_t y = k / o_w, x = k - y * o_w;
-                t = (o_miny + y) * gx + (o_minx + x);
-                tiles[p] = t;
+                tiles[p] = (o_miny + y) * gx + (o_minx + x);
                 gids[p] = o_idx;
             }
-            if (digit_hist)
-                for (int k = 0; k < npass; k++) os_count(s_h[k], (t >> (8 * k)) & 0xFFu, p < end);
         }
         if (group_end >= p1 || g0 + 64u >= (uint32_t)P) break;      // (wave-uniform)
-    }
-    }
-    if (digit_hist) {
-        __syncthreads();
-        for (int k = 0; k < npass; k++) {
-            const uint32_t c = s_h[k][threadIdx.x];
-            if (c) atomicAdd(&digit_hist[256 * k + threadIdx.x], c);
-        }
     }
 }
 
@@ -351,22 +336,24 @@ tile_ranges(uint32_t L, const uint32_t* __restrict__ tiles, uint2* __restrict__ 
             const uint32_t* __restrict__ sort_error, uint32_t* __restrict__ async_status)
 {
     L = device_item_count(L, n_dev);
-    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (sort_error && *sort_error) {
-        if (idx == 0 && async_status) *async_status = 1u;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && async_status) *async_status = 1u;
         return;
     }
-    if (idx >= L) return;
-    const uint32_t currtile = tiles[idx] >> shift;
-    if (idx == 0) ranges[currtile].x = 0;
-    else {
-        const uint32_t prevtile = tiles[idx - 1] >> shift;
-        if (currtile != prevtile) {
-            ranges[prevtile].y = idx;
-            ranges[currtile].x = idx;
+    // grid-stride (api.hip caps the grid: a launch sized for a capacity far above the count -- learnt on another view -- costs no
+    // empty workgroups)
+    for (uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < L; idx += gridDim.x * 256u) {
+        const uint32_t currtile = tiles[idx] >> shift;
+        if (idx == 0) ranges[currtile].x = 0;
+        else {
+            const uint32_t prevtile = tiles[idx - 1] >> shift;
+            if (currtile != prevtile) {
+                ranges[prevtile].y = idx;
+                ranges[currtile].x = idx;
+            }
         }
+        if (idx == L - 1) ranges[currtile].y = L;
     }
-    if (idx == L - 1) ranges[currtile].y = L;
 }
 
 // Dispatch order of the tile kernels (pop_tile, gof_common.h).  ONE workgroup:

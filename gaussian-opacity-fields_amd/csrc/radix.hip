@@ -17,6 +17,7 @@
 //                 writes each digit's run contiguously at its global offset (coalesced).
 #include "gof_common.h"
 #include "gof_status.h"
+#include "gof_digit_count.h"
 
 namespace gof {
 
@@ -56,10 +57,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
     return base + inc - v;
 }
 
+// hist_items_dev (nullable; the radix sort's [digit][block] histogram of a launch sized for a CAPACITY, rs_hist): the scan covers only
+// the blocks that hold items -- RS_DIGITS x ceil(count / RS_BLOCK) words; the workgroups past that write a zero sum and leave
+__device__ __forceinline__ uint32_t hist_words(uint32_t n, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity);
 __global__ void __launch_bounds__(256)
-scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums)
+scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity)
 {
     __shared__ uint32_t s_wave[4];
+    n = hist_words(n, hist_items_dev, capacity);
+    if (blockIdx.x * SCAN_BLOCK >= n) { if (threadIdx.x == 0) sums[blockIdx.x] = 0u; return; }
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
 #pragma unroll
@@ -93,9 +99,13 @@ scan_sums(uint32_t* __restrict__ sums, uint32_t nb, uint32_t* __restrict__ total
 template <bool INCLUSIVE, bool GATHER, bool DIRECT>
 __global__ void __launch_bounds__(256)
 scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ sums,
-           uint32_t* __restrict__ out, uint32_t* __restrict__ total_host)
+           uint32_t* __restrict__ out, uint32_t* __restrict__ total_host, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity)
 {
     __shared__ uint32_t s_wave[4];
+    if (hist_items_dev) {                           // (nobody reads the grand total of a histogram scan)
+        n = hist_words(n, hist_items_dev, capacity);
+        if (blockIdx.x * SCAN_BLOCK >= n) return;
+    }
     uint32_t before = 0;
     if (DIRECT) {
         __shared__ uint32_t s_pre[4];
@@ -149,8 +159,9 @@ size_t scan_tmp_words(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK + 2; 
 // out = scan(in[idx]) if idx != nullptr else scan(in).  tmp: scan_tmp_words(n) u32.  The grand total is left in
 // tmp[nblocks] (device); total_dev_out (optional) receives its address.
 // total_host (nullable): a DEVICE-VISIBLE address of host memory (hipHostGetDevicePointer) that receives the grand total as well.
-hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
-                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host)
+static hipError_t device_scan_impl(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host,
+                                   const uint32_t* hist_items_dev, uint32_t capacity)
 {
     const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (total_dev_out) *total_dev_out = tmp + nb;
@@ -159,16 +170,21 @@ hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint
         return hipMemsetAsync(tmp, 0, 2 * sizeof(uint32_t), stream);
     }
     if (idx) hipLaunchKernelGGL(scan_block_sums_gather<true>, dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp);
-    else hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, stream, in, (uint32_t)n, tmp);
+    else hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, stream, in, (uint32_t)n, tmp, hist_items_dev, capacity);
     const bool direct = nb <= SCAN_DIRECT_MAX;         // few workgroups: each adds up its predecessors' sums itself, two launches
     if (!direct) hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, tmp, nb, total_host);
 #define GOF_SCAN_APPLY(INC, GA)                                                                                                        \
-    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, total_host);   \
-         else hipLaunchKernelGGL((scan_apply<INC, GA, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, (uint32_t*)nullptr); } while (0)
+    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, total_host, hist_items_dev, capacity);   \
+         else hipLaunchKernelGGL((scan_apply<INC, GA, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, (uint32_t*)nullptr, hist_items_dev, capacity); } while (0)
     if (idx) { if (inclusive) GOF_SCAN_APPLY(true, true); else GOF_SCAN_APPLY(false, true); }
     else { if (inclusive) GOF_SCAN_APPLY(true, false); else GOF_SCAN_APPLY(false, false); }
 #undef GOF_SCAN_APPLY
     return hipGetLastError();
+}
+hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host)
+{
+    return device_scan_impl(in, idx, out, n, inclusive, tmp, total_dev_out, stream, total_host, nullptr, 0);
 }
 hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
                            const uint32_t** total_dev_out, hipStream_t stream)
@@ -198,12 +214,30 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid)
 // ---- block kernels: 256 threads, RS_BLOCK items; wave w owns the contiguous quarter [w*RS_BLOCK/4, ...) ----
 constexpr int RS_STEPS = RS_CHUNK / 64;              // steps of 64 items per wave
 constexpr int RS_BLOCK = 4 * RS_CHUNK;               // items per block
+// blocks of a sort launch sized for `capacity` items that hold items when the count lives on the device (never 0: block 0 then
+// writes an all-zero histogram row) -- the stride of the [digit][block] histogram and the bound of its scan
+__device__ __forceinline__ uint32_t rs_active_blocks(uint32_t capacity, const uint32_t* __restrict__ n_dev)
+{
+    const uint32_t n = device_item_count(capacity, n_dev);
+    return n ? (n + RS_BLOCK - 1) / RS_BLOCK : 1u;
+}
+__device__ __forceinline__ uint32_t hist_words(uint32_t n, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity)
+{
+    if (!hist_items_dev) return n;
+    const uint32_t w = (uint32_t)RS_DIGITS * rs_active_blocks(capacity, hist_items_dev);
+    return w < n ? w : n;
+}
 
 __global__ void __launch_bounds__(256)
 rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nblocks,
         const uint32_t* __restrict__ n_dev)
 {
-    n = device_item_count(n, n_dev);            // device-side item count (sync-free forward): n is then the capacity
+    // device-side item count (sync-free forward): n is then the capacity.  Only the blocks that hold items take part, and they are the
+    // histogram's stride: its scan and the scatter's blocks past the count cost nothing (a capacity learnt on the view with the most
+    // instances serves every view)
+    if (n_dev) nblocks = rs_active_blocks(n, n_dev);
+    if (blockIdx.x >= nblocks) return;
+    n = device_item_count(n, n_dev);
     // counting only (no ranks needed here): one LDS atomic per item, all 16 loads of a thread in flight together
     __shared__ uint32_t s_cnt[RS_DIGITS];
     s_cnt[threadIdx.x] = 0;
@@ -225,6 +259,8 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
            uint32_t* __restrict__ vals_out, uint32_t n, int shift, const uint32_t* __restrict__ offs, uint32_t nblocks,
            const uint32_t* __restrict__ n_dev)
 {
+    if (n_dev) nblocks = rs_active_blocks(n, n_dev);      // (as rs_hist)
+    if (blockIdx.x >= nblocks) return;
     n = device_item_count(n, n_dev);
     __shared__ uint32_t s_cur[4][RS_DIGITS];     // per-wave digit counts, then running cursors
     __shared__ uint32_t s_bstart[RS_DIGITS];     // block-local start of every digit in sorted order
@@ -322,6 +358,9 @@ constexpr uint32_t OS_MAX_UNITS = GOF_OS_MAX_UNITS;          // tiles of RS_BLOC
 constexpr int OS_LOOKBACK = GOF_OS_LOOKBACK;                 // predecessor descriptors requested per look-back round trip (os_pass)
 constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
 
+#ifndef GOF_OS_HIST_PLAIN
+#define GOF_OS_HIST_PLAIN 0      // 1: one LDS atomic per key and pass (developer A/B of os_count)
+#endif
 // one block per RS_BLOCK keys (grid-stride beyond 1024 blocks): all of a thread's loads of a round are in flight together
 __global__ void __launch_bounds__(256)
 os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase, const uint32_t* __restrict__ n_dev)
@@ -338,7 +377,11 @@ os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __re
         for (int s = 0; s < RS_BLOCK / 256; s++) {
             const uint32_t i = base + s * 256 + threadIdx.x;
             if (base + s * 256 < n)                          // (block-uniform: whole rows past the end are skipped)
+#if GOF_OS_HIST_PLAIN
+                { if (i < n) for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(k[s] >> (8 * p)) & 0xFFu], 1u); }
+#else
                 for (int p = 0; p < npass; p++) os_count(s_h[p], (k[s] >> (8 * p)) & 0xFFu, i < n);
+#endif
         }
     }
     __syncthreads();
@@ -487,7 +530,7 @@ size_t rs_tmp_words(size_t n)
 // single-kernel passes need anyway where it ends there, by one of its own otherwise (the caller's next kernel keeps its state there).
 hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                   uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
-                                  size_t zero_words_behind, bool hist_done)
+                                  size_t zero_words_behind)
 {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     const int npass = (end_bit + 7) / 8;
@@ -502,14 +545,12 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
             uint32_t* tickets = tmp + OS_MAX_PASSES * RS_DIGITS;
             uint32_t* err = tickets + 8;
             uint32_t* desc = tmp + OS_HDR;
-            if (!hist_done) {            // (else: radix_single_kernel_begin cleared the scratch and the caller's producer kernel counted the digits)
             size_t zero_words = (size_t)OS_HDR + (size_t)npass * hwords;
             if (zero_words_behind && zero_words == rs_tmp_words(n)) { zero_words += zero_words_behind; zero_words_behind = 0; }
             hipError_t e = hipMemsetAsync(tmp, 0, zero_words * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
             if (zero_words_behind) { e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
             hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase, n_dev);
-            }
             for (int p = 0; p < npass; p++) {
                 hipLaunchKernelGGL(os_pass, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, 8 * p, gbase + p * RS_DIGITS,
                                    desc + (size_t)p * hwords, tickets + p, err, n_dev);
@@ -526,7 +567,7 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
         uint32_t* scan_tmp = tmp + hwords;
         for (int shift = 0; shift < end_bit; shift += 8) {
             hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits, n_dev);
-            hipError_t e = device_scan_u32(hist, nullptr, hist, hwords, false, scan_tmp, nullptr, stream);
+            hipError_t e = device_scan_impl(hist, nullptr, hist, hwords, false, scan_tmp, nullptr, stream, nullptr, n_dev, (uint32_t)n);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(rs_scatter, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, shift, hist, nunits, n_dev);
             uint32_t* t;
@@ -542,17 +583,7 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev)
 {
-    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0, false);
-}
-// Clears the scratch of a sort of n pairs on end_bit bits and returns where its global digit histograms lie (pass p: RS_DIGITS words at
-// [p * RS_DIGITS]) if that sort runs as single-kernel passes, else nullptr (nothing was queued; sort without hist_done).
-uint32_t* radix_single_kernel_begin(uint32_t* tmp, size_t n, int end_bit, hipStream_t stream)
-{
-    const int npass = (end_bit + 7) / 8;
-    if (n == 0 || npass <= 0 || rs_units(n) > OS_MAX_UNITS || npass > OS_MAX_PASSES) return nullptr;
-    const size_t hwords = (size_t)RS_DIGITS * rs_units(n);
-    if (hipMemsetAsync(tmp, 0, ((size_t)OS_HDR + (size_t)npass * hwords) * sizeof(uint32_t), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return tmp;
+    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0);
 }
 int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
 

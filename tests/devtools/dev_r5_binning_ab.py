@@ -17,8 +17,12 @@ import synthetic_scenes as S  # noqa: E402
 from diff_gaussian_rasterization import GaussianRasterizer, _backend as B  # noqa: E402
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(B.__file__)))
+# the instance capacity the binding learns is keyed by (device, P, W, H): S1M-clustered (24.8 M instances) raises it for S1M (8.8 M) as well --
+# "S1M-overcap" is S1M again behind it (a capacity 3.5x the count: what a view with few instances pays for one with many); every variant
+# starts from forgotten capacities
 SCENES = (("S1M", lambda: S.scene_frustum(1_000_000, seed=0), 100),
           ("S1M-clustered", lambda: S.scene_clustered(1_000_000, seed=0), 30),
+          ("S1M-overcap", None, 100),
           ("6M@1237x822", lambda: S.scene_frustum(6_000_000, W=1237, H=822, focal=1237.0 * 0.75, seed=0, sigma_px=1.5), 30))
 only = os.environ.get("AB_SCENES")
 if only:
@@ -48,10 +52,12 @@ def main():
         specs.append((label, tag, env))
     scenes = []
     for name, make, steps in SCENES:
-        sd = to_dev(make())
+        sd = to_dev(make()) if make else scenes[0][1]
         scenes.append((name, sd, steps))
     for label, tag, env in specs:
         load_variant(tag, env)
+        for dct in (B._capacity, B._mask_need, B._staged_need):
+            dct.clear()
         for name, sd, steps in scenes:
             params = {k: sd[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)

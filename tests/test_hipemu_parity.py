@@ -543,3 +543,24 @@ def test_emulated_single_kernel_radix_passes_with_long_look_back_chains(name):
     pts = np.ascontiguousarray(S.tetra_points(sc)[:30000], dtype=np.float32)
     for a, b in zip(E.EmuScene(sc, lib=lib).integrate(pts)[:3], E.EmuScene(sc).integrate(pts)[:3]):
         assert np.array_equal(bits(a), bits(b))
+
+
+@pytest.mark.parametrize("name", ["posed_mod2", "lego10k"])
+def test_emulated_capacity_far_above_the_count_in_the_histogram_scan_scatter_sort(name):
+    """gof_forward_fused with a capacity of 3.5x / 1.01x the instance count and every sort as histogram / scan / scatter launches (build
+    variant GOF_OS_MAX_UNITS=0, tiles of 256 items): only the blocks that hold items take part -- they are the histogram's stride and the
+    bound of its scan (radix.hip: rs_active_blocks), tile_ranges strides over the count -- and the lists are those of the two-stage
+    forward, nothing written behind the workspaces."""
+    lib = E.load(extra_flags=("-DGOF_RS_CHUNK=64", "-DGOF_OS_MAX_UNITS=0"), tag="classic")
+    sc = TP.SCENES[name]()
+    e = E.EmuScene(sc)
+    want, _ = e.forward()
+    want = want.copy(); R = e.R
+    list_two_stage = e.fetch("point_list").copy()
+    ranges = e.fetch("ranges").copy()
+    for cap in (int(3.5 * R) + 777, R + R // 100 + 1, R):
+        f = E.EmuScene(sc, lib=lib)
+        rc, count, intact = f.forward_fused(cap)
+        assert rc == 0 and count == R and intact, (cap, rc, count, intact)
+        assert np.array_equal(bits(f.color), bits(want))
+        assert np.array_equal(f.fetch("point_list")[:R], list_two_stage) and np.array_equal(f.fetch("ranges"), ranges)
