@@ -40,7 +40,6 @@ KERNEL_SOURCES = {
     "rot3_apply_kernel": "gaussian_model_ops.hip",
 }
 SHARED_HEADERS = ("gof_common.h", "gof_status.h")
-EXTRA_HEADERS = {"radix.hip": ("gof_digit_count.h",)}      # headers only these translation units include
 
 
 def kernel_sha16(kernel=None):
@@ -49,7 +48,7 @@ def kernel_sha16(kernel=None):
     import hashlib
     h = hashlib.sha256()
     files = ("blend_forward.hip", "blend_backward.hip") if kernel is None else (KERNEL_SOURCES.get(kernel, kernel + ".hip"),)
-    for f in tuple(files) + SHARED_HEADERS + tuple(h for src in files for h in EXTRA_HEADERS.get(src, ())):
+    for f in tuple(files) + SHARED_HEADERS:
         path = os.path.join(ROOT, "gaussian-opacity-fields_amd", "csrc", f)
         if os.path.exists(path):
             h.update(open(path, "rb").read())

@@ -466,10 +466,12 @@ size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullpt
 #define GOF_K1_SPLIT_DEFAULT 1
 #endif
 namespace {
-// GOF_K1_SPLIT: 0 = one kernel; 1 = stage 2 on the library's second stream, the binning chain stays on the caller's;
+// GOF_K1_SPLIT: 0 = one kernel; 1 (shipped) = stage 2 on the library's second stream, the binning chain stays on the caller's;
 // 2 = the other way round: the binning chain (depth sort ... tile order: short, latency-bound launches, the forward's critical path) runs
 // on the library's stream created with the device's HIGHEST priority, stage 2 on the caller's stream -- the device offers no priority
-// BELOW the caller's to push stage 2 down with, but one above it to lift the chain with
+// BELOW the caller's to push stage 2 down with, but one above it to lift the chain with.  Measured (profiles/r05_ab_call7_binning.txt):
+// the priority changes nothing the chain can feel -- S1M 2.443 vs 2.429 ms per step, clustered 3.285 vs 3.265, 6M 4.162 vs 4.146: kept as
+// a developer switch only
 int k1_split_mode()
 {
     static const int mode = [] { const char* e = getenv("GOF_K1_SPLIT"); return e ? atoi(e) : GOF_K1_SPLIT_DEFAULT; }();

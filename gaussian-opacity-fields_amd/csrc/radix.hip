@@ -17,7 +17,6 @@
 //                 writes each digit's run contiguously at its global offset (coalesced).
 #include "gof_common.h"
 #include "gof_status.h"
-#include "gof_digit_count.h"
 
 namespace gof {
 
@@ -358,10 +357,10 @@ constexpr uint32_t OS_MAX_UNITS = GOF_OS_MAX_UNITS;          // tiles of RS_BLOC
 constexpr int OS_LOOKBACK = GOF_OS_LOOKBACK;                 // predecessor descriptors requested per look-back round trip (os_pass)
 constexpr int OS_HDR = OS_MAX_PASSES * RS_DIGITS + 64;       // digit bases of every pass, then tickets[4], error flag
 
-#ifndef GOF_OS_HIST_PLAIN
-#define GOF_OS_HIST_PLAIN 0      // 1: one LDS atomic per key and pass (developer A/B of os_count)
-#endif
-// one block per RS_BLOCK keys (grid-stride beyond 1024 blocks): all of a thread's loads of a round are in flight together
+// one block per RS_BLOCK keys (grid-stride beyond 1024 blocks): all of a thread's loads of a round are in flight together (until round 5
+// one key per loop trip: sixteen dependent round trips per thread).  One LDS atomic per key and pass: counting the crowded digits of a
+// wave -- the high bytes of depth keys take a handful of values -- per group of equal digits instead (one ballot per group, one add per
+// group) was built and measured no faster (depth sort 0.155 vs 0.149 ms at S1M, profiles/r05_ab_call7_binning.txt)
 __global__ void __launch_bounds__(256)
 os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __restrict__ gbase, const uint32_t* __restrict__ n_dev)
 {
@@ -377,11 +376,7 @@ os_hist(const uint32_t* __restrict__ keys, uint32_t n, int npass, uint32_t* __re
         for (int s = 0; s < RS_BLOCK / 256; s++) {
             const uint32_t i = base + s * 256 + threadIdx.x;
             if (base + s * 256 < n)                          // (block-uniform: whole rows past the end are skipped)
-#if GOF_OS_HIST_PLAIN
-                { if (i < n) for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(k[s] >> (8 * p)) & 0xFFu], 1u); }
-#else
-                for (int p = 0; p < npass; p++) os_count(s_h[p], (k[s] >> (8 * p)) & 0xFFu, i < n);
-#endif
+                if (i < n) for (int p = 0; p < npass; p++) atomicAdd(&s_h[p][(k[s] >> (8 * p)) & 0xFFu], 1u);
         }
     }
     __syncthreads();
@@ -447,9 +442,11 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
             __hip_atomic_store(my, OS_FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // Look-back, OS_LOOKBACK predecessors per round trip: the descriptors of tiles j, j - 1, ... are requested together and
             // consumed in order up to the first one that is not published yet (or the first PREFIX).  A descriptor is a device-scope
-            // load (~1 us: it is another XCD's store), and when the tiles of a pass start together every one of them finds AGGREGATEs
-            // on its nearest predecessors -- one load per round trip made the chain the pass's duration (29 us per pass at 245 tiles,
-            // and the reason the single-kernel passes lost beyond 512 tiles).
+            // load (it is another XCD's store), and when the tiles of a pass start together every one of them finds AGGREGATEs on
+            // its nearest predecessors.  Measured (profiles/r05_ab_call6_binning.txt): 1 / 8 descriptors per round trip = depth sort
+            // 0.157 / 0.150 ms at S1M -- the passes are bound by their chain of dependent steps (ticket, loads, ranks, look-back,
+            // exchange, stores), not by the look-back alone; and beyond 512 tiles the single-kernel passes still lose to histogram /
+            // scan / scatter (tile sort of 8.8 M pairs 0.38 vs 0.23 ms), whatever the width.
             int j = (int)tile - 1;
             uint32_t spins = 0;
             bool done = false;
@@ -538,8 +535,9 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
         const uint32_t nunits = rs_units(n);
         const size_t hwords = (size_t)RS_DIGITS * nunits;
         const dim3 grid(nunits), block(256);
-        // measured on MI355X: 1M pairs x 4 passes 0.142 -> 0.107 ms, but 8.8M pairs x 2 passes 0.178 -> 0.199 ms (with ~1000 resident
-        // blocks the look-back chains get long): the single-kernel passes are used where launch latency dominates
+        // measured on MI355X: 1M pairs x 4 passes 0.142 -> 0.107 ms, but 8.8M pairs x 2 passes 0.178 -> 0.199 ms (round 3; round 5 with
+        // 8 or 16 descriptors per look-back round trip: still 0.38 vs 0.23 ms, and 37 M query points 1.93 vs 1.75 ms): the single-kernel
+        // passes are used where launch latency dominates
         if (nunits <= OS_MAX_UNITS && npass <= OS_MAX_PASSES) {
             uint32_t* gbase = tmp;
             uint32_t* tickets = tmp + OS_MAX_PASSES * RS_DIGITS;
