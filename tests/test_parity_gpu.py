@@ -1163,3 +1163,35 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
         assert x["dropped_by_the_scan"] == 0 and x["accepted_pairs"] > 0, x
         assert x["integrate_dropped_by_the_scan"] == 0 and x["integrate_accepted_pairs"] > 0, x       # (round 5: integrate_rays' scan, one ray per lane)
     assert rows[0]["accepted_pairs"] > 100_000_000            # S1M: ~1.2e8 contributing pairs were examined
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("over", [1.25, 3.5])
+def test_fused_forward_at_full_size_under_a_capacity_above_the_count(over):
+    """The sync-free forward at S1M (8.8 M instances: the tile sort runs as histogram / scan / scatter launches sized for the CAPACITY, the
+    count read on the device -- radix.hip: rs_active_blocks, the histogram's stride and its scan's bound; tile_ranges strides over the
+    count) with the binding's usual 1.25x and with the capacity of a view that holds 3.5x the instances: the sorted list, the ranges,
+    the contributor counts and the image are the two-stage forward's, bit for bit, and so are the blend gradients' inputs."""
+    from diff_gaussian_rasterization import _backend as B
+    sc = S.scene_frustum(1_000_000, seed=0)
+    sd = to_dev(sc)
+    exact = product_forward_raw(sd, fused=False)
+    key = (str(sd["means3D"].device), sd["means3D"].shape[0], sd["W"], sd["H"])
+    keep = B._capacity.get(key)
+    try:
+        B._capacity[key] = B._round_capacity(int(over / 1.25 * int(exact["R"])))
+        fused = product_forward_raw(sd, fused=True)
+        assert fused["R"] == exact["R"] and fused["R"].layout == B._capacity[key] >= int(over * 0.99 * int(exact["R"]))
+        assert torch.equal(fused["color"], exact["color"]) and torch.equal(fused["radii"], exact["radii"])
+        for name in ("ranges", "n_contrib", "final_T"):
+            assert _same(fetch(fused, name), fetch(exact, name)), name
+        assert _same(fetch(fused, "point_list")[:exact["R"]], fetch(exact, "point_list"))
+        dL = np.random.default_rng(3).normal(size=(9, sd["H"], sd["W"])).astype(np.float32)
+        ge, gf = _product_backward(exact, dL), _product_backward(fused, dL)
+        for k in ("means2D", "colors", "opacity", "view2gaussian"):
+            assert np.array_equal(bits(gf[k]), bits(ge[k])), k            # no atomics in the backward: the same bits through either layout
+    finally:
+        if keep is None:
+            B._capacity.pop(key, None)
+        else:
+            B._capacity[key] = keep
