@@ -26,7 +26,8 @@ __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const 
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
                                float tan_fovy, float focal_x, float focal_y, float kernel_size, uint32_t gx, uint32_t gy,
                                int prefiltered, int32_t* radii, float* depths, SplatRec* rec, float4* conic_out, float4* bbox_out, float4* fconic_out,
-                               uint32_t* tiles_touched, uint2* rect_out, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags);
+                               uint32_t* tiles_touched, uint2* rect_out, uint8_t* clamped, uint32_t* depth_key, uint32_t* depth_val, uint32_t* flags,
+                               uint32_t* zero_ptr, uint32_t zero_n);
 template <int MODE>
 __global__ void preprocess_bwd(int P, int D, int M, const float* means3D, const int32_t* radii, const float* shs, const float* shs_rest,
                                const uint8_t* clamped, const float* scales, const float* rotations, Cam cam,
@@ -52,11 +53,15 @@ hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* ke
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev = nullptr);
 hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                   uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
-                                  size_t zero_words_behind);
+                                  size_t zero_words_behind, bool first_hist_done, bool scratch_zeroed = false);
+size_t radix_zero_words(size_t n, int end_bit);
+uint32_t* radix_classic_hist(uint32_t* tmp, size_t n, int end_bit);
+uint32_t rs_block_items();
 int radix_passes(int end_bit);
 uint32_t emit_instances_grid(uint32_t slots, int P);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first);
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first, uint32_t* hist0);
+uint32_t emit_block_slots();
 __global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
 __global__ void tile_ranges(uint32_t L, const uint32_t* tiles, uint2* ranges, int shift, const uint32_t* n_dev, const uint32_t* sort_error,
@@ -342,12 +347,12 @@ static inline Dims dims_of(const GofRasterArgs* a)
 // grid of a tile_ranges launch over up to n items (grid-stride kernel): at most 64 workgroups per CU
 static inline uint32_t tile_ranges_grid(uint32_t n) { const uint32_t b = (n + 255u) / 256u; return b < 16384u ? (b ? b : 1u) : 16384u; }
 static int sort_by_tile(const BinWs& b, uint32_t n, uint32_t* tiles_in, uint32_t* vals_in, int tile_bits, hipStream_t stream,
-                        const uint32_t* n_dev = nullptr)
+                        const uint32_t* n_dev = nullptr, bool first_hist_done = false)
 {
     uint32_t* tiles_other = (tiles_in == b.tiles) ? b.tiles_alt : b.tiles;
     uint32_t* vals_other = (vals_in == b.vals) ? b.vals_alt : b.vals;
     uint32_t *kr = nullptr, *vr = nullptr;
-    GOF_HIP_CHECK(radix_sort_pairs_u32(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev));
+    GOF_HIP_CHECK(radix_sort_pairs_u32_z(tiles_in, vals_in, tiles_other, vals_other, n, tile_bits, b.sort_tmp, &kr, &vr, stream, n_dev, 0, first_hist_done));
     if (kr != b.tiles || vr != b.vals) { set_error("internal: sort result in the wrong buffer"); return GOF_E_DEVICE; }
     return GOF_OK;
 }
@@ -363,16 +368,19 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         const bool odd = radix_passes(tile_bits) & 1;
         uint32_t* t_in = odd ? b.tiles_alt : b.tiles;
         uint32_t* v_in = odd ? b.vals_alt : b.vals;
-        // (measured and dropped, round 5, profiles/r05_ab_call6_binning.txt: the emission counting the tile sort's digits as it writes the
-        // tile ids -- no histogram launch, no read of the keys for it -- doubled emit_instances, 0.040 -> 0.084 ms at S1M; and the tile
-        // sort as single-kernel passes at all lost to histogram / scan / scatter beyond 2 M pairs: 0.38 vs 0.23 ms)
+        // Where the tile sort runs as histogram / scan / scatter launches, its blocks are the emission's workgroups: the emission leaves the
+        // first pass's histogram (the tile id's low byte: one LDS add per written slot) and that pass starts at its scan.
+        // (Measured and dropped, profiles/r05_ab_call6_binning.txt: counting the digits of ALL passes in the emission for a tile sort of
+        // single-kernel passes -- emit_instances 0.040 -> 0.084 ms at S1M, and that sort itself lost beyond 2 M pairs: 0.38 vs 0.23 ms.)
+        static const bool emit_counts = [] { const char* e = getenv("GOF_EMIT_HIST0"); return !(e && e[0] == '0'); }();      // (developer A/B)
+        uint32_t* const hist0 = (emit_counts && rs_block_items() == emit_block_slots()) ? radix_classic_hist(b.sort_tmp, R, tile_bits) : nullptr;
         { GOF_PROFILE("emit_instances", stream);
         // one wave per EMIT_SLOTS output slots (R: the instance count, or the workspace's capacity when only the device knows the count)
         hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R, a->P)), dim3(256), 0, stream, a->P, g.dval_a,
-                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first); }
+                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first, hist0); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
-        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev);
+        int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev, hist0 != nullptr);
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
@@ -536,7 +544,20 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,                          \
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,                             \
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, k1_bits,                                                                             \
-                       radii, g.depths, g.rec, g.conic, g.bbox, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags)
+                       radii, g.depths, g.rec, g.conic, g.bbox, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags, k1_zero_ptr, k1_zero_n)
+    // what the depth sort and the fused gather + scan behind it need cleared: cleared by the per-Gaussian kernel, the first launch of the
+    // frame, instead of by a memset launch in front of the sort (GOF_K1_ZERO=0: the memset)
+    static const bool fused_scan = [] { const char* e = getenv("GOF_FUSED_SCAN"); return !(e && e[0] == '0'); }();      // (developer A/B: 0 = gather_rects + the three-kernel scan)
+    static const bool k1_zeroes = [] { const char* e = getenv("GOF_K1_ZERO"); return !(e && e[0] == '0'); }();
+    const size_t scan_words = fused_scan ? gather_scan_state_words((size_t)a->P) : 0;
+    const size_t sort_zero = radix_zero_words((size_t)a->P, 32);                 // words at the start of the sort's scratch its single-kernel passes want zero (0: none)
+    const bool sort_zero_to_end = sort_zero == rs_tmp_words((size_t)a->P);       // ... reaching the scan's state: one range
+    uint32_t* k1_zero_ptr = nullptr;
+    uint32_t k1_zero_n = 0;
+    if (k1_zeroes && (sort_zero == 0 || sort_zero_to_end)) {
+        k1_zero_ptr = sort_zero ? g.sort_tmp : g.sort_tmp + rs_tmp_words((size_t)a->P);
+        k1_zero_n = (uint32_t)(sort_zero + scan_words);
+    }
     // (tight tile rectangles take their tiles_touched from stage 2's footprint box: one kernel then)
     AuxStream* const aux = (join && k1_mode == 0 && !(k1_bits & 2) && !a->debug) ? aux_stream() : nullptr;
     { GOF_PROFILE("preprocess_fwd", stream);
@@ -566,12 +587,11 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
     // (the state words of the fused gather + scan behind it lie right behind the sort's scratch: the sort's own memset clears them too)
-    static const bool fused_scan = [] { const char* e = getenv("GOF_FUSED_SCAN"); return !(e && e[0] == '0'); }();      // (developer A/B: 0 = gather_rects + the three-kernel scan)
     uint32_t* const scan_state = g.sort_tmp + rs_tmp_words((size_t)a->P);
     uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
     GOF_HIP_CHECK(radix_sort_pairs_u32_z(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream, nullptr,
-                                         fused_scan ? gather_scan_state_words((size_t)a->P) : 0));
+                                         k1_zero_ptr ? 0 : scan_words, false, k1_zero_ptr != nullptr));
     if (vr != g.dval_a) { set_error("internal: depth sort result in the wrong buffer"); return GOF_E_DEVICE; } }
     GOF_LAUNCH_CHECK(stream, a->debug);
     // first instance of every depth-sorted Gaussian + the instance count (replaces rasterizer_impl.cu:332)

@@ -206,6 +206,7 @@ constexpr uint32_t EMIT_SLOTS = GOF_EMIT_SLOTS;       // output slots per wave
 // workgroups of an emit_instances launch that may write up to `slots` instances (api.hip sizes the grid with it)
 // (and never fewer than one thread per Gaussian: the threads also store inst_first, one Gaussian each -- a view that sees few of many
 // Gaussians would otherwise leave that loop to a handful of workgroups)
+uint32_t emit_block_slots() { return 4u * EMIT_SLOTS; }      // slots a workgroup of emit_instances writes
 uint32_t emit_instances_grid(uint32_t slots, int P)
 {
     const size_t by_slots = ((size_t)slots + 4 * EMIT_SLOTS - 1) / (4 * EMIT_SLOTS), by_gaussians = ((size_t)P + 255) / 256;
@@ -214,8 +215,14 @@ uint32_t emit_instances_grid(uint32_t slots, int P)
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
                const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity,
-               uint32_t* __restrict__ inst_first)
+               uint32_t* __restrict__ inst_first, uint32_t* __restrict__ hist0)
 {
+    // hist0 (nullable): the [digit][block] histogram of the tile sort's FIRST pass (radix.hip: rs_hist, digit = the tile id's low byte) where
+    // that sort runs as histogram / scan / scatter launches over blocks of exactly this workgroup's 4 EMIT_SLOTS slots: the workgroup
+    // counts the tile ids it writes (consecutive tiles of a rectangle row: the low bytes spread over the bins, few same-address adds) and
+    // stores its row -- the sort starts without its first histogram launch and without that read of the keys
+    __shared__ uint32_t s_cnt[256];
+    if (hist0) { s_cnt[threadIdx.x] = 0u; __syncthreads(); }
     const uint32_t lane = threadIdx.x & 63u;
     if (inst_first)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)P; i += gridDim.x * 256u) {
@@ -229,7 +236,7 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     const uint32_t total = order_off[P - 1] + (wh_last & 0xFFFFu) * (wh_last >> 16);
     const uint32_t limit = min(total, capacity);       // capacity < the instance count only in the sync-free forward (then redone)
     const uint64_t p0_wide = (uint64_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * EMIT_SLOTS;
-    if (p0_wide >= (uint64_t)limit) return;             // (wave-uniform)
+    if (p0_wide < (uint64_t)limit) {                    // (wave-uniform; no early return: the histogram's barrier below is the workgroup's)
     const uint32_t p0 = (uint32_t)p0_wide;
     const uint32_t p1 = (uint32_t)min((uint64_t)limit, p0_wide + EMIT_SLOTS);
     // 1. the last position i of the order with order_off[i] <= p0 (offsets are non-decreasing, order_off[0] = 0 <= p0; a run of equal
@@ -278,11 +285,20 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
             if (p < end) {
                 const uint32_t k = p - o_off;
                 const uint32_t y = k / o_w, x = k - y * o_w;
-                tiles[p] = (o_miny + y) * gx + (o_minx + x);
+                const uint32_t t = (o_miny + y) * gx + (o_minx + x);
+                tiles[p] = t;
                 gids[p] = o_idx;
+                if (hist0) atomicAdd(&s_cnt[t & 0xFFu], 1u);
             }
         }
         if (group_end >= p1 || g0 + 64u >= (uint32_t)P) break;      // (wave-uniform)
+    }
+    }
+    if (hist0) {
+        __syncthreads();
+        // the stride of the histogram = the blocks that hold items (radix.hip: rs_active_blocks; never 0)
+        const uint32_t nb = limit ? (limit + 4u * EMIT_SLOTS - 1u) / (4u * EMIT_SLOTS) : 1u;
+        if (blockIdx.x < nb) hist0[(size_t)threadIdx.x * nb + blockIdx.x] = s_cnt[threadIdx.x];
     }
 }
 

@@ -250,8 +250,14 @@ preprocess_fwd(int P, int D, int M,
                int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
                float4* __restrict__ conic_out, float4* __restrict__ bbox_out, float4* __restrict__ fconic_out, uint32_t* __restrict__ tiles_touched,
                uint2* __restrict__ rect_out, uint8_t* __restrict__ clamped,
-               uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags)
+               uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags,
+               uint32_t* __restrict__ zero_ptr, uint32_t zero_n)
 {
+    // zero_n words at zero_ptr are cleared on the way (the first kernel of a frame: the scratch of the depth sort's single-kernel passes and
+    // the state of the fused gather + scan behind it must be zero before those launches -- a memset launch of its own until round 5);
+    // never by stage 2, which runs BESIDE them
+    if (STAGE != 2 && zero_n)
+        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < zero_n; w += gridDim.x * 256u) zero_ptr[w] = 0u;
     constexpr bool TILED = MODE != 0;
     __shared__ float s_sh[TILED ? 256 * K9_ROW : 1];
     __shared__ uint64_t s_vis[4];
@@ -482,19 +488,19 @@ preprocess_fwd(int P, int D, int M,
 }
 template __global__ void preprocess_fwd<0, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
-                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 template __global__ void preprocess_fwd<1, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
-                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 template __global__ void preprocess_fwd<2, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
-                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 template __global__ void preprocess_fwd<0, 1>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
-                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 template __global__ void preprocess_fwd<0, 2>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
-                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 
 // ---------------------------------------------------------------------------------------------------
 // K9: backward of the per-Gaussian stage (backward.cu:593-631): view2gaussian backward

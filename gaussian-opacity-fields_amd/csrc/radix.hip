@@ -527,7 +527,7 @@ size_t rs_tmp_words(size_t n)
 // single-kernel passes need anyway where it ends there, by one of its own otherwise (the caller's next kernel keeps its state there).
 hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                   uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev,
-                                  size_t zero_words_behind)
+                                  size_t zero_words_behind, bool first_hist_done, bool scratch_zeroed)
 {
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     const int npass = (end_bit + 7) / 8;
@@ -543,11 +543,13 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
             uint32_t* tickets = tmp + OS_MAX_PASSES * RS_DIGITS;
             uint32_t* err = tickets + 8;
             uint32_t* desc = tmp + OS_HDR;
+            if (!scratch_zeroed) {       // (else: the caller's kernel in front of the sort cleared radix_zero_words(n, end_bit) words at tmp)
             size_t zero_words = (size_t)OS_HDR + (size_t)npass * hwords;
             if (zero_words_behind && zero_words == rs_tmp_words(n)) { zero_words += zero_words_behind; zero_words_behind = 0; }
             hipError_t e = hipMemsetAsync(tmp, 0, zero_words * sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
             if (zero_words_behind) { e = hipMemsetAsync(tmp + rs_tmp_words(n), 0, zero_words_behind * sizeof(uint32_t), stream); if (e != hipSuccess) return e; }
+            }
             hipLaunchKernelGGL(os_hist, dim3(nunits < 1024u ? nunits : 1024u), block, 0, stream, ki, (uint32_t)n, npass, gbase, n_dev);
             for (int p = 0; p < npass; p++) {
                 hipLaunchKernelGGL(os_pass, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, 8 * p, gbase + p * RS_DIGITS,
@@ -564,7 +566,8 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
         uint32_t* hist = tmp;
         uint32_t* scan_tmp = tmp + hwords;
         for (int shift = 0; shift < end_bit; shift += 8) {
-            hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits, n_dev);
+            // (first_hist_done: the kernel that produced the keys left the first pass's [digit][block] histogram at `tmp`: radix_classic_hist)
+            if (!(first_hist_done && shift == 0)) hipLaunchKernelGGL(rs_hist, grid, block, 0, stream, ki, (uint32_t)n, shift, hist, nunits, n_dev);
             hipError_t e = device_scan_impl(hist, nullptr, hist, hwords, false, scan_tmp, nullptr, stream, nullptr, n_dev, (uint32_t)n);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(rs_scatter, grid, block, 0, stream, ki, vi, ko, vo, (uint32_t)n, shift, hist, nunits, n_dev);
@@ -581,9 +584,27 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
                                 uint32_t* tmp, uint32_t** keys_res, uint32_t** vals_res, hipStream_t stream, const uint32_t* n_dev)
 {
-    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0);
+    return radix_sort_pairs_u32_z(keys_a, vals_a, keys_b, vals_b, n, end_bit, tmp, keys_res, vals_res, stream, n_dev, 0, false, false);
 }
 int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
+// Where a sort of n pairs on end_bit bits that runs as histogram / scan / scatter launches expects the [digit][block] histogram of its FIRST
+// pass (blocks of rs_block_items() consecutive items; stride = the blocks that hold items) -- nullptr if that sort runs as single-kernel
+// passes.  A kernel that produces the keys block by block can leave it there (first_hist_done of radix_sort_pairs_u32_z).
+uint32_t* radix_classic_hist(uint32_t* tmp, size_t n, int end_bit)
+{
+    const int npass = (end_bit + 7) / 8;
+    if (n == 0 || npass <= 0 || (rs_units(n) <= OS_MAX_UNITS && npass <= OS_MAX_PASSES)) return nullptr;
+    return tmp;
+}
+uint32_t rs_block_items() { return (uint32_t)RS_BLOCK; }
+// u32 words at the start of the scratch that a sort of n pairs on end_bit bits wants cleared before its first launch (its single-kernel
+// passes' digit counts, tickets, error flag and descriptors); 0 if it runs as histogram / scan / scatter launches
+size_t radix_zero_words(size_t n, int end_bit)
+{
+    const int npass = (end_bit + 7) / 8;
+    if (n == 0 || npass <= 0 || rs_units(n) > OS_MAX_UNITS || npass > OS_MAX_PASSES) return 0;
+    return (size_t)OS_HDR + (size_t)npass * (size_t)RS_DIGITS * rs_units(n);
+}
 
 // Device word that is non-zero after radix_sort_pairs_u32(.., n, end_bit, tmp, ..) if a single-kernel pass gave up waiting for a
 // predecessor (bounded look-back poll); nullptr when that sort runs as histogram / scan / scatter launches, which cannot time out.
