@@ -566,8 +566,8 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 float4* dst = part16 + (size_t)slot * 4;
 #pragma unroll
                 for (int q = 0; q < 4; q++) dst[q] = make_float4(total(4 * q), total(4 * q + 1), total(4 * q + 2), total(4 * q + 3));
-                // (dL_dv2g[9] = -0.5 wgt x the total of value 6, wgt a constant of the Gaussian: formed once per Gaussian by
-                // gather_tile_partials from its sum of value 6 -- until round 5 a 17th value per record, in an array of its own: a
+                // (dL_dv2g[9]'s share of this record, -0.5 wgt x the total of value 6 with wgt a constant of the Gaussian, is formed by
+                // gather_tile_partials from the record's value 6 -- until round 5 a 17th value stored here, in an array of its own: a
                 // second random sector per record for the flush and for the gather)
                 slot_of[s_inst[tid]] = slot + 1u;
             }
@@ -625,6 +625,13 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
     const uint32_t g = (uint32_t)i;
     const uint32_t n = live ? tiles_touched[g] : 0u;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // dL_dview2gaussian[9] = dL_dmin_value summed over the pairs = -0.5 wgt (G dL_dalpha) summed, wgt = opacity x the 3D filter's coefficient, a
+    // constant of the Gaussian (preprocess_fwd leaves it in the spare word of the 2D conic): each record's share is -0.5 wgt x its
+    // opacity sum (value 6: word z of the quarter lane 1 of the quad loads).  Until round 5 the flush stored that product as a 17th
+    // value in an array of its own -- a second random sector per record for the flush and for this kernel; formed here from the same
+    // operands in the same order, it and its sum (acc17, in lane 1) have the bits they had
+    float acc17 = 0.f;
+    float wm = (n ? -0.5f * conic_w[g].w : 0.f);          // (a culled Gaussian's conic is never written)
     constexpr uint32_t BIG = 64;          // Gaussians covering more tiles than this are summed by the whole wave (a near, huge splat can
                                           // cover thousands of tiles: left to its own quad it alone determined the kernel's duration)
     const size_t e0 = n ? inst_off[g] : 0;
@@ -641,7 +648,7 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
         float4 r[8];                                                                                                   \
         GOF_GATHER_LOAD(E0, K0, 0, va, 0x00) GOF_GATHER_LOAD(E0, K0, 1, va, 0x55) GOF_GATHER_LOAD(E0, K0, 2, va, 0xAA) GOF_GATHER_LOAD(E0, K0, 3, va, 0xFF) \
         GOF_GATHER_LOAD(E0, K0, 4, vb, 0x00) GOF_GATHER_LOAD(E0, K0, 5, vb, 0x55) GOF_GATHER_LOAD(E0, K0, 6, vb, 0xAA) GOF_GATHER_LOAD(E0, K0, 7, vb, 0xFF) \
-        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc.x += r[j].x; acc.y += r[j].y; acc.z += r[j].z; acc.w += r[j].w; }                            \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) { acc.x += r[j].x; acc.y += r[j].y; acc.z += r[j].z; acc.w += r[j].w; acc17 += wm * r[j].z; }      \
     }
 #define GOF_GATHER_LOAD(E0, K0, J, V, CTRL)                                                                          \
         {                                                                                                              \
@@ -672,12 +679,14 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
         big &= big - 1ull;
         const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)n, owner);
         const size_t be0 = ((size_t)(uint32_t)__builtin_amdgcn_readlane((int)(e0 >> 32), owner) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e0, owner);
-        float4 keep = acc;
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 keep = acc; float keep17 = acc17; const float keep_wm = wm;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f); acc17 = 0.f;
+        wm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(keep_wm), owner));      // the owner's weight, for every quad that helps
         for (uint32_t k0 = 8u * (lane >> 2); k0 < bn; k0 += 8u * 16u) GOF_GATHER_TRIP(be0, bn, k0)
-        float v5[4] = { acc.x, acc.y, acc.z, acc.w };
+        wm = keep_wm;
+        float v5[5] = { acc.x, acc.y, acc.z, acc.w, acc17 };
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < 5; c++) {
             float x = v5[c];
             x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4  (quads of the row)
             x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -687,20 +696,19 @@ gather_tile_partials(int P, const uint32_t* __restrict__ inst_off, const uint32_
         }
         const bool mine = (int)(lane & ~3u) == owner;
         acc = mine ? make_float4(v5[0], v5[1], v5[2], v5[3]) : keep;
+        acc17 = mine ? v5[4] : keep17;
     }
 #undef GOF_GATHER_LOAD
 #undef GOF_GATHER_TRIP_V
 #undef GOF_GATHER_TRIP
-    // record layout (blend_backward's flush): [colour 0-2, mean2D 0 | mean2D 1-2, opacity, v2g 0 | v2g 1-4 | v2g 5-8]
-    // v2g 9 = dL_dmin_value summed over the pairs = -0.5 wgt (G dL_dalpha) summed = -0.5 wgt x the opacity sum (value 6, lane 1 of the
-    // quad), wgt = opacity x the 3D filter's coefficient, which preprocess_fwd leaves in the spare word of the Gaussian's 2D conic
-    const float opac_sum = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc.z), 0x55, 0xf, 0xf, false));     // quad_perm [1,1,1,1]
+    // record layout (blend_backward's flush): [colour 0-2, mean2D 0 | mean2D 1-2, opacity, v2g 0 | v2g 1-4 | v2g 5-8]; v2g 9: acc17 of lane 1
+    const float v2g9 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc17), 0x55, 0xf, 0xf, false));     // quad_perm [1,1,1,1]
     if (!live) return;
     const size_t o = (size_t)g;
     if (q == 0u) {
         dL_dcolors[o * 3 + 0] = acc.x; dL_dcolors[o * 3 + 1] = acc.y; dL_dcolors[o * 3 + 2] = acc.z;
         dL_dmean2D[o * 3 + 0] = acc.w;
-        dL_dv2g[o * 10 + 9] = n ? -0.5f * conic_w[o].w * opac_sum : 0.f;      // (a culled Gaussian's conic is never written)
+        dL_dv2g[o * 10 + 9] = v2g9;
     } else if (q == 1u) {
         dL_dmean2D[o * 3 + 1] = acc.x; dL_dmean2D[o * 3 + 2] = acc.y;
         dL_dopacity[o] = acc.z;

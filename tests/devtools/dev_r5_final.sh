@@ -13,7 +13,7 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU
 timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-integrate --no-full-loop --no-clustered --no-views --no-reference --no-kernel-size-leg --no-large-p > $O/stats_bench.json 2> $O/stats.err ) || tail -3 $O/stats.err
-( timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 ) > $O/tests.txt 2>&1; cat $O/tests.txt
+timeout 900 python -m pytest tests -q -m gpu -rf --tb=short > $O/tests_full.txt 2>&1; tail -60 $O/tests_full.txt | cut -c1-1200 > $O/tests.txt; cat $O/tests.txt
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > $O/smoke.txt 2>&1; cat $O/smoke.txt
 run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE SQ_WAVES
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
