@@ -545,19 +545,18 @@ def test_emulated_single_kernel_radix_passes_with_long_look_back_chains(name):
         assert np.array_equal(bits(a), bits(b))
 
 
-@pytest.mark.parametrize("name,small_blocks", [("posed_mod2", True), ("lego10k", True), ("lego10k", False), ("posed_ragged", False)])
-def test_emulated_capacity_far_above_the_count_in_the_histogram_scan_scatter_sort(name, small_blocks):
+@pytest.mark.parametrize("name", ["posed_mod2", "lego10k", "posed_ragged"])
+def test_emulated_capacity_far_above_the_count_in_the_histogram_scan_scatter_sort(name):
     """gof_forward_fused with a capacity of 3.5x / 1.01x the instance count and every sort as histogram / scan / scatter launches (build
     variant GOF_OS_MAX_UNITS=0): only the blocks that hold items take part -- they are the histogram's stride and the bound of its scan
     (radix.hip: rs_active_blocks), tile_ranges strides over the count -- and the lists are those of the two-stage forward, nothing
-    written behind the workspaces.  With sort blocks of 256 items many blocks take part; with the shipped 4096 the sort's blocks are the
-    emission's workgroups and emit_instances leaves the first pass's histogram (binning.hip: hist0) -- on both forwards here."""
-    lib = E.load(extra_flags=("-DGOF_RS_CHUNK=64", "-DGOF_OS_MAX_UNITS=0"), tag="classic") if small_blocks else E.load(extra_flags=("-DGOF_OS_MAX_UNITS=0",), tag="classic4k")
+    written behind the workspaces.  The sort's blocks are the emission's workgroups here as in the shipped build beyond 2 M instances:
+    emit_instances leaves the first pass's histogram (binning.hip: hist0), on both forwards."""
+    lib = E.load(extra_flags=("-DGOF_OS_MAX_UNITS=0",), tag="classic4k")
     sc = TP.SCENES[name]()
-    if not small_blocks:                    # the two-stage forward of the variant (host-known count) against the shipped build's
-        v = E.EmuScene(sc, lib=lib); v.forward()
-        d = E.EmuScene(sc); d.forward()
-        assert v.R == d.R and np.array_equal(v.fetch("point_list"), d.fetch("point_list")) and np.array_equal(v.fetch("ranges"), d.fetch("ranges"))
+    v = E.EmuScene(sc, lib=lib); v.forward()          # the two-stage forward of the variant (host-known count) against the shipped build's
+    d = E.EmuScene(sc); d.forward()
+    assert v.R == d.R and np.array_equal(v.fetch("point_list"), d.fetch("point_list")) and np.array_equal(v.fetch("ranges"), d.fetch("ranges"))
     e = E.EmuScene(sc)
     want, _ = e.forward()
     want = want.copy(); R = e.R
