@@ -20,7 +20,7 @@ namespace gof {
 
 // ---- kernels / helpers defined in the other translation units -------------------------------------
 
-template <int MODE, int STAGE>
+template <int STAGE, int FOOT>
 __global__ void preprocess_fwd(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                                const float* rotations, const float* opacities, const float* shs, const float* shs_rest, const float* cov3D_precomp,
                                const float* colors_precomp, const float* v2g_precomp, Cam cam, int W, int H, float tan_fovx,
@@ -45,8 +45,6 @@ uint32_t higher_msb(uint32_t n);
 size_t scan_tmp_words(size_t n);
 hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
                            const uint32_t** total_dev_out, hipStream_t stream);
-hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
-                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host);
 size_t rs_tmp_words(size_t n);
 const uint32_t* radix_sort_error_flag(const uint32_t* tmp, size_t n, int end_bit);
 hipError_t radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int end_bit,
@@ -103,8 +101,6 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  float* out_alpha_integrated, float* out_color_integrated, const uint32_t* n_contrib, int acc_min, uint32_t gx, uint32_t ntiles,
                                  const uint32_t* tile_order, uint32_t* tile_queue);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
-__global__ void gather_rects(uint32_t n, const uint2* rect, const uint32_t* order, const uint32_t* keys_sorted, uint32_t* minxy_sorted, uint32_t* wh_sorted,
-                             uint32_t* counts, const uint32_t* sort_error, uint2* ranges, uint32_t ntiles);
 uint32_t gather_scan_tiles(size_t n);
 size_t gather_scan_state_words(size_t n);
 __global__ void gather_scan_rects(uint32_t n, const uint2* rect, const uint32_t* order, const uint32_t* keys_sorted, uint32_t* minxy_sorted, uint32_t* wh_sorted,
@@ -125,28 +121,36 @@ void set_error(const char* fmt, ...)
 }
 
 // ---- asynchronous device status ----------------------------------------------------------------------
-// One host-mapped word per process (pinned, visible to every device): a kernel that detects a failure nobody reads back in the
-// same call -- the tile sort's bounded look-back poll on lists of <= 2M instances, which has no host read-back behind it -- writes
-// it through the mapping, and the NEXT forward / backward / integrate call returns GOF_E_DEVICE (the convention of asynchronous
-// errors in the reference's runtime: they surface at a later call).  Written only on failure, so it costs nothing otherwise.
+// One host-mapped word per DEVICE (pinned, in one allocation visible to every device): a kernel that detects a failure nobody reads
+// back in the same call -- the tile sort's bounded look-back poll on lists of <= 2M instances, which has no host read-back behind it --
+// writes it through the mapping, and the NEXT forward / backward / integrate call ON THAT DEVICE returns GOF_E_DEVICE (the convention
+// of asynchronous errors in the reference's runtime: they surface at a later call).  Written only on failure, so it costs nothing
+// otherwise.  Beyond this word (and the thread-local error text, the per-thread second stream) the library keeps no state.
 namespace {
+constexpr int MAX_DEVICES = 16;
 std::mutex g_status_mutex;
-volatile uint32_t* g_status_host = nullptr;
+volatile uint32_t* g_status_host = nullptr;      // [MAX_DEVICES][16]: a 64-byte line per device
 uint32_t* g_status_dev = nullptr;
+int current_device_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return (dev >= 0 && dev < MAX_DEVICES) ? dev : 0;
+}
 }
 static uint32_t* async_status_word()
 {
     std::lock_guard<std::mutex> lk(g_status_mutex);
     if (!g_status_host) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        std::memset(p, 0, 64);
+        if (hipHostMalloc(&p, MAX_DEVICES * 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        std::memset(p, 0, MAX_DEVICES * 64);
         void* d = nullptr;
         if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return nullptr; }
         g_status_host = static_cast<volatile uint32_t*>(p);
         g_status_dev = static_cast<uint32_t*>(d);
     }
-    return g_status_dev;
+    return g_status_dev + 16 * current_device_slot();
 }
 // Device-visible address of `host_words` if that is pinned, device-mapped host memory (hipHostMalloc -- what torch's pin_memory() uses),
 // else nullptr: kernels then store a few result words there themselves, where a hipMemcpyAsync would put one or two blit kernels
@@ -161,9 +165,11 @@ static uint32_t* device_view_of_pinned(uint32_t* host_words)
 static int take_async_status()
 {
     std::lock_guard<std::mutex> lk(g_status_mutex);
-    if (g_status_host && *g_status_host) {
-        *g_status_host = 0;
-        set_error("an EARLIER call's tile sort timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
+    if (!g_status_host) return GOF_OK;
+    volatile uint32_t* w = g_status_host + 16 * current_device_slot();
+    if (*w) {
+        *w = 0;
+        set_error("an EARLIER call's tile sort on this device timed out waiting for a predecessor block (GPU heavily oversubscribed?): that frame was rendered as background");
         return GOF_E_DEVICE;
     }
     return GOF_OK;
@@ -223,7 +229,7 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     g.inst_first = g.dkey_a;        // (the sorted depth keys are dead once the depth sort has delivered the order: emit_instances writes over them)
     carve(p, g.dkey_b, n);
     carve(p, g.dval_b, n);
-    carve(p, g.sort_tmp, rs_tmp_words(n) + (scan_tmp_words(n) > gather_scan_state_words(n) ? scan_tmp_words(n) : gather_scan_state_words(n)));
+    carve(p, g.sort_tmp, rs_tmp_words(n) + gather_scan_state_words(n));
     if (out) *out = g;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
@@ -372,8 +378,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         // first pass's histogram (the tile id's low byte: one LDS add per written slot) and that pass starts at its scan.
         // (Measured and dropped, profiles/r05_ab_call6_binning.txt: counting the digits of ALL passes in the emission for a tile sort of
         // single-kernel passes -- emit_instances 0.040 -> 0.084 ms at S1M, and that sort itself lost beyond 2 M pairs: 0.38 vs 0.23 ms.)
-        static const bool emit_counts = [] { const char* e = getenv("GOF_EMIT_HIST0"); return !(e && e[0] == '0'); }();      // (developer A/B)
-        uint32_t* const hist0 = (emit_counts && rs_block_items() == emit_block_slots()) ? radix_classic_hist(b.sort_tmp, R, tile_bits) : nullptr;
+        uint32_t* const hist0 = (rs_block_items() == emit_block_slots()) ? radix_classic_hist(b.sort_tmp, R, tile_bits) : nullptr;
         { GOF_PROFILE("emit_instances", stream);
         // one wave per EMIT_SLOTS output slots (R: the instance count, or the workspace's capacity when only the device knows the count)
         hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R, a->P)), dim3(256), 0, stream, a->P, g.dval_a,
@@ -384,7 +389,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         if (rc) return rc; }
         GOF_LAUNCH_CHECK(stream, dbg);
     }
-    // im.ranges: gof_forward_fused ran stage 1 (gather_rects clears the ranges) in this very call.  gof_forward_render and
+    // im.ranges: gof_forward_fused ran stage 1 (gather_scan_rects clears the ranges) in this very call.  gof_forward_render and
     // gof_integrate_view are handed an image workspace by the caller: nothing guarantees that stage 1 of THIS frame went through it, and
     // stale ranges would walk point_list out of bounds -- they clear it themselves (5 us on paths that read a count back anyway).
     if (!n_dev) GOF_HIP_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)d.ntiles * sizeof(uint2), stream));
@@ -403,16 +408,9 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
 
 // The backward's dispatch order: what a tile costs there is known exactly after the forward blend (the deepest list position one of
 // its pixels blended = the entries the backward stages and walks), so the forward call leaves the order in the image workspace.
-// developer A/B (GOF_BW_ORDER_BY_LENGTH=1): the backward pops the forward's queues (cost = list length) and the second launch is skipped
-static bool bw_order_by_length()
-{
-    static const bool on = [] { const char* e = getenv("GOF_BW_ORDER_BY_LENGTH"); return e && e[0] == '1'; }();
-    return on;
-}
 // usage_host (nullable): device-visible address of the caller's pinned GOF_USAGE_WORDS words (gof_forward_fused)
 static void order_tiles_for_backward(const Dims& d, const ImageWs& im, hipStream_t stream, uint32_t* usage_host = nullptr)
 {
-    if (bw_order_by_length()) return;
     GOF_PROFILE("order_tiles_bw", stream);
     // (queue lengths at tile_queue[40..47]; the backward pops from heads in its own scratch, cleared per call -- it may run more than once per forward)
     hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, im.tile_cost, im.tile_order_bw, im.tile_queue + TILE_QUEUE_WORDS / 2, nullptr, nullptr, im.mask_cursors + POOL_SHARDS + 1,
@@ -429,10 +427,15 @@ static std::atomic<int> g_tight_rects{ [] { const char* e = getenv("GOF_TIGHT_RE
 // the ray-centric one (round 5) -- same outputs bit for bit, kept for A/B timing and as the cap fallback (integrate.hip)
 static std::atomic<int> g_integrate_pixel_pass{ [] { const char* e = getenv("GOF_INT_PIXELS"); return (e && e[0] == '1') ? 1 : 0; }() };
 static std::atomic<int> g_forward_exact{ [] { const char* e = getenv("GOF_FW_EXACT"); return (e && e[0] == '1') ? 1 : 0; }() };
+// a mode of THIS call (GofRasterArgs, ABI 12: > 0 on, < 0 off) or, at 0, the process-wide default the setters / the environment gave
+static inline bool mode_on(int32_t per_call, const std::atomic<int>& process_default)
+{
+    return per_call > 0 || (per_call == 0 && process_default.load(std::memory_order_relaxed) != 0);
+}
 static void launch_blend_forward(const GofRasterArgs* a, const Dims& d, const GeomWs& g, const BinWs& b, const ImageWs& im, float* out_color, hipStream_t stream)
 {
     GOF_PROFILE("blend_forward", stream);
-    auto* kernel = g_forward_exact.load(std::memory_order_relaxed) ? blend_forward_exact : blend_forward;
+    auto* kernel = mode_on(a->forward_exact, g_forward_exact) ? blend_forward_exact : blend_forward;
     hipLaunchKernelGGL(kernel, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                        im.ranges, b.vals, g.rec, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background,
                        im.final_T, im.n_contrib, out_color, b.mp, im.mask_cursors, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);
@@ -448,7 +451,7 @@ const char* gof_last_error(void) { return g_error.c_str(); }
 int gof_set_forward_exact(int on) { return g_forward_exact.exchange(on ? 1 : 0); }
 int gof_set_integrate_pixel_pass(int on) { return g_integrate_pixel_pass.exchange(on ? 1 : 0); }
 int gof_set_tight_tile_rects(int on) { return g_tight_rects.exchange(on ? 1 : 0); }
-int gof_abi_version(void) { return 11; }  // 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query; 10: gof_forward_fused(usage_pinned_host), backward scratch without its scan (round 4); 11: gof_set_integrate_pixel_pass (round 5)
+int gof_abi_version(void) { return 12; }  // 12: per-call modes in GofRasterArgs (forward_exact, tight_tile_rects, integrate_pixel_pass; round 6); 8: gof_set_forward_exact / gof_set_tight_tile_rects; 9: record pool in the backward scratch, gof_backward_query; 10: gof_forward_fused(usage_pinned_host), backward scratch without its scan (round 4); 11: gof_set_integrate_pixel_pass (round 5)
                                           // 4: densification entry points (gof_train_hip.h), integrate_points bounded by n_contrib; 7: workspace layouts of round 3
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
@@ -469,52 +472,46 @@ size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullpt
 // of it writes: the sync-free forward runs the culls + binning inputs first (stage 1), then the rest (stage 2) on this stream beside
 // the depth sort, scan, emission, tile sort and ranges, and the caller's stream waits for it in front of the blend.  The fork and the
 // join are events between the two streams: to the caller (and to torch's caching allocator) everything stays ordered on ITS stream.
-// GOF_K1_SPLIT=0 in the environment keeps the one-kernel form.
-#ifndef GOF_K1_SPLIT_DEFAULT
-#define GOF_K1_SPLIT_DEFAULT 1
-#endif
+// (Measured and dropped, profiles/r05_ab_call7_binning.txt: the binning chain on a stream of the device's highest priority with
+// stage 2 on the caller's -- the priority changes nothing latency-bound launches feel.)
 namespace {
-// GOF_K1_SPLIT: 0 = one kernel; 1 (shipped) = stage 2 on the library's second stream, the binning chain stays on the caller's;
-// 2 = the other way round: the binning chain (depth sort ... tile order: short, latency-bound launches, the forward's critical path) runs
-// on the library's stream created with the device's HIGHEST priority, stage 2 on the caller's stream -- the device offers no priority
-// BELOW the caller's to push stage 2 down with, but one above it to lift the chain with.  Measured (profiles/r05_ab_call7_binning.txt):
-// the priority changes nothing the chain can feel -- S1M 2.443 vs 2.429 ms per step, clustered 3.285 vs 3.265, 6M 4.162 vs 4.146: kept as
-// a developer switch only
-int k1_split_mode()
-{
-    static const int mode = [] { const char* e = getenv("GOF_K1_SPLIT"); return e ? atoi(e) : GOF_K1_SPLIT_DEFAULT; }();
-    return mode;
-}
-struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
+struct AuxStream {
+    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr, count_ready = nullptr; bool failed = false;
+    ~AuxStream()
+    {   // a caller thread that ends gives its stream and events back (thread_local storage: runs at thread exit; at process exit the
+        // runtime may already be gone -- errors are swallowed)
+        if (count_ready) (void)hipEventDestroy(count_ready);
+        if (join) (void)hipEventDestroy(join);
+        if (fork) (void)hipEventDestroy(fork);
+        if (s) (void)hipStreamDestroy(s);
+        (void)hipGetLastError();
+    }
+};
+// the (thread, device)'s stream + events, created at first use; nullptr if the runtime refuses (the forward then runs on one stream)
 AuxStream* aux_stream()
 {
-    if (k1_split_mode() == 0) return nullptr;
-    static thread_local AuxStream per_device[16];
+    static thread_local AuxStream per_device[MAX_DEVICES];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
     AuxStream& a = per_device[dev];
     if (a.failed) return nullptr;
     if (!a.fork) {
         int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; greatest = 0; }
-        static const int prio_env = [] { const char* e = getenv("GOF_K1_SPLIT_PRIORITY"); return e ? atoi(e) : 0x7fffffff; }();      // (developer A/B)
-        const int prio = prio_env != 0x7fffffff ? prio_env : (k1_split_mode() == 2 ? greatest : least);
-        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); a.failed = true; return nullptr; }
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&a.count_ready, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError(); a.failed = true; return nullptr; }
     }
     return &a;
 }
 // makes `stream` (the caller's) wait for the library stream's work of this call: explicitly in front of the first consumer, and on every
-// other way out.  record_on: (mode 2) the library's stream carries the binning chain, whose last launch is only known to the caller of
-// forward_stage1 -- the join event is recorded on it when the join is asked for
+// other way out
 struct AuxJoin {
     hipStream_t stream = nullptr;
     hipEvent_t pending = nullptr;
-    hipStream_t record_on = nullptr;
     void now()
     {
         if (!pending) return;
-        if (record_on) (void)hipEventRecord(pending, record_on);
         (void)hipStreamWaitEvent(stream, pending, 0);
         pending = nullptr;
     }
@@ -525,70 +522,62 @@ struct AuxJoin {
 // preprocess + depth sort + scan, all asynchronous; *total_dev_out = device address of the instance count
 // join (nullable): the caller can take stage 2 of the per-Gaussian kernel on the second stream; it must call join->now() in front of
 // the first launch that reads the records / conics / footprints / depths / clamp flags
-// chain_stream (with join): the stream the caller queues the rest of the binning chain on (the caller's, or in mode 2 the library's)
+// full_footprint: the per-Gaussian stage also leaves the footprint's pixel box, q and zfront (preprocess.hip: footprint_bbox<true>) -- what
+// the opacity-field query reads; a forward that is followed by the blend needs the conic alone (tight tile rectangles: the box as well)
 static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream,
-                          uint32_t* total_host_mapped = nullptr, AuxJoin* join = nullptr, hipStream_t* chain_stream = nullptr)
+                          bool full_footprint, uint32_t* total_host_mapped = nullptr, AuxJoin* join = nullptr)
 {
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     if (a->prefiltered) GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));   // only then written and read
-    // SH rows through the LDS (preprocess.hip, modes 1 / 2: one aligned [P,16,3] tensor / the (_features_dc, _features_rest) pair): built in
-    // round 5 and measured SLOWER than the per-thread reads (S1M 0.122 vs 0.110 ms, 6M Gaussians 0.648 vs 0.588 ms: 50 KB of LDS leave
-    // three workgroups per CU and two more barriers; profiles/r05_ab_call4_preprocess_fwd.txt) -- compiled in only with -DGOF_K1_TILED=1
-#ifndef GOF_K1_TILED
-#define GOF_K1_TILED 0
-#endif
-    const int k1_mode = (!GOF_K1_TILED || a->colors_precomp) ? 0 : (a->shs_rest ? 2 : ((a->shs && a->M == 16 && (reinterpret_cast<uintptr_t>(a->shs) & 15) == 0) ? 1 : 0));
-    const int k1_bits = (a->prefiltered ? 1 : 0) | (g_tight_rects.load(std::memory_order_relaxed) ? 2 : 0);
-#define GOF_K1_LAUNCH(MODE, STAGE, STREAM) hipLaunchKernelGGL((preprocess_fwd<MODE, STAGE>), dim3((a->P + 255) / 256), dim3(256), 0, STREAM,                 \
+    // (SH rows through the LDS as in preprocess_bwd: built in round 5 and measured SLOWER than the per-thread reads -- S1M 0.122 vs
+    // 0.110 ms, 6M Gaussians 0.648 vs 0.588 ms: 50 KB of LDS leave three workgroups per CU and two more barriers;
+    // profiles/r05_ab_call4_preprocess_fwd.txt -- and removed in round 6)
+    const int k1_bits = (a->prefiltered ? 1 : 0) | (mode_on(a->tight_tile_rects, g_tight_rects) ? 2 : 0);
+    const bool foot = full_footprint || (k1_bits & 2);
+#define GOF_K1_LAUNCH(STAGE, FOOT, STREAM) hipLaunchKernelGGL((preprocess_fwd<STAGE, FOOT>), dim3((a->P + 255) / 256), dim3(256), 0, STREAM,                 \
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,                          \
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,                             \
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, k1_bits,                                                                             \
                        radii, g.depths, g.rec, g.conic, g.bbox, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags, k1_zero_ptr, k1_zero_n)
     // what the depth sort and the fused gather + scan behind it need cleared: cleared by the per-Gaussian kernel, the first launch of the
-    // frame, instead of by a memset launch in front of the sort (GOF_K1_ZERO=0: the memset)
-    static const bool fused_scan = [] { const char* e = getenv("GOF_FUSED_SCAN"); return !(e && e[0] == '0'); }();      // (developer A/B: 0 = gather_rects + the three-kernel scan)
-    static const bool k1_zeroes = [] { const char* e = getenv("GOF_K1_ZERO"); return !(e && e[0] == '0'); }();
-    const size_t scan_words = fused_scan ? gather_scan_state_words((size_t)a->P) : 0;
+    // frame, instead of by a memset launch in front of the sort (depth sort 0.147 -> 0.140 ms at S1M, profiles/r05_ab_call8_binning.txt)
+    const size_t scan_words = gather_scan_state_words((size_t)a->P);
     const size_t sort_zero = radix_zero_words((size_t)a->P, 32);                 // words at the start of the sort's scratch its single-kernel passes want zero (0: none)
     const bool sort_zero_to_end = sort_zero == rs_tmp_words((size_t)a->P);       // ... reaching the scan's state: one range
     uint32_t* k1_zero_ptr = nullptr;
     uint32_t k1_zero_n = 0;
-    if (k1_zeroes && (sort_zero == 0 || sort_zero_to_end)) {
+    if (sort_zero == 0 || sort_zero_to_end) {
         k1_zero_ptr = sort_zero ? g.sort_tmp : g.sort_tmp + rs_tmp_words((size_t)a->P);
         k1_zero_n = (uint32_t)(sort_zero + scan_words);
     }
     // (tight tile rectangles take their tiles_touched from stage 2's footprint box: one kernel then)
-    AuxStream* const aux = (join && k1_mode == 0 && !(k1_bits & 2) && !a->debug) ? aux_stream() : nullptr;
+    AuxStream* const aux = (join && !(k1_bits & 2) && !a->debug) ? aux_stream() : nullptr;
     { GOF_PROFILE("preprocess_fwd", stream);
-    if (aux) GOF_K1_LAUNCH(0, 1, stream);
-    else if (k1_mode == 2) GOF_K1_LAUNCH(2, 0, stream);
-    else if (k1_mode == 1) GOF_K1_LAUNCH(1, 0, stream);
+    if (aux) GOF_K1_LAUNCH(1, 0, stream);
+    else if (foot) GOF_K1_LAUNCH(0, 1, stream);
     else GOF_K1_LAUNCH(0, 0, stream); }
     // (measured, profiles/r05_ab_call5_split_preprocess.txt: S1M 2.459 -> 2.434 ms per step, 6M Gaussians 4.18 -> 4.13, means over three
     // boxes each -- the two streams share the CUs, the depth sort runs 0.108 -> 0.166 ms beside stage 2; forking BEHIND the depth sort
     // instead loses: 2.468 / 4.18.  The device offers no priority below the caller's stream's to put stage 2 on.)
-    const bool chain_on_aux = aux && chain_stream && k1_split_mode() == 2;
     if (aux) {
         GOF_HIP_CHECK(hipGetLastError());
         GOF_HIP_CHECK(hipEventRecord(aux->fork, stream));
         GOF_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));
-        hipStream_t const heavy_stream = chain_on_aux ? stream : aux->s;
-        { GOF_PROFILE("preprocess_fwd_heavy", heavy_stream);
-          GOF_K1_LAUNCH(0, 2, heavy_stream); }
+        { GOF_PROFILE("preprocess_fwd_heavy", aux->s);
+          if (foot) GOF_K1_LAUNCH(2, 1, aux->s);
+          else GOF_K1_LAUNCH(2, 0, aux->s); }
         GOF_HIP_CHECK(hipGetLastError());
         join->stream = stream;
         join->pending = aux->join;
-        if (chain_on_aux) { join->record_on = aux->s; *chain_stream = aux->s; }
-        else GOF_HIP_CHECK(hipEventRecord(aux->join, aux->s));
+        GOF_HIP_CHECK(hipEventRecord(aux->join, aux->s));
     }
-    if (chain_on_aux) stream = aux->s;            // from here on: the binning chain
 #undef GOF_K1_LAUNCH
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
     // (the state words of the fused gather + scan behind it lie right behind the sort's scratch: the sort's own memset clears them too)
     uint32_t* const scan_state = g.sort_tmp + rs_tmp_words((size_t)a->P);
-    uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_rects)
+    uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_scan_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
     GOF_HIP_CHECK(radix_sort_pairs_u32_z(g.dkey_a, g.dval_a, g.dkey_b, g.dval_b, (size_t)a->P, 32, g.sort_tmp, &kr, &vr, stream, nullptr,
                                          k1_zero_ptr ? 0 : scan_words, false, k1_zero_ptr != nullptr));
@@ -598,22 +587,16 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     { GOF_PROFILE("scan_tiles", stream);
     // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
     // scanned in place
-    if (fused_scan) {
-        hipLaunchKernelGGL(gather_scan_rects, dim3(gather_scan_tiles((size_t)a->P)), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b,
-                           g.order_off, radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles, scan_state, total_host_mapped);
-        GOF_HIP_CHECK(hipGetLastError());
-        *total_dev_out = scan_state + 1;
-    } else {
-    hipLaunchKernelGGL(gather_rects, dim3((a->P + 255) / 256), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b, g.order_off,
-                       radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles);
-    GOF_HIP_CHECK(device_scan_u32_to_host(g.order_off, nullptr, g.order_off, (size_t)a->P, false, scan_state,
-                                          total_dev_out, stream, total_host_mapped)); } }
+    hipLaunchKernelGGL(gather_scan_rects, dim3(gather_scan_tiles((size_t)a->P)), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b,
+                       g.order_off, radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles, scan_state, total_host_mapped);
+    GOF_HIP_CHECK(hipGetLastError());
+    *total_dev_out = scan_state + 1; }
     GOF_LAUNCH_CHECK(stream, a->debug);
     return GOF_OK;
 }
 
-int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
-                        int32_t* radii, uint32_t* num_rendered_host, void* stream_)
+static int prepare_impl(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
+                        int32_t* radii, uint32_t* num_rendered_host, void* stream_, bool full_footprint)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = validate(a);
@@ -629,7 +612,7 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
     const uint32_t* total_dev = nullptr;
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream);
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream, full_footprint);
     if (rc) return rc;
     // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
     uint32_t host_words[2] = { 0, 0 };
@@ -648,6 +631,18 @@ int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
         return GOF_E_PREFILTER;
     }
     return GOF_OK;
+}
+
+int gof_forward_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
+                        int32_t* radii, uint32_t* num_rendered_host, void* stream_)
+{
+    return prepare_impl(a, geom_ws, geom_bytes, image_ws, image_bytes, radii, num_rendered_host, stream_, false);
+}
+// the same stage in front of gof_integrate_view / gof_integrate_run: the footprints complete (pixel box, q, zfront)
+int gof_integrate_prepare(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes, void* image_ws, size_t image_bytes,
+                          int32_t* radii, uint32_t* num_rendered_host, void* stream_)
+{
+    return prepare_impl(a, geom_ws, geom_bytes, image_ws, image_bytes, radii, num_rendered_host, stream_, true);
 }
 
 // The whole forward without a pipeline bubble: the binning workspace is sized for `capacity` instances chosen by the caller (e.g.
@@ -680,24 +675,27 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     uint32_t* const usage_mapped = device_view_of_pinned(usage_pinned_host);
     *num_rendered_pinned_host = 0xFFFFFFFFu;
     AuxJoin heavy;                       // (its destructor joins on every way out of this call)
-    hipStream_t cs = stream;             // the stream of the binning chain: the caller's, or (GOF_K1_SPLIT=2) the library's high-priority one
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream, count_mapped, &heavy, &cs);
+    rc = forward_stage1(a, g, im, radii, &total_dev, stream, false, count_mapped, &heavy);
     if (rc) return rc;
-    static thread_local hipEvent_t ev = nullptr;
-    if (!ev) GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    if (!count_mapped) GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
-    GOF_HIP_CHECK(hipEventRecord(ev, cs));
+    // the event the host waits for: one per (thread, device) -- an event belongs to the device it was created on
+    AuxStream* const aux = aux_stream();
+    hipEvent_t ev = aux ? aux->count_ready : nullptr;
+    bool ev_local = false;
+    if (!ev) { GOF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ev_local = true; }
+    struct EvGuard { hipEvent_t e; bool own; ~EvGuard() { if (own) (void)hipEventDestroy(e); } } ev_guard{ ev, ev_local };
+    if (!count_mapped) GOF_HIP_CHECK(hipMemcpyAsync(num_rendered_pinned_host, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GOF_HIP_CHECK(hipEventRecord(ev, stream));
     if (capacity > 0) {
-        rc = bin_gaussians(a, d, capacity, g, b, im, radii, cs, total_dev);
+        rc = bin_gaussians(a, d, capacity, g, b, im, radii, stream, total_dev);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, cs, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(order_tiles, dim3(1), dim3(1024), 0, stream, d.ntiles, im.ranges, nullptr, im.tile_order, im.tile_queue, nullptr, im.mask_cursors, nullptr, nullptr, nullptr);
     }
     heavy.now();                         // the two streams meet: records, conics and footprints are stage 2's, lists and ranges the chain's -- the blend is their first reader
     launch_blend_forward(a, d, g, b, im, out_color, stream);
     GOF_LAUNCH_CHECK(stream, 0);
     order_tiles_for_backward(d, im, stream, usage_mapped);
-    if (usage_pinned_host && (!usage_mapped || bw_order_by_length()))       // (not device-mapped, or the developer switch skipped the launch that stores the words: the copy form, as gof_forward_usage_async)
+    if (usage_pinned_host && !usage_mapped)       // (not device-mapped: the copy form, as gof_forward_usage_async)
         GOF_HIP_CHECK(hipMemcpyAsync(usage_pinned_host, im.mask_cursors, (POOL_SHARDS + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GOF_HIP_CHECK(hipEventSynchronize(ev));
     if (*num_rendered_pinned_host >= GOF_SORT_FAILED_COUNT) {
@@ -837,7 +835,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
         hipLaunchKernelGGL(blend_backward, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.conic, b.mp, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T,
                            im.n_contrib, dL_dout, g.rect, g.inst_first, ws.part16, ws.slot_of, ws.queue + BWD_REC_CURSOR, rec_cap, d.gx, d.ntiles,
-                           bw_order_by_length() ? im.tile_order : im.tile_order_bw, ws.queue, im.tile_queue + (bw_order_by_length() ? 0 : TILE_QUEUE_WORDS / 2) + NXCD);
+                           im.tile_order_bw, ws.queue, im.tile_queue + TILE_QUEUE_WORDS / 2 + NXCD);
         GOF_LAUNCH_CHECK(stream, a->debug);
     }
     { GOF_PROFILE("gather_tile_partials", stream);
@@ -897,7 +895,7 @@ static void decode_usage(const uint32_t* words, uint32_t R, int32_t W, int32_t H
     out3[1] = (uint32_t)(4u * asked > 0xFFFFFFFFull ? 0xFFFFFFFFull : 4u * asked);
     if (words[POOL_SHARDS]) out3[1] = out3[1] > b.mp.cap ? out3[1] : b.mp.cap + 4u;                   // (unserved requests: certainly more than held)
     const uint32_t staged = words[POOL_SHARDS + 1];
-    out3[0] = (bw_order_by_length() || staged > R) ? R : staged;                                       // (developer toggle: the forward left no backward order, hence no sum: worst case)
+    out3[0] = staged > R ? R : staged;
 }
 int gof_usage_decode(const uint32_t* words_host, uint32_t R, int32_t W, int32_t H, size_t binning_bytes, uint32_t* out3_host)
 {
@@ -983,7 +981,7 @@ int gof_integrate_view(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
     rc = bin_gaussians(a, d, R, g, b, im, radii, stream);
     if (rc) return rc;
     GOF_PROFILE("integrate_pixels", stream);
-    if (g_integrate_pixel_pass.load(std::memory_order_relaxed)) {      // the pixel-centric form of rounds 1-4 (gof_set_integrate_pixel_pass(1): A/B, tests)
+    if (mode_on(a->integrate_pixel_pass, g_integrate_pixel_pass)) {      // the pixel-centric form of rounds 1-4 (args->integrate_pixel_pass / gof_set_integrate_pixel_pass(1): A/B, tests)
         hipLaunchKernelGGL(integrate_pixels, dim3(xcd_padded_tiles(d.ntiles)), dim3(TILE_PIX), 0, stream,
                            im.ranges, b.vals, g.rec, g.bbox, g.fconic, a->W, a->H, d.focal_x, d.focal_y, a->background, im.final_T, im.n_contrib,
                            out_color, b.cmask, d.gx, d.ntiles, im.tile_order, im.tile_queue, im.tile_cost);

@@ -33,41 +33,15 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-// Everything the instance emission needs of a Gaussian, gathered into DEPTH order with one random 8-byte read per Gaussian (the
-// tile rectangle preprocess_fwd packed): the rectangle words, and the instance count for the scan.  (Gathering tiles_touched in
-// both scan passes and radii + the record's pixel position again in the emission cost three 64-byte sectors per Gaussian.)
-__global__ void __launch_bounds__(256)
-gather_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys_sorted,
-             uint32_t* __restrict__ minxy_sorted, uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ counts,
-             const uint32_t* __restrict__ sort_error, uint2* __restrict__ ranges, uint32_t ntiles)
-{
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    // the tile ranges must be zero before tile_ranges fills them in (cudaMemset of rasterizer_impl.cu:365): cleared here, on the way,
-    // instead of by a memset launch of its own between the sort and tile_ranges (~5 us of queue time for 54 KB)
-    for (uint32_t t = i; t < ntiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
-    if (i >= n) return;
-    // the depth sort's bounded look-back poll expired (radix.hip: OS_SPIN_LIMIT): `order` is not a sorted permutation.  Make the
-    // instance count the host reads back impossible (GOF_SORT_FAILED_COUNT) so that the call fails instead of rendering garbage.
-    // The sentinel sits in the LAST count: every exclusive offset stays 0 and every rectangle empty, so emit_instances writes
-    // nothing, and the launches already queued behind the scan see device_item_count() == 0 (gof_status.h).
-    if (sort_error && *sort_error) {
-        minxy_sorted[i] = 0u; wh_sorted[i] = 0u;
-        counts[i] = (i == n - 1u) ? GOF_SORT_FAILED_COUNT : 0u;
-        return;
-    }
-    // a culled Gaussian (sort key 0xFFFFFFFF: they sort last) has the empty rectangle: its random read is skipped -- a camera of a real
-    // capture culls most of the scene (the sorted keys are read in order: 4 coalesced bytes against a 64-byte sector)
-    const uint2 r = (keys_sorted && keys_sorted[i] == 0xFFFFFFFFu) ? make_uint2(0u, 0u) : rect[order[i]];
-    minxy_sorted[i] = r.x;
-    wh_sorted[i] = r.y;
-    counts[i] = (r.y & 0xFFFFu) * (r.y >> 16);
-}
-
-// gather_rects + the exclusive scan of the counts in ONE launch (replaces cub::DeviceScan::InclusiveSum of rasterizer_impl.cu:332 together
-// with the gather in front of it; until round 5: gather_rects, scan_block_sums, scan_apply = three launches, 31 us on the critical path
-// of a 1M-Gaussian frame, of which the kernels' own work is a third).  A workgroup takes a ticket (= its tile of GS_BLOCK consecutive
-// positions of the depth order: every tile with a smaller ticket is running or done, so waiting for them cannot deadlock), gathers
-// the rectangles exactly as gather_rects, scans its counts (wave by wave: a wave owns 1024 consecutive positions, 16 coalesced steps
+// Everything the instance emission needs of a Gaussian, gathered into DEPTH order with one random 8-byte read per Gaussian (the tile
+// rectangle preprocess_fwd packed) + the exclusive scan of the instance counts, in ONE launch (replaces cub::DeviceScan::InclusiveSum
+// of rasterizer_impl.cu:332 together with the gather in front of it; until round 5: a gather kernel, scan_block_sums, scan_apply = three
+// launches, 31 us on the critical path of a 1M-Gaussian frame, of which the kernels' own work is a third).  A workgroup takes a ticket
+// (= its tile of GS_BLOCK consecutive positions of the depth order: every tile with a smaller ticket is running or done, so waiting
+// for them cannot deadlock), gathers the rectangles -- a culled Gaussian (sort key 0xFFFFFFFF: they sort last) has the empty
+// rectangle and its random read is skipped; after a depth sort whose bounded look-back poll expired (`order` is then not a sorted
+// permutation) every rectangle is empty and the LAST count is GOF_SORT_FAILED_COUNT, so that the call fails instead of rendering
+// garbage and the launches already queued see 0 items --, scans its counts (wave by wave: a wave owns 1024 consecutive positions, 16 coalesced steps
 // of 64), publishes its total as an AGGREGATE descriptor, and wave 0 looks back over 64 predecessors per round trip -- their
 // descriptors in one load instruction, consumed in order up to the first PREFIX -- until it knows the sum in front of its tile;
 // then the tile publishes its PREFIX and stores its offsets.  Descriptors are 64-bit (flag << 32 | value): the value is an instance
@@ -95,19 +69,19 @@ gather_scan_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __
     __shared__ uint32_t s_tile, s_base;
     __shared__ uint32_t s_wtot[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // (the tile ranges cleared on the way, as gather_rects does)
+    // (the tile ranges must be zero before tile_ranges fills them in -- cudaMemset of rasterizer_impl.cu:365 --: cleared here, on the way)
     for (uint32_t t = blockIdx.x * 256u + tid; t < ntiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
     if (tid == 0) s_tile = atomicAdd(&state[0], 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
-    const bool failed = sort_error && *sort_error != 0u;          // the depth sort timed out: as gather_rects
+    const bool failed = sort_error && *sort_error != 0u;          // the depth sort timed out (see above)
     const uint32_t wbase = tile * GS_BLOCK + wave * (64u * GS_ITEMS);
     uint32_t ord[GS_ITEMS], cnt[GS_ITEMS];
     uint2 r[GS_ITEMS];
 #pragma unroll
     for (int s = 0; s < GS_ITEMS; s++) {
         const uint32_t i = wbase + 64u * s + lane;
-        // no rectangle to read (0xFFFFFFFF): past the end, a failed sort, or a culled Gaussian (sort key 0xFFFFFFFF: gather_rects).  Key
+        // no rectangle to read (0xFFFFFFFF): past the end, a failed sort, or a culled Gaussian (sort key 0xFFFFFFFF).  Key
         // and id are requested together -- one round trip, not two: this kernel is a chain of dependent loads
         const bool ok = i < n && !failed;
         const uint32_t key = (ok && keys_sorted) ? keys_sorted[i] : 0u;
@@ -227,11 +201,11 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     if (inst_first)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)P; i += gridDim.x * 256u) {
             // (a depth sort whose look-back poll expired leaves slots of `order` unwritten: whatever lies there must not become an
-            // address -- gather_rects guards its reads with the sort's error flag, this store with the range itself)
+            // address -- gather_scan_rects guards its reads with the sort's error flag, this store with the range itself)
             const uint32_t id = order[i];
             if (id < (uint32_t)P) inst_first[id] = order_off[i];
         }
-    // the instance count: exclusive offset + count of the last Gaussian in the order (0 after a failed depth sort: gather_rects)
+    // the instance count: exclusive offset + count of the last Gaussian in the order (0 after a failed depth sort: gather_scan_rects)
     const uint32_t wh_last = wh_sorted[P - 1];
     const uint32_t total = order_off[P - 1] + (wh_last & 0xFFFFu) * (wh_last >> 16);
     const uint32_t limit = min(total, capacity);       // capacity < the instance count only in the sync-free forward (then redone)

@@ -8,11 +8,10 @@
 //    (backward.cu:836, 905-912, 943-952).  Here all 64 lanes of a wave (an 8x8 pixel quadrant) look at the SAME splat
 //    at the same time, and the partial gradients are summed IN REGISTERS over the whole wave (16 of the 17: the last one,
 //    dL_dview2gaussian[9] = -0.5 w G dL_dalpha, is -0.5 w times the opacity gradient with w a constant of the Gaussian):
-//      1. a TRANSPOSED reduction of the 16 values: every level halves the number of live values per lane -- the half-wave and
-//         row levels with v_permlane32_swap / v_permlane16_swap (gfx950; no selects), the two quad levels with DPP and selects,
-//         two row rotations finish;
-//      2. lane l ends with the wave total of value 8 b1 + 4 b0 + 2 p + h (lane bits 0, 1, row parity, wave half);
-//      3. ONE plain LDS store (16 active lanes) puts the totals into the wave's own slab
+//      1. every lane stores its 16 values into a [value][lane] LDS panel of its wave, in two halves of 8 (contiguous ds_write2_b32);
+//      2. lane (v, p) = (lane / 8, lane % 8) reads back lanes 8 p .. 8 p + 7 of value v (two ds_read_b128), adds them, three DPP steps
+//         finish: lanes 0, 8, 16, ... hold the wave totals of the half's 8 values;
+//      3. ONE plain LDS store per half (8 active lanes) puts the totals into the wave's own slab
 //         s_slab[wave][16][BATCH]: a wave visits an entry at most once per batch, so nothing is read back and no LDS
 //         atomic is needed (measured: ds_add_f32 costs ~3.5 cycles per active LANE; the former 68 lane-atomics per
 //         entry and wave kept the LDS busy ~70 % of the time);
@@ -54,33 +53,23 @@ constexpr int NGRAD = 16;   // colour 3, mean2D 3, opacity 1, view2gaussian 0..8
 #endif
 constexpr int BATCH = GOF_BW_BATCH;
 static_assert(BATCH == 32 || BATCH == 64 || BATCH == 128, "BATCH must be 32, 64 or 128");
-// How the 16 per-pair values are summed over the wave (GOF_BW_REDUCE):
-//   0  in registers: transposed reduction with v_permlane32/16_swap, DPP quad levels and row rotations (rounds 2-3; ~75 VALU
-//      instructions of which 12 lane-group swaps at ~12 cycles: ~300 of the trip's 749 SIMD-cycles);
-//   2  through the LDS (round 4, shipped), in two halves of 8 values: every lane stores 8 values into a [value][lane] panel of its
-//      wave (ds_write2_b32, contiguous per instruction), then lane (v, p) = (lane / 8, lane % 8) reads back the 8 lanes 8 p .. 8 p + 7
-//      of value v with two ds_read_b128, adds them, and three DPP steps finish: 18 VALU instructions per half; the transposition is
-//      done by the LDS crossbar, which this kernel leaves idle otherwise.  Row stride 68 words (b128 lane groups on distinct 16-byte
-//      slots: MI355X_MICROARCH.md, LDS).  8.5 KB more LDS: 31.5 KB, 5 workgroups per CU.
-// Measured (profiles/r04_ab_call2_*.txt, S1M / S1M-clustered): 0: 1.162 / 1.543 ms; 2: 1.070 / 1.373 ms (-8 % / -11 %).  The ISA count
-// promised more (746 -> 598 SIMD-cycles per trip): an LDS store moves its source registers through the SIMD's register read ports
-// (~2 cycles per dword), so the 16 stored values cost about what the 12 swaps did.  Also measured, not kept: all 16 values through
-// one 17 KB panel (1.091 / 1.396, 4 workgroups per CU); that software-pipelined over the visits -- panel of visit k read back during
-// visit k + 1's arithmetic (1.082 / 1.393: the round trip was not what limited it); lanes without a contribution storing a zero
-// register instead of every lane clearing 16 registers first (1.174 / 1.521: eight more store instructions cost more than 16 v_mov).
-#ifndef GOF_BW_REDUCE
-#define GOF_BW_REDUCE 2
-#endif
-#if GOF_BW_REDUCE != 0 && GOF_BW_REDUCE != 2
-#error "GOF_BW_REDUCE: 0 (register swaps) or 2 (LDS panel, two halves)"
-#endif
+// How the 16 per-pair values are summed over the wave: through the LDS (round 4), in two halves of 8 values: every lane stores 8 values
+// into a [value][lane] panel of its wave (ds_write2_b32, contiguous per instruction), then lane (v, p) = (lane / 8, lane % 8) reads back
+// the 8 lanes 8 p .. 8 p + 7 of value v with two ds_read_b128, adds them, and three DPP steps finish: 18 VALU instructions per half; the
+// transposition is done by the LDS crossbar, which this kernel leaves idle otherwise.  Row stride 68 words (b128 lane groups on distinct
+// 16-byte slots: MI355X_MICROARCH.md, LDS).  8.5 KB more LDS: 31.5 KB, 5 workgroups per CU.
+// Measured (profiles/r04_ab_call2_*.txt, S1M / S1M-clustered) against rounds 2-3's transposed reduction IN REGISTERS (v_permlane32_swap /
+// v_permlane16_swap, DPP quad levels with selects, row rotations: ~75 VALU instructions of which 12 lane-group swaps at ~12 cycles, ~300
+// of the trip's 749 SIMD-cycles; removed in round 6): 1.162 / 1.543 ms -> 1.070 / 1.373 ms (-8 % / -11 %).  The ISA count promised more
+// (746 -> 598 SIMD-cycles per trip): an LDS store moves its source registers through the SIMD's register read ports (~2 cycles per
+// dword), so the 16 stored values cost about what the 12 swaps did.  Also measured, not kept: all 16 values through one 17 KB panel
+// (1.091 / 1.396, 4 workgroups per CU); that software-pipelined over the visits -- panel of visit k read back during visit k + 1's
+// arithmetic (1.082 / 1.393: the round trip was not what limited it); lanes without a contribution storing a zero register instead of
+// every lane clearing 16 registers first (1.174 / 1.521: eight more store instructions cost more than 16 v_mov); the batch's records
+// staged by quads of lanes over all four waves instead of by one thread per entry (round 5: 1.075 vs 1.058 / 1.399 vs 1.364 ms,
+// profiles/r05_ab_call6_binning.txt -- with five workgroups per CU resident the idle waves at the staging barrier cost nothing another
+// workgroup cannot use; removed in round 6).
 constexpr int RED_STRIDE = 68;
-// GOF_BW_STAGE: who stages a batch's records -- 0 (shipped): one thread per entry (wave 0 at 64 entries per batch); 1: a quad of lanes
-// per entry, all four waves (measured: profiles/r05_ab_call6_*.txt)
-#ifndef GOF_BW_STAGE
-#define GOF_BW_STAGE 0
-#endif
-
 #ifdef GOF_STATS
 // developer-only instrumentation (never in the shipped build): [0] wave iterations of the entry loop, [1] (row, iteration) pairs with
 // an entry to visit, [2] contributing (lane, entry) pairs, [3] word fetches, [4] staged entries, [5] pairs of CONSECUTIVE visited
@@ -190,9 +179,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
     __shared__ float s_slab[4][NGRAD][BATCH + GOF_BW_SLAB_PAD];
     __shared__ uint32_t s_vis[4][BATCH / 32];           // per wave: which entries those are
     __shared__ uint32_t s_max_last;
-#if GOF_BW_REDUCE == 2
     __shared__ __attribute__((aligned(16))) float s_red[4][NGRAD / 2][RED_STRIDE];
-#endif
 
     const float T_final = inside ? final_Ts[pix_id] : 0;
     float T = T_final;
@@ -258,35 +245,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         __syncthreads();
         const uint32_t p0 = (uint32_t)kb * BATCH;
         const int n = (int)min((uint32_t)BATCH, max_last - p0);
-#if GOF_BW_STAGE == 1
-        {
-            // staging by all four waves (round 5, A/B): a QUAD of lanes per entry, lane q loads the q-th 16-byte quarter of the record (one
-            // 64-byte line per quad) and its share of the entry's other words -- a fourth of the loads per wave and no wave idling at the
-            // barrier behind wave 0's gathers; the pair layout's mixed words travel between the quad's lanes by DPP
-            const uint32_t e = tid >> 2, q = tid & 3u;
-            const bool live = (int)e < n;
-            const uint32_t id = live ? point_list[range.x + p0 + e] : 0u;
-            const float4 ch = live ? reinterpret_cast<const float4*>(&rec[id])[q] : make_float4(0.f, 0.f, 0.f, 0.f);      // a | b | c | d
-            float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint2 rc = make_uint2(0u, 0u);
-            uint32_t io = 0u;
-            if (live && q == 0u) co = conic[id];
-            if (live && q == 1u) { rc = rect[id]; io = inst_off[id]; }
-            // words of the neighbouring quarters: from lane q - 1 (quad_perm [0,0,1,2]) and lane q + 1 (quad_perm [1,2,3,3])
-            const float prev_z = dpp_get<0x90>(ch.z);       // q = 1: a.z
-            const float next_x = dpp_get<0xF9>(ch.x);       // q = 1: c.x, q = 2: d.x
-            if (live) {
-                if (q == 0u) { s_rec[0][e] = f4{ ch.x, ch.y, ch.y, ch.w }; s_rec[5][e] = f4{ co.x, co.z, co.y, co.y }; }
-                else if (q == 1u) {
-                    s_rec[1][e] = f4{ prev_z, ch.x, prev_z, ch.z };
-                    s_rec[2][e] = f4{ ch.x, ch.w, ch.y, next_x };
-                    s_inst[e] = io + (ty - (rc.x >> 16)) * (rc.y & 0xFFFFu) + (tx - (rc.x & 0xFFFFu));
-                }
-                else if (q == 2u) s_rec[3][e] = f4{ ch.y, ch.z, ch.w, next_x };
-                else s_rec[4][e] = f4{ ch.y, 0.f, ch.z, ch.w };
-            }
-        }
-#else
         {
             // staging: one thread per entry reads the 64-byte record + the 2D conic and writes the pair layout
             if ((int)tid < n) {
@@ -306,7 +264,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                 s_inst[tid] = inst_off[id] + (ty - (rc.x >> 16)) * (rc.y & 0xFFFFu) + (tx - (rc.x & 0xFFFFu));
             }
         }
-#endif
         // the pixel's contributor words of this batch: read by their own thread only -- registers, not LDS
         uint32_t cmw[BATCH / 32];
         {
@@ -328,9 +285,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
         // The wave walks the union of its pixels' contributors back to front (wave-uniform entry index: scalar bit walk over
         // the OR of the 64 mask words, LDS reads of the record are broadcasts).
         const uint32_t wave = tid >> 6;
-#if GOF_BW_REDUCE == 0
-        const uint32_t slab_row = 8u * ((lane >> 1) & 1u) + 4u * (lane & 1u) + 2u * ((lane >> 4) & 1u) + (lane >> 5);   // value this lane's total belongs to
-#endif
 #pragma unroll
         for (int w = BATCH / 32 - 1; w >= 0; w--) {
             if (w > ((n + 31) >> 5) - 1) continue;                 // (wave-uniform; the loop is unrolled so that cmw[] stays in registers)
@@ -480,38 +434,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                     // formed from the total of g[6] at the flush, not reduced here
                     }
                 }
-                // GOF_BW_REDUCE == 0: wave total of the 16 values by a transposed reduction whose first two levels use gfx950's lane-group
-                // swaps (no selects): v_permlane32_swap exchanges the upper half of one register with the lower half of another, so
-                // x + y afterwards holds value A summed over the halves in lanes 0-31 and value B in lanes 32-63; v_permlane16_swap
-                // does the same for odd / even rows.  16 -> 8 -> 4 live values; two DPP quad levels with selects 4 -> 2 -> 1; two row
-                // rotations finish.  Lane l ends with the wave total of value 8 b1 + 4 b0 + 2 p + h (b0, b1 = lane bits 0, 1;
-                // p = row parity; h = wave half).
-#if GOF_BW_REDUCE == 0
-                float u[8], v4[4];
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g[2 * m]), __float_as_uint(g[2 * m + 1]), false, false);
-                    u[m] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                }
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * m]), __float_as_uint(u[2 * m + 1]), false, false);
-                    v4[m] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                }
-                float tot;
-                {
-                    const bool b0 = (lane & 1u) != 0u, b1 = (lane & 2u) != 0u;
-                    const float k0 = b0 ? v4[1] : v4[0], s0 = b0 ? v4[0] : v4[1];
-                    const float k1 = b0 ? v4[3] : v4[2], s1 = b0 ? v4[2] : v4[3];
-                    const float w0 = k0 + dpp_get<0xB1>(s0);          // quad_perm [1,0,3,2]
-                    const float w1 = k1 + dpp_get<0xB1>(s1);
-                    const float k = b1 ? w1 : w0, sn = b1 ? w0 : w1;
-                    tot = k + dpp_get<0x4E>(sn);                      // quad_perm [2,3,0,1]
-                    tot = tot + dpp_get<0x124>(tot);                  // row_ror:4
-                    tot = tot + dpp_get<0x128>(tot);                  // row_ror:8
-                }
-                if ((lane & 12u) == 0u) s_slab[wave][slab_row][j] = tot;
-#else
                 // The wave's own panel: no other wave touches it, and the LDS serves a wave's instructions in order -- the wave
                 // barriers only keep the compiler from moving the accesses across (no instruction).
                 {
@@ -534,7 +456,6 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
                         if ((lane & 7u) == 0u) s_slab[wave][h * (NGRAD / 2) + (lane >> 3)][j] = tot;
                     }
                 }
-#endif
             }
             if (lane == 0) s_vis[wave][w] = visited;
         }
@@ -583,11 +504,7 @@ blend_backward_tile(const uint32_t tile, const uint2* __restrict__ ranges, const
 }
 
 // one workgroup per tile, popped as the workgroup starts: deepest walk first (pop_tile, gof_common.h; order by the forward's tile_cost)
-#if GOF_BW_REDUCE == 0
 #define GOF_BW_MIN_WAVES 5
-#else
-#define GOF_BW_MIN_WAVES 5
-#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GOF_BW_MIN_WAVES, 8)))
 blend_backward(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const SplatRec* __restrict__ rec,
                const float4* __restrict__ conic, const MaskPool masks, int W, int H, float focal_x, float focal_y,

@@ -138,10 +138,18 @@ __device__ __forceinline__ void v2g_intermediates(V3 scale, V3 mean, float4 rot,
 // (round 5, cost: this function was ~45 % of preprocess_fwd's 670 fp64 instructions, and the kernel is bound by them, not by HBM: the
 // level m0 from the fp32 logarithm -- its ~1e-6 relative error is 1e-5 of the 0.05 the level carries for exactly such things --, the
 // three 1 / l_c taken as s_c^2 + 1e-7, which is what l_c is the reciprocal of (`var_*`), and one reciprocal for the four box edges)
+// FULL (round 6): true = everything above -- what the opacity-field query reads (pixel box: its pixel-centric pass / the capped fallback,
+// and the opt-in tight tile rectangles; q: the half-pixel allowance of the pixel-centric scan; zfront: the point pass).  false = the
+// conic alone, which is all blend_forward reads of a footprint (fc[0], fc[1].xy): the pixel box (five symmetric products, two
+// discriminants, two fp64 square roots, a division, four edges with ceil / floor) and zfront (a square root and a division) were ~40 %
+// of this kernel's fp64 instructions, computed and stored by every training forward for nobody.  Then the box is returned UNBOUNDED,
+// q = -1e30 ("every entry a candidate") and zfront = -1e30 ("no statement"): a query that is handed such a workspace all the same stays
+// exact, only unculled.
+template <bool FULL>
 __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float w, float focal_x, float focal_y, int W, int H, float4* fc, double var_x, double var_y, double var_z)
 {
     fc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    fc[1] = make_float4(0.f, 0.f, 0.f, -1e30f);
+    fc[1] = make_float4(0.f, 0.f, FULL ? 0.f : -1e30f, -1e30f);
     const float4 unbounded = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);
     const float4 empty = make_float4(1e30f, -1e30f, 1e30f, -1e30f);
     if (!(w > 0.0f)) return empty;                                  // alpha <= 0 < 1/255 everywhere
@@ -149,8 +157,7 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     if (!(m0 > -0.05)) return empty;                                // w < 1/255: can never reach the threshold
     const double lx = I.Sx, ly = I.Sy, lz = I.Sz;                   // eigenvalues of Sigma' = 1 / (s^2 + 1e-7)
     const double lmax = fmax(lx, fmax(ly, lz)), lmin = fmin(lx, fmin(ly, lz));
-    const double cond = lmax / lmin;
-    if (!(cond < 1e4)) return unbounded;
+    if (!(lmax < 1e4 * lmin)) return unbounded;                     // cond(Sigma') >= 1e4 (or NaN): no statement (a product instead of round 5's fp64 division)
     {   // the closed form below needs an orthonormal frame (unit quaternion, rigid view matrix); otherwise leave it unbounded
         const M3& R = I.Rt;
         float dev = 0.f;
@@ -178,11 +185,6 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
     const double a00 = Rt.m[0][0], a01 = Rt.m[0][1], a02 = Rt.m[0][2];
     const double a10 = Rt.m[1][0], a11 = Rt.m[1][1], a12 = Rt.m[1][2];
     const double a20 = Rt.m[2][0], a21 = Rt.m[2][1], a22 = Rt.m[2][2];
-    const double Sxx = k * (a00 * a00 * ix + a01 * a01 * iy + a02 * a02 * iz);
-    const double Syy = k * (a10 * a10 * ix + a11 * a11 * iy + a12 * a12 * iz);
-    const double Szz = k * (a20 * a20 * ix + a21 * a21 * iy + a22 * a22 * iz);
-    const double Sxz = k * (a00 * a20 * ix + a01 * a21 * iy + a02 * a22 * iz);
-    const double Syz = k * (a10 * a20 * ix + a11 * a21 * iy + a12 * a22 * iz);
     {   // footprint conic (see the header comment): Sigma'_ij = sum_c a_ic a_jc l_c
         const double pxx = a00 * a00 * lx + a01 * a01 * ly + a02 * a02 * lz, pxy = a00 * a10 * lx + a01 * a11 * ly + a02 * a12 * lz;
         const double pyy = a10 * a10 * lx + a11 * a11 * ly + a12 * a12 * lz, pxz = a00 * a20 * lx + a01 * a21 * ly + a02 * a22 * lz;
@@ -194,14 +196,26 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
         const double Sm = fabs(m00) + 2.0 * fabs(m01) + fabs(m11) + 2.0 * fabs(m02) + 2.0 * fabs(m12) + fabs(m22);
         if (Sm > 0.0 && Sm < 1e300) {
             const double is = 1.0 / Sm;
-            const double hx = 0.5 / (double)focal_x, hy = 0.5 / (double)focal_y;
-            const double q = (m00 * hx * hx + m11 * hy * hy - 2.0 * fabs(m01) * hx * hy) * is;
             fc[0] = make_float4((float)(m00 * is), (float)(m01 * is), (float)(m11 * is), (float)(m02 * is));
-            fc[1] = make_float4((float)(m12 * is), (float)(m22 * is), (float)q, -1e30f);
+            if (FULL) {
+                const double hx = 0.5 / (double)focal_x, hy = 0.5 / (double)focal_y;
+                const double q = (m00 * hx * hx + m11 * hy * hy - 2.0 * fabs(m01) * hx * hy) * is;
+                fc[1] = make_float4((float)(m12 * is), (float)(m22 * is), (float)q, -1e30f);
+            } else {
+                fc[1] = make_float4((float)(m12 * is), (float)(m22 * is), -1e30f, -1e30f);
+            }
         }
-        const double zf = mz - sqrt(k / lmin) * (1.0 + 1e-5) - 1e-5 * fabs(mz);
-        if (zf == zf) fc[1].w = (float)(zf - 1e-6 * fabs(zf));               // rounded down
+        if (FULL) {
+            const double zf = mz - sqrt(k / lmin) * (1.0 + 1e-5) - 1e-5 * fabs(mz);
+            if (zf == zf) fc[1].w = (float)(zf - 1e-6 * fabs(zf));           // rounded down
+        }
     }
+    if (!FULL) return unbounded;
+    const double Sxx = k * (a00 * a00 * ix + a01 * a01 * iy + a02 * a02 * iz);
+    const double Syy = k * (a10 * a10 * ix + a11 * a11 * iy + a12 * a12 * iz);
+    const double Szz = k * (a20 * a20 * ix + a21 * a21 * iy + a22 * a22 * iz);
+    const double Sxz = k * (a00 * a20 * ix + a01 * a21 * iy + a02 * a22 * iz);
+    const double Syz = k * (a10 * a20 * ix + a11 * a21 * iy + a12 * a22 * iz);
     const double czz = mz * mz - Szz;
     // camera inside (or the ellipsoid reaching the camera plane): unbounded
     if (!(czz > 1e-9 * mz * mz) || !(mz > 0.0)) return unbounded;
@@ -225,19 +239,18 @@ __device__ __forceinline__ float4 footprint_bbox(const V2GInter& I, V3 mu, float
 // 3.4 TB/s on its algorithmic bytes until round 4)
 constexpr int K9_ROW = 49;
 
-// MODE 0: coefficients read per thread from global memory (any M, unaligned tensors, colors_precomp); 1: shs is one 16-byte aligned
-// [P,16,3] tensor; 2: shs = _features_dc [P,1,3], shs_rest = _features_rest [P,15,3] (GofRasterArgs.shs_rest) -- both through the LDS.
-// Only the rows of Gaussians that survive the culls are loaded, and only the coefficients the active degree reads.
+// The SH coefficients are read per thread from global memory (any M, unaligned tensors, the (_features_dc, _features_rest) pair of
+// GofRasterArgs.shs_rest, or colors_precomp instead).  (Rows staged through the LDS as in preprocess_bwd: measured slower in round 5,
+// removed in round 6 -- profiles/r05_ab_call4_preprocess_fwd.txt.)
 // STAGE (round 5): 0 = the whole kernel; 1 = the culls and what binning needs of a Gaussian (radii, tiles_touched, tile rectangle,
 // depth key) and nothing else; 2 = everything else (record, conics, footprint, depth, clamp flags), the culls recomputed.  Nothing of
 // the binning chain -- depth sort, scan, instance emission, tile sort, ranges, tile order: 0.34 ms at S1M, 0.9 ms at 6M Gaussians --
 // reads what stage 2 writes (the blend does), and stage 2 is bound by its fp64 arithmetic at 4 waves per SIMD: the sync-free forward
 // queues stage 1 (a third of the instructions), then stage 2 on a second stream BESIDE the binning chain, and joins in front of the
 // blend (api.hip: forward_stage1).  Both stages evaluate the culls with the same instructions: same bits.
-template <int MODE, int STAGE>
-#ifdef GOF_PRE_WAVES
-__attribute__((amdgpu_waves_per_eu(GOF_PRE_WAVES, 8)))
-#endif
+// FOOT: 1 = the full footprint (pixel box, q, zfront: the opacity-field query, tight tile rectangles), 0 = the conic alone (a forward
+// that is followed by the blend only: footprint_bbox<false>)
+template <int STAGE, int FOOT>
 __global__ void __launch_bounds__(256)
 preprocess_fwd(int P, int D, int M,
                const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
@@ -258,9 +271,6 @@ preprocess_fwd(int P, int D, int M,
     // never by stage 2, which runs BESIDE them
     if (STAGE != 2 && zero_n)
         for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < zero_n; w += gridDim.x * 256u) zero_ptr[w] = 0u;
-    constexpr bool TILED = MODE != 0;
-    __shared__ float s_sh[TILED ? 256 * K9_ROW : 1];
-    __shared__ uint64_t s_vis[4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < P;
     int32_t my_radii = 0;
@@ -358,70 +368,15 @@ preprocess_fwd(int P, int D, int M,
         return;
     }
 
-    // ---- the surviving Gaussians' SH rows: global -> LDS, 16 bytes per lane, consecutive lanes consecutive addresses ----
-    const float* my_row = nullptr;
-    if (TILED) {
-        const uint64_t wv = __ballot(vis);
-        if ((threadIdx.x & 63u) == 0u) s_vis[threadIdx.x >> 6] = wv;
-        __syncthreads();
-        const int b0 = blockIdx.x * 256;
-        const int rows = min(256, P - b0);
-        const int nco = 3 * (D + 1) * (D + 1);                     // floats of a row the active degree reads (forward.cu:20-71)
-        auto row_visible = [&](int g) { return (s_vis[g >> 6] >> (g & 63)) & 1ull; };
-        if (MODE == 1) {
-            const float4* src = reinterpret_cast<const float4*>(shs + (size_t)b0 * 48);
-            for (int i = threadIdx.x; i < rows * 12; i += 256) {
-                const int f = i * 4, g = f / 48, k = f - g * 48;
-                if (k >= nco || !row_visible(g)) continue;
-                const float4 v = src[i];
-                float* d = &s_sh[g * K9_ROW + k];
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            const float* dc = shs + (size_t)b0 * 3;
-            for (int i = threadIdx.x; i < rows * 3; i += 256) {
-                const int g = i / 3, k = i - g * 3;
-                if (row_visible(g)) s_sh[g * K9_ROW + k] = dc[i];
-            }
-            if (nco > 3) {
-                const float* rest = shs_rest + (size_t)b0 * 45;
-                const int n4 = (reinterpret_cast<uintptr_t>(rest) & 15) ? 0 : (rows * 45) >> 2;       // 16-byte loads when the tensor allows
-                const float4* src = reinterpret_cast<const float4*>(rest);
-                for (int i = threadIdx.x; i < n4; i += 256) {
-                    const int f0 = i * 4, g0 = f0 / 45, g1 = (f0 + 3) / 45;           // a 16-byte group may straddle two rows
-                    if ((!row_visible(g0) && !row_visible(g1)) || (f0 - g0 * 45 + 3 >= nco && g1 == g0)) continue;
-                    const float4 v = src[i];
-                    const float q[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int f = f0 + e, g = f / 45, k = f - g * 45;
-                        s_sh[g * K9_ROW + 3 + k] = q[e];
-                    }
-                }
-                for (int f = n4 * 4 + threadIdx.x; f < rows * 45; f += 256) {
-                    const int g = f / 45, k = f - g * 45;
-                    if (row_visible(g)) s_sh[g * K9_ROW + 3 + k] = rest[f];
-                }
-            }
-        }
-        __syncthreads();
-        my_row = &s_sh[threadIdx.x * K9_ROW];
-    }
-
     // ---- part 2: colour, view2gaussian, footprint, the record ----
     if (vis) {
         SplatRec r;
         uint32_t cb = 0;
         if (colors_precomp == nullptr) {
             const V3 campos = { cam.campos[0], cam.campos[1], cam.campos[2] };
-            V3 rgb;
-            if (TILED) {
-                rgb = sh_to_rgb(D, p_orig, campos, my_row, my_row, cb);
-            } else {
-                const float* sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
-                const float* shp = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
-                rgb = sh_to_rgb(D, p_orig, campos, sh0, shp, cb);
-            }
+            const float* sh0 = shs_rest ? shs + (size_t)idx * 3 : shs + (size_t)idx * M * 3;
+            const float* shp = shs_rest ? shs_rest + (size_t)idx * (M - 1) * 3 - 3 : sh0;
+            const V3 rgb = sh_to_rgb(D, p_orig, campos, sh0, shp, cb);
             r.f[REC_RGB] = rgb.x; r.f[REC_RGB + 1] = rgb.y; r.f[REC_RGB + 2] = rgb.z;
         } else {
             r.f[REC_RGB] = colors_precomp[3 * (size_t)idx]; r.f[REC_RGB + 1] = colors_precomp[3 * (size_t)idx + 1]; r.f[REC_RGB + 2] = colors_precomp[3 * (size_t)idx + 2];
@@ -429,13 +384,13 @@ preprocess_fwd(int P, int D, int M,
         clamped[idx] = (uint8_t)cb;
 
         float4 box = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);     // unbounded unless proven otherwise
-        float4 fc[2] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, -1e30f) };
+        float4 fc[2] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, -1e30f) };     // (all-zero conic: never culls, whatever q)
         if (v2g_precomp == nullptr) {
             V2GInter I;
             v2g_intermediates(scale, p_orig, rot, cam.view, I);
             const V3 t2 = I.t2;
             const double C = (double)(t2.x * t2.x) * I.Sx + (double)(t2.y * t2.y) * I.Sy + (double)(t2.z * t2.z) * I.Sz;
-            box = footprint_bbox(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H, fc,      // (s_c^2 + 1e-7: the doubles v2g_intermediates divides by)
+            box = footprint_bbox<FOOT != 0>(I, p_view, opacities[idx] * coef, focal_x, focal_y, W, H, fc,      // (s_c^2 + 1e-7: the doubles v2g_intermediates divides by)
                                  (double)scale.x * scale.x + 1e-7, (double)scale.y * scale.y + 1e-7, (double)scale.z * scale.z + 1e-7);
             const V3 B = mul(t2, I.SR);
             const M3 Sigma = mul(transpose(I.Rt), I.SR);
@@ -489,16 +444,16 @@ preprocess_fwd(int P, int D, int M,
 template __global__ void preprocess_fwd<0, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
                                               float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
+template __global__ void preprocess_fwd<0, 1>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
+                                              const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
+                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 template __global__ void preprocess_fwd<1, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
                                               float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 template __global__ void preprocess_fwd<2, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
                                               float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
-template __global__ void preprocess_fwd<0, 1>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
-                                              const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
-                                              float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
-template __global__ void preprocess_fwd<0, 2>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
+template __global__ void preprocess_fwd<2, 1>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,
                                               float4*, float4*, float4*, uint32_t*, uint2*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 

@@ -180,15 +180,10 @@ static hipError_t device_scan_impl(const uint32_t* in, const uint32_t* idx, uint
 #undef GOF_SCAN_APPLY
     return hipGetLastError();
 }
-hipError_t device_scan_u32_to_host(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
-                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host)
-{
-    return device_scan_impl(in, idx, out, n, inclusive, tmp, total_dev_out, stream, total_host, nullptr, 0);
-}
 hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
                            const uint32_t** total_dev_out, hipStream_t stream)
 {
-    return device_scan_u32_to_host(in, idx, out, n, inclusive, tmp, total_dev_out, stream, nullptr);
+    return device_scan_impl(in, idx, out, n, inclusive, tmp, total_dev_out, stream, nullptr, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ class GofRasterArgs(C.Structure):
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
         ("view2gaussian_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p), ("shs_rest", C.c_void_p),
+        ("forward_exact", C.c_int32), ("tight_tile_rects", C.c_int32), ("integrate_pixel_pass", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -50,7 +51,7 @@ def _load():
         f = getattr(lib, name)
         f.restype = sz
         f.argtypes = args
-    lib.gof_forward_prepare.argtypes = [A, vp, sz, vp, sz, vp, C.POINTER(u32), vp]
+    lib.gof_forward_prepare.argtypes = lib.gof_integrate_prepare.argtypes = [A, vp, sz, vp, sz, vp, C.POINTER(u32), vp]
     lib.gof_forward_render.argtypes = [A, u32, vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.gof_forward_fused.argtypes = [A, u32, vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, vp]
     lib.gof_forward_fused.restype = C.c_int
@@ -85,7 +86,7 @@ def _load():
     lib.gof_set_forward_exact.restype = lib.gof_set_tight_tile_rects.restype = lib.gof_set_integrate_pixel_pass.restype = C.c_int
     lib.gof_profile_enable.argtypes = [C.c_int]
     lib.gof_profile_report.argtypes = [C.c_char_p, sz]
-    for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
+    for name in ("gof_profile_enable", "gof_profile_report", "gof_forward_prepare", "gof_integrate_prepare", "gof_forward_render", "gof_backward", "gof_integrate_prepare_points",
                  "gof_integrate_run", "gof_integrate_view", "gof_integrate_points", "gof_integrate_points_packed", "gof_integrate_points_min", "gof_integrate_pack_geom", "gof_mark_visible", "gof_mtets_classify", "gof_mtets_count", "gof_mtets_emit"):
         getattr(lib, name).restype = C.c_int
     return lib
@@ -133,6 +134,35 @@ def _dev_f32(t, device, what):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_call_modes = threading.local()
+
+
+class call_modes:
+    """``with call_modes(forward_exact=True): ...`` -- the modes of the rasterizer calls made by THIS thread inside the block, handed
+    to the library per call (GofRasterArgs.forward_exact / tight_tile_rects / integrate_pixel_pass, ABI 12): None = the process-wide
+    default (set_forward_exact & co. below), True / False = on / off for these calls whatever the default.  Nothing process-wide
+    changes: other threads, and other streams of this thread, keep their own modes.  Blocks nest; an inner None keeps the outer value."""
+
+    def __init__(self, forward_exact=None, tight_tile_rects=None, integrate_pixel_pass=None):
+        self.want = {"forward_exact": forward_exact, "tight_tile_rects": tight_tile_rects, "integrate_pixel_pass": integrate_pixel_pass}
+
+    def __enter__(self):
+        self.prev = getattr(_call_modes, "value", None)
+        cur = dict(self.prev or {})
+        cur.update({k: v for k, v in self.want.items() if v is not None})
+        _call_modes.value = cur
+        return self
+
+    def __exit__(self, *exc):
+        _call_modes.value = self.prev
+        return False
+
+
+def _mode_field(name):
+    v = (getattr(_call_modes, "value", None) or {}).get(name)
+    return 0 if v is None else (1 if v else -1)
 
 
 class _View:
@@ -188,6 +218,7 @@ class _View:
         a.viewmatrix = _ptr(k["view"]); a.projmatrix = _ptr(k["proj"]); a.campos = _ptr(k["campos"])
         a.subpixel_offset = _ptr(k["subpix"])
         a.shs_rest = _ptr(k["sh_rest"]) if k["sh_rest"] is not None else None
+        a.forward_exact, a.tight_tile_rects, a.integrate_pixel_pass = _mode_field("forward_exact"), _mode_field("tight_tile_rects"), _mode_field("integrate_pixel_pass")
 
     def ref(self):
         return C.byref(self.args)
@@ -196,13 +227,14 @@ class _View:
         return torch.empty(int(n), dtype=torch.uint8, device=self.device)
 
 
-def _prepare_and_bin(v):
-    """Stage 1 shared by forward and integrate: preprocess + scan + instance count."""
+def _prepare_and_bin(v, for_query=False):
+    """Stage 1 shared by forward and integrate: preprocess + scan + instance count.  for_query: the footprints complete (pixel box,
+    front depth: gof_integrate_prepare), which only the opacity-field query reads."""
     geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
     img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
     radii = torch.empty(v.P, dtype=torch.int32, device=v.device)       # preprocess_fwd writes every element (0 for culled Gaussians)
     n = C.c_uint32(0)
-    _check(lib.gof_forward_prepare(v.ref(), _ptr(geom), geom.numel(), _ptr(img), img.numel(), _ptr(radii), C.byref(n), _stream()))
+    _check((lib.gof_integrate_prepare if for_query else lib.gof_forward_prepare)(v.ref(), _ptr(geom), geom.numel(), _ptr(img), img.numel(), _ptr(radii), C.byref(n), _stream()))
     rendered = int(n.value)
     binning = v.bytes_tensor(lib.gof_binning_bytes(rendered, v.W, v.H))
     return geom, img, binning, radii, rendered
@@ -217,7 +249,31 @@ _mask_need = {}         # (device, P, W, H) -> most contributor-mask sub-chunks 
 _staged_need = {}       # (device, P, W, H) -> most tile-list entries a backward of this shape has staged (= partial gradient records written)
 USAGE_WORDS = 66        # GOF_USAGE_WORDS (include/gof_hip.h)
 _stats = {"fused_redone_frames": 0, "last_num_rendered": 0, "mask_pool_redone_frames": 0, "record_pool_redone_backwards": 0,
-          "backward_queries": 0}      # bench.py reads these (no effect on the path)
+          "backward_queries": 0, "two_stage_frames": 0, "inherited_shapes": 0, "forwards": 0, "backwards": 0}      # bench.py reads these (no effect on the path)
+_recent_P = {}          # (device, W, H) -> P of the latest frame at that resolution
+
+
+def _inherit_learnt(shape_key):
+    """Training changes P at every densification (train.py:258-264, every 100 iterations): a shape never seen before would run the
+    two-stage forward (a host read-back mid-frame) and a synchronising backward query, and would learn its pools from scratch over the
+    next views.  A new P at a resolution whose previous frames had between half and twice as many Gaussians INHERITS what those
+    frames learnt -- instance capacity, mask sub-chunks, staged records -- scaled by the growth (never down: a capacity above the
+    count costs nothing); the pools are verified per frame as ever, so a guess that turns out too small costs one
+    redone frame.  The old shape's entries are dropped (P changes for good in training; the dicts stay bounded)."""
+    dev, P, W, H = shape_key
+    prev = _recent_P.get((dev, W, H))
+    _recent_P[(dev, W, H)] = P
+    if prev is None or prev == P or shape_key in _capacity:
+        return
+    old = (dev, prev, W, H)
+    if old not in _capacity or not (0.5 * prev <= P <= 2.0 * prev):
+        return
+    grow = max(1.0, P / float(prev))
+    _capacity[shape_key] = (int(_capacity.pop(old) * grow) + 0xFFFF) & ~0xFFFF
+    for d in (_mask_need, _staged_need):
+        if old in d:
+            d[shape_key] = int(d.pop(old) * grow) + 1
+    _stats["inherited_shapes"] += 1
 
 
 class MaskPoolTooSmall(RuntimeError):
@@ -246,7 +302,7 @@ def _mask_pool_subchunks(shape_key):
     or switched off -> the worst case)"""
     need = None if FULL_MASK_POOL else _mask_need.get(shape_key)
     return None if need is None else int(need * 1.25) + 256
-_pinned = {}            # device -> pinned host word for the asynchronous instance-count read-back
+_pinned = threading.local()      # .by_device: device -> pinned host word for the asynchronous instance-count read-back (per thread)
 
 
 def _round_capacity(n):
@@ -310,6 +366,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             empty = v.bytes_tensor(0)
             return 0, out_color, torch.zeros(0, dtype=torch.int32, device=v.device), empty, empty.clone(), empty.clone()
         shape_key = (str(v.device), v.P, v.W, v.H)
+        _stats["forwards"] += 1
+        if use_fused and not prefiltered and not debug:
+            _inherit_learnt(shape_key)
         cap = _capacity.get(shape_key) if (use_fused and not prefiltered and not debug) else None
         if cap is not None:
             geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
@@ -317,9 +376,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             sub = _mask_pool_subchunks(shape_key)
             binning = v.bytes_tensor(lib.gof_binning_bytes(cap, v.W, v.H) if sub is None else lib.gof_binning_bytes_for(cap, v.W, v.H, sub))
             radii = torch.empty(v.P, dtype=torch.int32, device=v.device)
-            pin = _pinned.get(str(v.device))
+            # one pinned count word per (thread, device): ctypes releases the GIL for the call, and the library writes / waits for / reads
+            # this word inside it -- two threads rendering on the same device must not share it
+            pins = getattr(_pinned, "by_device", None)
+            if pins is None:
+                pins = _pinned.by_device = {}
+            pin = pins.get(str(v.device))
             if pin is None:
-                pin = _pinned[str(v.device)] = torch.zeros(4, dtype=torch.int32).pin_memory()
+                pin = pins[str(v.device)] = torch.zeros(4, dtype=torch.int32).pin_memory()
             # the frame's pool counters go to pinned host memory at the end of the forward (stored by its last kernel: no copy launch),
             # an event behind the call tells the backward when they are there (optimistic pools, rasterize_gaussians_backward)
             no_counters = FULL_MASK_POOL and FULL_BACKWARD_SCRATCH
@@ -344,6 +408,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _usage_free.append(words)
             del geom, img, binning, radii, usage                                     # too small: redo the frame below with the exact count
         geom, img, binning, radii, rendered = _prepare_and_bin(v)
+        _stats["two_stage_frames"] += 1               # (a host read-back in the middle of the frame, as the reference: rasterizer_impl.cu:336)
         _check(lib.gof_forward_render(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                       _ptr(img), img.numel(), _ptr(out_color), _stream()))
         if use_fused and not prefiltered and not debug:
@@ -394,6 +459,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     g_cov3D = torch.empty((P, 6), **f) if want_cov3D else _zero_scalar(dev).expand(P, 6)
     if P != 0:
         dl = _dev_f32(dL_dout_color, dev, "dL_dout_color")
+        _stats["backwards"] += 1
         with torch.cuda.device(dev):
             # Pools (round 4).  The record pool of the scratch needs as many records as the forward staged entries (~30 % of R at S1M);
             # the frame's mask pool (in binningBuffer) was sized from earlier frames.  Both numbers are on their way to pinned host
@@ -660,7 +726,7 @@ def integrate_gaussians_to_points(background, points3D, means3D, colors, opacity
         entry = _view_cache.get(key) if key is not None else None
         points_fn = lib.gof_integrate_points
         if entry is None:
-            geom, img, binning, radii, rendered = _prepare_and_bin(v)
+            geom, img, binning, radii, rendered = _prepare_and_bin(v, for_query=True)
             base = out_color
             _check(lib.gof_integrate_view(v.ref(), rendered, _ptr(radii), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                           _ptr(img), img.numel(), _ptr(base), _stream()))
@@ -734,8 +800,8 @@ def debug_fetch(name, view, num_rendered, geom, binning, img):
 
 def set_forward_exact(on):
     """Verification mode of the forward blend (gof_set_forward_exact, include/gof_hip.h): True = every (pixel, Gaussian) pair in the
-    reference's own arithmetic (every output bit the oracle's); False (default) = the same arithmetic without its two fp64 divisions per pair (pair_nodiv_cc: decisions and channels 0-7 identical on every scene tested).  Process-wide;
-    returns the previous setting."""
+    reference's own arithmetic (every output bit the oracle's); False (default) = the same arithmetic without its two fp64 divisions per pair (pair_nodiv_cc: decisions and channels 0-7 identical on every scene tested).  The process-wide
+    DEFAULT (calls inside a `call_modes(forward_exact=...)` block carry their own mode); returns the previous setting."""
     return bool(lib.gof_set_forward_exact(1 if on else 0))
 
 

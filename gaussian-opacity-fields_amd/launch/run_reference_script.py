@@ -149,6 +149,18 @@ def main():
             if shim not in sys.path:
                 sys.path.append(shim)
     import diff_gaussian_rasterization  # noqa: F401  fail early and loudly if libgof_hip.so is missing
+    if os.environ.get("GOF_STATS_JSON"):
+        # the binding's counters of the whole run (frames redone for a pool / capacity learnt too small, read-backs, shapes that inherited
+        # their pools across a densification: _backend._stats) written at exit -- evidence runs read them (tests/devtools/dev_r6_trajectory.py)
+        import atexit
+        import json
+
+        def _dump_stats(path=os.environ["GOF_STATS_JSON"]):
+            st = getattr(getattr(diff_gaussian_rasterization, "_C", None), "_stats", None)
+            if st is not None:
+                with open(path, "w") as f:
+                    json.dump(st, f)
+        atexit.register(_dump_stats)
     try:
         import utils.tetmesh as ref_tetmesh
         import tetmesh as hip_tetmesh

@@ -74,14 +74,22 @@ typedef struct GofRasterArgs {
                                            them (scene/gaussian_model.py:351-352) -- `shs` = _features_dc [P,1,3], `shs_rest` =
                                            _features_rest [P,M-1,3] -- so that the caller need not concatenate 192 B per Gaussian
                                            (GaussianModel.get_features, gaussian_model.py:173-176) every iteration.  M == 16 only. */
+    /* PER-CALL modes (ABI 12).  0 = the process-wide default (gof_set_forward_exact / gof_set_tight_tile_rects /
+     * gof_set_integrate_pixel_pass below: what a zero-initialised struct has always meant), > 0 = on for this call, < 0 = off for this
+     * call.  The library keeps no state between calls (rasterize_points.cu:36-58 is stateless too): two threads, or two streams of one
+     * thread, may run different modes side by side. */
+    int32_t forward_exact;              /* the forward blend's verification mode (gof_set_forward_exact)                          */
+    int32_t tight_tile_rects;           /* tile rectangles intersected with the footprint box (gof_set_tight_tile_rects)          */
+    int32_t integrate_pixel_pass;       /* the opacity-field query's pixel pass in its pixel-centric form (gof_set_integrate_pixel_pass) */
+    int32_t reserved0;                  /* 0 */
 } GofRasterArgs;
 
 /* ---- error text ----------------------------------------------------------------------- */
 const char* gof_last_error(void);
 /* library / ABI version, bumped when a signature or workspace layout changes */
 int gof_abi_version(void);
-/* Verification mode of the forward blend (process-wide; returns the previous setting; initial value: 1 if the environment variable
- * GOF_FW_EXACT=1 is set when the library is loaded, else 0).
+/* Verification mode of the forward blend: the process-wide DEFAULT that calls with args->forward_exact == 0 use (returns the previous
+ * setting; initial value: 1 if the environment variable GOF_FW_EXACT=1 is set when the library is loaded, else 0).
  *   0 (default): the arithmetic of the reference's renderCUDA (forward.cu:504-557) WITHOUT its two fp64 divisions per (pixel,
  *      Gaussian) pair: the quotient BB / AA comes from the fp32 reciprocal corrected twice in fp64 (faithfully rounded; everything
  *      behind it -- t, min_value, alpha, T, every threshold decision -- is evaluated as in mode 1), the mapped depth in fp32.
@@ -89,15 +97,16 @@ int gof_abi_version(void);
  *      in ~1e7 may differ: csrc/gof_common.h, pair_nodiv_cc); distortion channel within a few 1e-7.
  *   1: every pair in the reference's arithmetic as written (fp64 where forward.cu widens to double): every output bit is the oracle's. */
 int gof_set_forward_exact(int on);
-/* Tile lists (process-wide; returns the previous setting; initial value from the environment variable GOF_TIGHT_RECTS=1).
+/* Tile lists: the process-wide default for calls with args->tight_tile_rects == 0 (returns the previous setting; initial value from
+ * the environment variable GOF_TIGHT_RECTS=1).
  *   0 (default): a Gaussian is binned into every tile of the square of its 3-sigma radius, as getRect does (auxiliary.h:64-74):
  *      tiles_touched, the sorted lists and the ranges are the reference's entry for entry.
  *   1: that rectangle intersected with the conservative pixel box of the Gaussian's alpha >= 1/255 footprint -- tiles it cannot reach
  *      are dropped (R -21 % at 1M Gaussians @ 1600x1063).  Image, final_T, radii, the opacity-field query: unchanged bit for bit;
  *      gradients equal up to the summation order of the per-Gaussian gather; the intermediate lists are no longer the reference's. */
 int gof_set_tight_tile_rects(int on);
-/* Pixel pass of the opacity-field query, integrateCUDA's first half (forward.cu:886-993) (process-wide; returns the previous setting;
- * initial value from the environment variable GOF_INT_PIXELS=1).
+/* Pixel pass of the opacity-field query, integrateCUDA's first half (forward.cu:886-993): the process-wide default for calls with
+ * args->integrate_pixel_pass == 0 (returns the previous setting; initial value from the environment variable GOF_INT_PIXELS=1).
  *   0 (default, round 5): ray-centric -- the centre and corner sub-rays of neighbouring pixels that are the same ray bit for bit
  *      (pixf +- 0.5f is exact) are evaluated once per tile: 545 rays where thread = pixel evaluates 1280; tiles in which a pixel
  *      meets the 1024-contributor cap (forward.cu:986-990) are rendered by the pixel-centric kernel behind it.
@@ -139,6 +148,17 @@ int gof_forward_prepare(const GofRasterArgs* args,
                         int32_t* radii,
                         uint32_t* num_rendered_host,
                         void* stream);
+/* The same stage in front of the opacity-field query (gof_integrate_view / gof_integrate_run; rasterizer_impl.cu:530-700 runs the same
+ * preprocessCUDA there): same arguments, same outputs, and the per-Gaussian footprints COMPLETE -- besides the ray-space conic the forward
+ * blend culls with, the conservative pixel box and the front depth the query's pixel and point passes prefilter with (ABI 12: since round 6
+ * gof_forward_prepare / gof_forward_fused leave those two at "no statement", which costs a training forward ~40 % fewer fp64
+ * instructions per Gaussian; a query run on a workspace of theirs is still exact, only slower). */
+int gof_integrate_prepare(const GofRasterArgs* args,
+                          void* geom_ws, size_t geom_bytes,
+                          void* image_ws, size_t image_bytes,
+                          int32_t* radii,
+                          uint32_t* num_rendered_host,
+                          void* stream);
 /* Stage 2: duplicateWithKeys + stable radix sort + identifyTileRanges + forward blend
  * (rasterizer_impl.cu:344-402, forward.cu:409-612).  out_color is [9,H,W]; every pixel of
  * every channel is written.  geom_ws must be the one gof_forward_prepare of THIS frame filled; image_ws need only be large

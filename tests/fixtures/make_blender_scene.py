@@ -40,6 +40,59 @@ def ground_truth(seed=0, n=3000, scale=0.035):
                 rotations=q.astype(np.float32), opacities=np.full((n, 1), 0.95, np.float32))
 
 
+def ground_truth_large(seed=0, n=250_000, scale=0.009):
+    """The structured scene of the config-3-shaped evidence run (tests/devtools/dev_r6_trajectory.py): a dozen ellipsoid shells of
+    different sizes, a tilted ground disc and three thin rods, every surface carrying a high-frequency colour pattern (stripes and
+    checks of 0.04-0.1 units: sub-splat detail at 800x800 that the optimiser can only fit by densifying), drawn with `n` small
+    anisotropic Gaussians.  Same dictionary as ground_truth()."""
+    rng = np.random.default_rng(seed)
+    ne = 12
+    centres = rng.uniform(-0.85, 0.85, (ne, 3)) * np.array([1.0, 0.6, 1.0])
+    centres[0] = 0.0
+    radii = rng.uniform(0.12, 0.34, (ne, 3))
+    radii[0] = [0.5, 0.38, 0.42]
+    base = rng.uniform(0.15, 0.95, (ne, 3))
+    share = np.concatenate([np.prod(radii, 1) ** (2.0 / 3.0), [0.9, 0.12, 0.12, 0.12]])      # ~ surface area; disc; rods
+    which = rng.choice(ne + 4, n, p=share / share.sum())
+    means = np.empty((n, 3)); colors = np.empty((n, 3)); nrm = np.empty((n, 3))
+    for k in range(ne):
+        m = which == k
+        d = rng.normal(size=(m.sum(), 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        means[m] = centres[k] + d * radii[k] * rng.uniform(0.97, 1.0, (m.sum(), 1))
+        nrm[m] = d
+        stripes = 0.5 + 0.5 * np.sign(np.sin((25.0 + 6.0 * k) * d[:, 1]) * np.sin((18.0 + 5.0 * k) * np.arctan2(d[:, 0], d[:, 2])))
+        colors[m] = base[k] * (0.35 + 0.65 * stripes[:, None]) + 0.15 * d
+    m = which == ne                                   # ground disc y = 0.62 (y is down in the camera convention of look_at_pose), radius 1.25
+    r = 1.25 * np.sqrt(rng.uniform(0, 1, m.sum())); a = rng.uniform(0, 2 * math.pi, m.sum())
+    means[m] = np.stack([r * np.cos(a), 0.62 + 0.08 * np.sin(3.0 * r * np.cos(a)), r * np.sin(a)], 1)
+    nrm[m] = [0.0, -1.0, 0.0]
+    check = (np.floor(means[m][:, 0] / 0.09) + np.floor(means[m][:, 2] / 0.09)) % 2
+    colors[m] = np.where(check[:, None] > 0, [0.85, 0.85, 0.8], [0.15, 0.2, 0.3])
+    for j in range(3):                                # rods
+        m = which == ne + 1 + j
+        t = rng.uniform(-1.0, 1.0, m.sum()); a = rng.uniform(0, 2 * math.pi, m.sum())
+        axis = np.eye(3)[j]; u = np.eye(3)[(j + 1) % 3]; v = np.eye(3)[(j + 2) % 3]
+        off = np.array([0.45, -0.35, -0.5])[j] * u + np.array([-0.4, 0.5, 0.3])[j] * v
+        means[m] = t[:, None] * axis + off + 0.035 * (np.cos(a)[:, None] * u + np.sin(a)[:, None] * v)
+        nrm[m] = np.cos(a)[:, None] * u + np.sin(a)[:, None] * v
+        colors[m] = np.where((np.floor(t / 0.06) % 2)[:, None] > 0, np.eye(3)[j] * 0.9 + 0.05, [0.9, 0.9, 0.9])
+    colors = np.clip(colors + rng.normal(0, 0.02, (n, 3)), 0.02, 0.98)
+    # flat splats lying in the surface: two tangent axes of `scale`, the normal axis a fifth of it; rotation = [t1, t2, normal]
+    t1 = np.cross(nrm, rng.normal(size=(n, 3))); t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(nrm, t1)
+    Rm = np.stack([t1, t2, nrm], 2)
+    q = np.empty((n, 4))
+    tr = Rm[:, 0, 0] + Rm[:, 1, 1] + Rm[:, 2, 2]
+    q[:, 0] = 0.5 * np.sqrt(np.maximum(1e-12, 1.0 + tr))
+    q[:, 1] = (Rm[:, 2, 1] - Rm[:, 1, 2]) / (4.0 * q[:, 0]); q[:, 2] = (Rm[:, 0, 2] - Rm[:, 2, 0]) / (4.0 * q[:, 0]); q[:, 3] = (Rm[:, 1, 0] - Rm[:, 0, 1]) / (4.0 * q[:, 0])
+    bad = tr < -0.9                                   # (half-turns: the formula above loses its digits; any unit quaternion draws a valid splat)
+    q[bad] = rng.normal(size=(bad.sum(), 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    scales = np.exp(rng.normal(math.log(scale), 0.25, (n, 3))) * np.array([1.0, 1.0, 0.2])
+    return dict(means3D=means.astype(np.float32), colors=colors.astype(np.float32), scales=scales.astype(np.float32),
+                rotations=q.astype(np.float32), opacities=np.full((n, 1), 0.95, np.float32))
+
+
 def look_at_pose(theta, phi, radius=4.0):
     """(R_c2w in the reference's camera convention: x right, y down, z forward; camera centre)."""
     c = radius * np.array([math.cos(phi) * math.sin(theta), -math.sin(phi), math.cos(phi) * math.cos(theta)])
@@ -70,12 +123,12 @@ def render_view(gt, R_c2w, centre, W, H, bg, device="cuda:0"):
     return color[:3].clamp(0, 1).permute(1, 2, 0).cpu().numpy()
 
 
-def make_scene(out_dir, n_train=24, n_test=4, W=160, H=120, seed=0, n_init=6000, white_background=False, n_gt=3000, gt_scale=0.035):
+def make_scene(out_dir, n_train=24, n_test=4, W=160, H=120, seed=0, n_init=6000, white_background=False, n_gt=3000, gt_scale=0.035, large=False):
     from PIL import Image
     from plyfile import PlyData, PlyElement
     os.makedirs(os.path.join(out_dir, "train"), exist_ok=True)
     os.makedirs(os.path.join(out_dir, "test"), exist_ok=True)
-    gt = ground_truth(seed, n_gt, gt_scale)
+    gt = ground_truth_large(seed, n_gt, gt_scale) if large else ground_truth(seed, n_gt, gt_scale)
     rng = np.random.default_rng(seed + 1)
     bg = (1.0, 1.0, 1.0) if white_background else (0.0, 0.0, 0.0)
     for split, n in (("train", n_train), ("test", n_test)):
@@ -111,6 +164,8 @@ if __name__ == "__main__":
     ap.add_argument("--gt", type=int, default=3000, help="ground-truth Gaussians the images are rendered from")
     ap.add_argument("--gt-scale", type=float, default=0.035)
     ap.add_argument("--init", type=int, default=6000, help="points of the initial cloud (points3d.ply)")
+    ap.add_argument("--test-views", type=int, default=4)
+    ap.add_argument("--large", action="store_true", help="the structured ground truth of the config-3-shaped evidence run (ground_truth_large)")
     a = ap.parse_args()
-    make_scene(a.out, n_train=a.views, W=a.size[0], H=a.size[1], n_gt=a.gt, gt_scale=a.gt_scale, n_init=a.init)
+    make_scene(a.out, n_train=a.views, n_test=a.test_views, W=a.size[0], H=a.size[1], n_gt=a.gt, gt_scale=a.gt_scale, n_init=a.init, large=a.large)
     print("wrote", a.out)

@@ -30,8 +30,10 @@ def settings_from(sd, debug=False, prefiltered=False):
 
 
 class forward_exact:
-    """with forward_exact(): ... -- the forward blend's verification mode (gof_set_forward_exact: every pair in the reference's own
-    arithmetic, every output bit the oracle's) for the calls inside; the previous mode is restored."""
+    """with forward_exact(): ... -- the forward blend's verification mode (every pair in the reference's own arithmetic, every output
+    bit the oracle's) for the calls THIS THREAD makes inside the block: a per-call mode (GofRasterArgs.forward_exact, ABI 12;
+    _backend.call_modes), nothing process-wide.  With `lib` (a second library instance: the audit / variant builds, or the host
+    emulation, whose bindings build their own argument structs) the process-wide default of THAT library is switched and restored."""
 
     def __init__(self, on=True, lib=None):
         self.on, self.lib = on, lib
@@ -39,11 +41,16 @@ class forward_exact:
     def __enter__(self):
         if self.lib is None:
             from diff_gaussian_rasterization import _backend as B
-            self.lib = B.lib
-        self.prev = self.lib.gof_set_forward_exact(1 if self.on else 0)
+            self.ctx = B.call_modes(forward_exact=bool(self.on))
+            self.ctx.__enter__()
+        else:
+            self.prev = self.lib.gof_set_forward_exact(1 if self.on else 0)
 
     def __exit__(self, *exc):
-        self.lib.gof_set_forward_exact(self.prev)
+        if self.lib is None:
+            self.ctx.__exit__(*exc)
+        else:
+            self.lib.gof_set_forward_exact(self.prev)
 
 
 # The forward blend's default mode (the reference's arithmetic without its two fp64 divisions per pair: csrc/gof_common.h,

@@ -179,7 +179,7 @@ class EmuScene:
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
-        self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
+        self._check(lib.gof_integrate_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
         self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
         base = np.zeros((9, self.H, self.W), np.float32)
@@ -229,7 +229,7 @@ class EmuScene:
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
-        self._check(lib.gof_forward_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
+        self._check(lib.gof_integrate_prepare(C.byref(self.args), _p(self.geom), self.geom.size, _p(self.img), self.img.size, _p(self.radii), C.byref(n), None))
         self.R = int(n.value)
         self.binning = _aligned(lib.gof_binning_bytes(self.R, self.W, self.H), what="binning")
         self.base = np.zeros((9, self.H, self.W), np.float32)

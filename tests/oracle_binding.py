@@ -22,7 +22,8 @@ class GofRasterArgs(C.Structure):
         ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
         ("view2gaussian_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
-        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p), ("shs_rest", C.c_void_p),   # shs_rest: product only, NULL here
+        ("campos", C.c_void_p), ("subpixel_offset", C.c_void_p), ("shs_rest", C.c_void_p),
+        ("forward_exact", C.c_int32), ("tight_tile_rects", C.c_int32), ("integrate_pixel_pass", C.c_int32), ("reserved0", C.c_int32),   # shs_rest and the per-call modes: product only, NULL / 0 here
     ]
 
 

@@ -63,7 +63,7 @@ def test_struct_layout_matches_header():
         fields.extend(n.strip() for n in names[1:])
     assert [f[0] for f in B.GofRasterArgs._fields_] == fields
     assert [f[0] for f in ob.GofRasterArgs._fields_] == fields
-    assert ctypes.sizeof(B.GofRasterArgs) == ctypes.sizeof(ob.GofRasterArgs) == 11 * 4 + 4 + 14 * 8
+    assert ctypes.sizeof(B.GofRasterArgs) == ctypes.sizeof(ob.GofRasterArgs) == 11 * 4 + 4 + 14 * 8 + 4 * 4
 
 
 def test_train_epilogue_struct_and_host_queries():

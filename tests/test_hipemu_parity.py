@@ -570,36 +570,3 @@ def test_emulated_capacity_far_above_the_count_in_the_histogram_scan_scatter_sor
         assert np.array_equal(f.fetch("point_list")[:R], list_two_stage) and np.array_equal(f.fetch("ranges"), ranges)
 
 
-@pytest.mark.parametrize("env", [{"GOF_FUSED_SCAN": "0"}, {"GOF_EMIT_HIST0": "0", "GOF_K1_ZERO": "0"}, {"GOF_K1_SPLIT": "2"}, {"GOF_K1_SPLIT": "0"}])
-def test_emulated_developer_switches_of_the_binning_chain_change_no_output(env, tmp_path):
-    """The environment switches behind the A/B tables of round 5's second session select launches, never results: the
-    three-launch scan, the tile sort's own first histogram + the memset in front of the depth sort, the binning chain on the library's
-    stream, the one-kernel per-Gaussian stage.  A switch is read once per loaded library: each case loads its own copy."""
-    import shutil
-    from diff_gaussian_rasterization import _backend as B
-    src = build_emu.build()
-    dst = str(tmp_path / ("libgof_hip_emu_" + "_".join("%s%s" % kv for kv in sorted(env.items())) + ".so"))
-    shutil.copy(src, dst)
-    keep_env = {k: os.environ.get(k) for k in env}
-    keep_path = B.LIB_PATH
-    try:
-        os.environ.update(env)
-        B.LIB_PATH = dst
-        lib = B._load()
-        for name in ("small_ks01", "posed_clustered150k"):          # (the second one: 2.7 M instances, the tile sort as histogram / scan / scatter)
-            sc = TP.SCENES[name]()
-            d = E.EmuScene(sc); cd, rd = d.forward()
-            v = E.EmuScene(sc, lib=lib); cv, rv = v.forward()
-            assert v.R == d.R and np.array_equal(rv, rd) and np.array_equal(bits(cv), bits(cd))
-            for arr in TP.INT_ARRAYS:
-                assert TP._same(v.fetch(arr), d.fetch(arr)), arr
-            f = E.EmuScene(sc, lib=lib)
-            rc, count, intact = f.forward_fused(int(1.3 * d.R) + 11)
-            assert rc == 0 and count == d.R and intact and np.array_equal(bits(f.color), bits(cd))
-    finally:
-        B.LIB_PATH = keep_path
-        for k, val in keep_env.items():
-            if val is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = val

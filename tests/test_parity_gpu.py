@@ -533,8 +533,9 @@ def uint16_scene_below_the_cap():
 
 
 class integrate_pixel_pass:
-    """with integrate_pixel_pass(1): ... -- the opacity-field query's pixel pass in its pixel-centric form (gof_set_integrate_pixel_pass,
-    include/gof_hip.h) for the calls inside; the previous form is restored."""
+    """with integrate_pixel_pass(1): ... -- the opacity-field query's pixel pass in its pixel-centric form for the calls this thread
+    makes inside: a per-call mode (GofRasterArgs.integrate_pixel_pass, ABI 12; _backend.call_modes), nothing process-wide.  With `lib`
+    (another library instance) that library's process-wide default is switched and restored."""
 
     def __init__(self, mode, lib=None):
         self.mode, self.lib = mode, lib
@@ -542,11 +543,16 @@ class integrate_pixel_pass:
     def __enter__(self):
         if self.lib is None:
             from diff_gaussian_rasterization import _backend as B
-            self.lib = B.lib
-        self.prev = self.lib.gof_set_integrate_pixel_pass(self.mode)
+            self.ctx = B.call_modes(integrate_pixel_pass=bool(self.mode))
+            self.ctx.__enter__()
+        else:
+            self.prev = self.lib.gof_set_integrate_pixel_pass(self.mode)
 
     def __exit__(self, *exc):
-        self.lib.gof_set_integrate_pixel_pass(self.prev)
+        if self.lib is None:
+            self.ctx.__exit__(*exc)
+        else:
+            self.lib.gof_set_integrate_pixel_pass(self.prev)
 
 
 def _integrate_outputs(sd, pts):
@@ -1002,6 +1008,43 @@ def test_full_size_s1m_against_oracle(kernel_size):
         assert_grad_close(gp[k], go[k], k)
 
 
+# the scenes of bench.py's `large_p` leg (round 5: the regime of real captures -- BASELINE configs 3-5 are multi-million-Gaussian scenes)
+LARGE_P = {
+    "bicycle_like_6M": lambda: S.scene_frustum(6_000_000, W=1237, H=822, focal=1237.0 * 0.75, seed=0, sigma_px=1.5),
+    "s5m": lambda: S.scene_frustum(5_000_000, seed=0, sigma_px=1.5),
+}
+
+
+@pytest.mark.parametrize("name", list(LARGE_P))
+def test_full_size_large_p_against_oracle(name):
+    """Forward + backward ABOVE 1M Gaussians, on exactly the scenes bench.py's `large_p` leg times (6M @ 1237x822 -- the resolution of
+    Mip-NeRF360 bicycle at images_4 --, 5M @ 1600x1063; median projected sigma 1.5 px, 18-22 M instances, tile lists of 2700-5500
+    entries of which ~490 are walked): the depth sort and the tile sort run as histogram / scan / scatter launches there (more than 512
+    radix tiles), the fused gather + scan spans ~1500 look-back tiles, preprocess_fwd / preprocess_bwd / gather_tile_partials move
+    gigabytes.  Instance count, radii, sorted list, ranges, contributor counts, transmittances and the image (verification mode)
+    bit-exact against the oracle; the blend gradients within the table's tolerances; the per-Gaussian backward on identical inputs."""
+    sc = LARGE_P[name]()
+    o, oc, orad, res = _forward_pair(sc)
+    assert res["R"] == o.num_rendered() and res["R"] > 15_000_000 and np.array_equal(res["radii"].cpu().numpy(), orad)
+    for arr in ("point_list", "ranges", "n_contrib"):
+        assert _same(fetch(res, arr), o.fetch(arr)), arr
+    assert_final_T_matches(fetch(res["exact"], "final_T"), o.fetch("final_T"), sc["W"] * sc["H"])
+    assert_image_matches(res["exact"]["color"].cpu().numpy(), oc)
+    dL = np.random.default_rng(1).normal(size=oc.shape).astype(np.float32)
+    go = o.backward(dL)
+    gp = _product_backward(res, dL)
+    for k in ("means2D", "colors", "opacity", "view2gaussian"):
+        assert_grad_close(gp[k], go[k], k)
+    assert not gp["cov3D"].any()
+    iso = o.preprocess_backward(gp["view2gaussian"], gp["colors"])
+    for k in ("means3D", "sh", "scales", "rotations"):
+        assert_k9_close(gp[k], iso[k], k)
+    inv = orad <= 0
+    assert inv.sum() > 100_000                     # (the 10 % overscan: culled Gaussians sort last and receive exact zeros)
+    for k, v in gp.items():
+        assert not v.reshape(len(orad), -1)[inv].any(), k
+
+
 def test_full_size_s1m_posed_against_oracle():
     """BASELINE config 2 at full size under a random rigid pose (pose_scene: the same 1M-Gaussian cloud seen by a posed camera --
     what a real training step renders): sorted list, contributor counts, transmittances and image bit-exact, blend gradients
@@ -1111,12 +1154,9 @@ def test_tight_tile_rectangles_change_no_output(name):
     sc = S.scene_frustum(1_000_000, seed=0) if name == "s1m" else SCENES[name]()
     sd = to_dev(sc)
     base = product_forward_raw(sd)
-    prev = B.set_tight_tile_rects(True)
-    try:
+    with B.call_modes(tight_tile_rects=True):          # a per-call mode (GofRasterArgs.tight_tile_rects): nothing process-wide changes
         tight = product_forward_raw(sd)
         torch.cuda.synchronize()
-    finally:
-        B.set_tight_tile_rects(prev)
     assert tight["R"] <= base["R"] and (name in ("small_ks01",) or tight["R"] < base["R"])
     assert torch.equal(tight["color"], base["color"]) and torch.equal(tight["radii"], base["radii"])
     assert _same(fetch(tight, "final_T"), fetch(base, "final_T"))
@@ -1130,11 +1170,8 @@ def test_tight_tile_rectangles_change_no_output(name):
         pts = torch.from_numpy(np.ascontiguousarray(S.tetra_points(sc)[:200_000], dtype=np.float32)).cuda()
         kw = dict(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
         want = GaussianRasterizer(settings_from(sd)).integrate(**kw)
-        prev = B.set_tight_tile_rects(True)
-        try:
+        with B.call_modes(tight_tile_rects=True):
             got = GaussianRasterizer(settings_from(sd)).integrate(**kw)
-        finally:
-            B.set_tight_tile_rects(prev)
         for a, b in zip(got[:3], want[:3]):
             assert torch.equal(a, b)
 
@@ -1195,3 +1232,124 @@ def test_fused_forward_at_full_size_under_a_capacity_above_the_count(over):
             B._capacity.pop(key, None)
         else:
             B._capacity[key] = keep
+
+
+def test_per_call_modes_and_the_process_wide_defaults_behind_them():
+    """ABI 12: the three modes are arguments of a call (GofRasterArgs.forward_exact / tight_tile_rects / integrate_pixel_pass: 0 = the
+    process default, > 0 on, < 0 off).  The setters of ABI 8-11 stay as the DEFAULT of calls that do not say: a call inside
+    `call_modes(forward_exact=False)` is not switched by gof_set_forward_exact(1), a call outside is; the setters' return values are the
+    previous settings."""
+    from diff_gaussian_rasterization import _backend as B
+    sc = SCENES["posed_ragged"]()
+    sd = to_dev(sc)
+    fast = product_forward_raw(sd)
+    with B.call_modes(forward_exact=True):
+        exact = product_forward_raw(sd)
+    o = ob.OracleScene(sc)
+    oc, _ = o.forward()
+    assert_image_matches(exact["color"].cpu().numpy(), oc)
+    differ = not torch.equal(fast["color"][8], exact["color"][8])          # (the modes differ in the distortion channel's last bits on this scene)
+    assert differ
+    assert B.set_forward_exact(True) is False
+    try:
+        by_default = product_forward_raw(sd)                                # no mode given: the process default, now the verification mode
+        with B.call_modes(forward_exact=False):
+            pinned_off = product_forward_raw(sd)                            # the call says off: the default does not reach it
+    finally:
+        assert B.set_forward_exact(False) is True
+    assert torch.equal(by_default["color"], exact["color"]) and torch.equal(pinned_off["color"], fast["color"])
+    assert torch.equal(product_forward_raw(sd)["color"], fast["color"])
+    # tight rectangles and the query's pixel pass: the setter-selected default equals the per-call mode
+    with B.call_modes(tight_tile_rects=True):
+        tight = product_forward_raw(sd)
+    assert B.set_tight_tile_rects(True) is False
+    try:
+        tight_default = product_forward_raw(sd)
+        with B.call_modes(tight_tile_rects=False):
+            assert product_forward_raw(sd)["R"] == fast["R"]
+    finally:
+        assert B.set_tight_tile_rects(False) is True
+    assert tight["R"] == tight_default["R"] < fast["R"] and torch.equal(tight["color"], fast["color"])
+    pts = torch.from_numpy(np.ascontiguousarray(S.tetra_points(sc)[:50_000], dtype=np.float32)).cuda()
+    rays = _integrate_outputs(sd, pts)
+    assert B.set_integrate_pixel_pass(True) is False
+    try:
+        pix = _integrate_outputs(sd, pts)
+    finally:
+        assert B.set_integrate_pixel_pass(False) is True
+    for x, y in zip(rays, pix):
+        assert np.array_equal(bits(x), bits(y))
+
+
+def _stream_job(sd, dL, pts, exact):
+    """forward + backward through the autograd surface and one opacity-field query of `sd` on the CURRENT stream; `exact`: the forward in
+    its verification mode (a per-call mode: the other stream / thread keeps its own)"""
+    from diff_gaussian_rasterization import GaussianRasterizer, _backend as B
+    leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    m2d = torch.zeros_like(leaf["means3D"], requires_grad=True)
+    r = GaussianRasterizer(settings_from(sd))
+    with B.call_modes(forward_exact=exact):
+        color, radii = r(means3D=leaf["means3D"], means2D=m2d, shs=leaf["shs"], opacities=leaf["opacities"], scales=leaf["scales"], rotations=leaf["rotations"])
+    (color * dL).sum().backward()
+    with torch.no_grad():
+        ic, ia, ip, _ = r.integrate(points3D=pts, means3D=sd["means3D"], means2D=None, opacities=sd["opacities"], shs=sd["shs"], scales=sd["scales"], rotations=sd["rotations"])
+    return [color.detach(), radii, m2d.grad] + [leaf[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")] + [ic, ia, ip]
+
+
+def test_non_default_stream_and_two_streams():
+    """Every entry point takes the caller's stream; the reference itself only ever runs on the legacy default stream
+    (forward.cu:637-657).  Forward + backward + opacity-field query of TWO different scenes, in two different forward modes, issued
+    alternately on two side streams of one thread without a synchronisation in between (five rounds: the fused forward's learnt
+    capacities, the pools, the library's second stream and its fork / join events, the per-thread pinned count word are all reused
+    across the streams), then from two Python threads at once, each on its own stream: every result bit-identical to the same job on
+    the default stream.  (What the library keeps per (thread, device) -- its second stream and events -- or per device -- the status
+    word -- is not per call; what it keeps per process -- the setters' defaults -- is not touched.)"""
+    import threading
+    host = [SCENES["posed_mid100k"](), SCENES["clustered150k"]()]
+    scenes = [to_dev(sc) for sc in host]
+    gen = torch.Generator().manual_seed(11)
+    dLs = [torch.randn((9, sd["H"], sd["W"]), generator=gen).cuda() for sd in scenes]
+    pts = [torch.from_numpy(np.ascontiguousarray(S.tetra_points(sc)[:100_000], dtype=np.float32)).cuda() for sc in host]
+    modes = [False, True]
+    want = []
+    for _ in range(2):                      # (twice: the second pass runs the sync-free forward on learnt pools, as the side streams will)
+        want = [_stream_job(scenes[i], dLs[i], pts[i], modes[i]) for i in range(2)]
+    torch.cuda.synchronize()
+
+    def same(got, ref, what):
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (what, k)
+
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    got = [[], []]
+    for _ in range(5):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                got[i].append(_stream_job(scenes[i], dLs[i], pts[i], modes[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for g in got[i]:
+            same(g, want[i], "alternating streams, scene %d" % i)
+
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(streams[i]):
+                out = [_stream_job(scenes[i], dLs[i], pts[i], modes[i]) for _ in range(4)]
+            streams[i].synchronize()
+            results[i] = out
+        except Exception as e:      # noqa: BLE001  (reported by the asserting thread)
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for g in results[i]:
+            same(g, want[i], "two threads, scene %d" % i)
