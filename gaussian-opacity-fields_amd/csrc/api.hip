@@ -55,10 +55,11 @@ hipError_t radix_sort_pairs_u32_z(uint32_t* keys_a, uint32_t* vals_a, uint32_t* 
 size_t radix_zero_words(size_t n, int end_bit);
 uint32_t* radix_classic_hist(uint32_t* tmp, size_t n, int end_bit);
 uint32_t rs_block_items();
+uint32_t rs_units(size_t n);
 int radix_passes(int end_bit);
 uint32_t emit_instances_grid(uint32_t slots, int P);
 __global__ void emit_instances(int P, const uint32_t* order, const uint32_t* order_off, const uint32_t* minxy_sorted, const uint32_t* wh_sorted,
-                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first, uint32_t* hist0);
+                               uint32_t* tiles, uint32_t* gids, uint32_t gx, uint32_t capacity, uint32_t* inst_first, uint32_t* hist0, uint32_t hist_stride);
 uint32_t emit_block_slots();
 __global__ void point_keys(int PN, const float4* pos, const uint32_t* offsets, const uint32_t* tiles_touched, uint32_t* keys, uint32_t* vals,
                            uint32_t gx, uint32_t gy);
@@ -102,6 +103,7 @@ __global__ void integrate_points(const uint2* gaussian_ranges, const uint2* poin
                                  const uint32_t* tile_order, uint32_t* tile_queue);
 __global__ void pack_view_geometry(int P, const SplatRec* rec, const float4* fconic, SplatRec* rec_out, float* zfront_out);
 uint32_t gather_scan_tiles(size_t n);
+uint32_t gather_scan_threads();
 size_t gather_scan_state_words(size_t n);
 __global__ void gather_scan_rects(uint32_t n, const uint2* rect, const uint32_t* order, const uint32_t* keys_sorted, uint32_t* minxy_sorted, uint32_t* wh_sorted,
                                   uint32_t* order_off, const uint32_t* sort_error, uint2* ranges, uint32_t ntiles, uint32_t* state, uint32_t* total_host);
@@ -382,7 +384,7 @@ static int bin_gaussians(const GofRasterArgs* a, const Dims& d, uint32_t R, cons
         { GOF_PROFILE("emit_instances", stream);
         // one wave per EMIT_SLOTS output slots (R: the instance count, or the workspace's capacity when only the device knows the count)
         hipLaunchKernelGGL(emit_instances, dim3(emit_instances_grid(R, a->P)), dim3(256), 0, stream, a->P, g.dval_a,
-                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first, hist0); }
+                           g.order_off, g.dkey_b, g.dval_b, t_in, v_in, d.gx, R, g.inst_first, hist0, n_dev ? 0u : rs_units((size_t)R)); }
         GOF_LAUNCH_CHECK(stream, dbg);
         { GOF_PROFILE("sort_instances_by_tile", stream);
         int rc = sort_by_tile(b, R, t_in, v_in, tile_bits, stream, n_dev, hist0 != nullptr);
@@ -475,8 +477,27 @@ size_t gof_point_bytes(int32_t PN) { return point_layout(PN < 0 ? 0 : PN, nullpt
 // (Measured and dropped, profiles/r05_ab_call7_binning.txt: the binning chain on a stream of the device's highest priority with
 // stage 2 on the caller's -- the priority changes nothing latency-bound launches feel.)
 namespace {
+// workgroups per CU of stage 2 of the per-Gaussian kernel beside the binning chain (preprocess.hip: the kernel strides; 0 = one workgroup
+// per 256 Gaussians, i.e. every wave slot of the device)
+// Measured, interleaved A/B (profiles/r06_ab_call2_stage2_grid.txt; ms per fwd+bwd step, unbounded / 1 / 2 workgroups per CU / no fork):
+// S1M 2.404 / 2.388 / 2.403 / 2.419, S1M-clustered 3.255 / 3.241 / 3.261 / 3.293, 6M Gaussians 4.160 / 4.181 / 4.228 / 4.181.  What precedes
+// the blend is work-conserving -- stage 2 alone + the chain alone = what the two take side by side, 0.44 ms at S1M, 1.42 ms at 6M -- so
+// the bound only decides who waits: at 1 M Gaussians one workgroup per CU lets the depth sort's 245-workgroup passes find their slots
+// (0.162 -> 0.145 ms) while stage 2 still ends long before the blend; at 6 M the bounded stage 2 (1.18 ms) becomes the critical path
+// (and half / a quarter of a workgroup per CU at S1M: stage 2 0.28 / 0.52 ms, steps 2.42 / 2.56 ms -- r06_ab_call3_*.txt).
+// Hence: bounded up to GOF_K1_HEAVY_BOUND_MAX_P Gaussians, unbounded beyond.
+#ifndef GOF_K1_HEAVY_WGS_PER_CU
+#define GOF_K1_HEAVY_WGS_PER_CU 1
+#endif
+#ifndef GOF_K1_HEAVY_BOUND_MAX_P
+#define GOF_K1_HEAVY_BOUND_MAX_P (2 << 20)
+#endif
+// 0: stage 2 is not forked (one per-Gaussian kernel in front of the binning chain) -- developer A/B builds only
+#ifndef GOF_K1_SPLIT
+#define GOF_K1_SPLIT 1
+#endif
 struct AuxStream {
-    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr, count_ready = nullptr; bool failed = false;
+    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr, count_ready = nullptr; bool failed = false; int cus = 0;
     ~AuxStream()
     {   // a caller thread that ends gives its stream and events back (thread_local storage: runs at thread exit; at process exit the
         // runtime may already be gone -- errors are swallowed)
@@ -501,6 +522,7 @@ AuxStream* aux_stream()
         if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&a.count_ready, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError(); a.failed = true; return nullptr; }
+        if (hipDeviceGetAttribute(&a.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || a.cus <= 0) { (void)hipGetLastError(); a.cus = 256; }
     }
     return &a;
 }
@@ -535,7 +557,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     // profiles/r05_ab_call4_preprocess_fwd.txt -- and removed in round 6)
     const int k1_bits = (a->prefiltered ? 1 : 0) | (mode_on(a->tight_tile_rects, g_tight_rects) ? 2 : 0);
     const bool foot = full_footprint || (k1_bits & 2);
-#define GOF_K1_LAUNCH(STAGE, FOOT, STREAM) hipLaunchKernelGGL((preprocess_fwd<STAGE, FOOT>), dim3((a->P + 255) / 256), dim3(256), 0, STREAM,                 \
+#define GOF_K1_LAUNCH(STAGE, FOOT, STREAM) hipLaunchKernelGGL((preprocess_fwd<STAGE, FOOT>), dim3(k1_grid), dim3(256), 0, STREAM,                 \
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,                          \
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,                             \
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, k1_bits,                                                                             \
@@ -552,7 +574,8 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
         k1_zero_n = (uint32_t)(sort_zero + scan_words);
     }
     // (tight tile rectangles take their tiles_touched from stage 2's footprint box: one kernel then)
-    AuxStream* const aux = (join && !(k1_bits & 2) && !a->debug) ? aux_stream() : nullptr;
+    AuxStream* const aux = (GOF_K1_SPLIT && join && !(k1_bits & 2) && !a->debug) ? aux_stream() : nullptr;
+    uint32_t k1_grid = (uint32_t)((a->P + 255) / 256);
     { GOF_PROFILE("preprocess_fwd", stream);
     if (aux) GOF_K1_LAUNCH(1, 0, stream);
     else if (foot) GOF_K1_LAUNCH(0, 1, stream);
@@ -564,6 +587,8 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
         GOF_HIP_CHECK(hipGetLastError());
         GOF_HIP_CHECK(hipEventRecord(aux->fork, stream));
         GOF_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+        if (GOF_K1_HEAVY_WGS_PER_CU > 0 && a->P <= GOF_K1_HEAVY_BOUND_MAX_P)
+            k1_grid = std::min(k1_grid, (uint32_t)(GOF_K1_HEAVY_WGS_PER_CU * aux->cus));      // bounded: the chain's workgroups find free slots
         { GOF_PROFILE("preprocess_fwd_heavy", aux->s);
           if (foot) GOF_K1_LAUNCH(2, 1, aux->s);
           else GOF_K1_LAUNCH(2, 0, aux->s); }
@@ -576,6 +601,9 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     GOF_LAUNCH_CHECK(stream, a->debug);
     // depth order of the Gaussians (4 passes over P; an even number of passes returns to the *_a buffers)
     // (the state words of the fused gather + scan behind it lie right behind the sort's scratch: the sort's own memset clears them too)
+    // (Measured and removed, round 6 -- profiles/r06_ab_call3_three_pass_depth_sort.txt: THREE passes of 9 bits under a caller's promise
+    // of depth keys below 2^27, detected and redone when broken.  Beside stage 2 the sort's time is set by the interference, not by its
+    // passes: 0.139 vs 0.137 ms at S1M, 0.620 vs 0.615 at 6 M Gaussians, step times equal to 0.1 %.)
     uint32_t* const scan_state = g.sort_tmp + rs_tmp_words((size_t)a->P);
     uint32_t *kr = nullptr, *vr = nullptr;          // where the sort leaves its keys / values (kr: read by gather_scan_rects)
     { GOF_PROFILE("sort_gaussians_by_depth", stream);
@@ -587,7 +615,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
     { GOF_PROFILE("scan_tiles", stream);
     // dkey_b / dval_b are free after the (even number of) sort passes: they take the depth-ordered rectangles; the counts are
     // scanned in place
-    hipLaunchKernelGGL(gather_scan_rects, dim3(gather_scan_tiles((size_t)a->P)), dim3(256), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b,
+    hipLaunchKernelGGL(gather_scan_rects, dim3(gather_scan_tiles((size_t)a->P)), dim3(gather_scan_threads()), 0, stream, (uint32_t)a->P, g.rect, g.dval_a, kr, g.dkey_b, g.dval_b,
                        g.order_off, radix_sort_error_flag(g.sort_tmp, (size_t)a->P, 32), im.ranges, d.ntiles, scan_state, total_host_mapped);
     GOF_HIP_CHECK(hipGetLastError());
     *total_dev_out = scan_state + 1; }

@@ -49,10 +49,18 @@ uint32_t higher_msb(uint32_t n)
 // state (u32 words, zeroed in front of the launch): [0] ticket, [1] grand total (the device-side instance count), [2] raised by a tile
 // whose look-back poll expired, [4..] descriptors.
 #ifndef GOF_GS_ITEMS
-#define GOF_GS_ITEMS 16
+#define GOF_GS_ITEMS 4
 #endif
 constexpr int GS_ITEMS = GOF_GS_ITEMS;                 // per lane
-constexpr uint32_t GS_BLOCK = 256u * GS_ITEMS;         // positions per workgroup
+// waves per workgroup (round 6: as the single-kernel radix passes, radix.hip OS_WAVES -- the same tile spread over more waves, each
+// scanning fewer steps of 64 positions in sequence)
+#ifndef GOF_GS_WAVES
+#define GOF_GS_WAVES 16      // (measured, profiles/r06_ab_call1_binning.txt: 16 waves x 4 positions per lane against 4 x 16 -- scan_tiles 0.0285 -> 0.0227 ms at S1M, 6M: unchanged)
+#endif
+constexpr int GS_WAVES = GOF_GS_WAVES;
+constexpr uint32_t GS_THREADS = 64u * GS_WAVES;
+constexpr uint32_t GS_BLOCK = GS_THREADS * GS_ITEMS;   // positions per workgroup
+uint32_t gather_scan_threads() { return GS_THREADS; }
 constexpr uint32_t GS_SPIN_LIMIT = 1u << 18;
 uint32_t gather_scan_tiles(size_t n) { return (uint32_t)((n + GS_BLOCK - 1) / GS_BLOCK); }
 size_t gather_scan_state_words(size_t n) { return 4 + 2 * (size_t)gather_scan_tiles(n) + 2; }
@@ -60,17 +68,17 @@ __device__ __forceinline__ unsigned long long* gather_scan_desc(uint32_t* state)
 {
     return reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(state + 4) + 7u) & ~(uintptr_t)7u);
 }
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(GS_THREADS)
 gather_scan_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys_sorted,
                   uint32_t* __restrict__ minxy_sorted, uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ order_off,
                   const uint32_t* __restrict__ sort_error, uint2* __restrict__ ranges, uint32_t ntiles, uint32_t* __restrict__ state,
                   uint32_t* __restrict__ total_host)
 {
     __shared__ uint32_t s_tile, s_base;
-    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_wtot[GS_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // (the tile ranges must be zero before tile_ranges fills them in -- cudaMemset of rasterizer_impl.cu:365 --: cleared here, on the way)
-    for (uint32_t t = blockIdx.x * 256u + tid; t < ntiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
+    for (uint32_t t = blockIdx.x * GS_THREADS + tid; t < ntiles; t += gridDim.x * GS_THREADS) ranges[t] = make_uint2(0u, 0u);
     if (tid == 0) s_tile = atomicAdd(&state[0], 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
@@ -105,9 +113,9 @@ gather_scan_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __
     }
     if (lane == 0) s_wtot[wave] = run;
     __syncthreads();
-    const uint32_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
-    const uint32_t total = (t0 + t1) + (t2 + t3);
-    const uint32_t wave_excl = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+    uint32_t total = 0, wave_excl = 0;
+#pragma unroll
+    for (int w = 0; w < GS_WAVES; w++) { const uint32_t tw = s_wtot[w]; if ((uint32_t)w < wave) wave_excl += tw; total += tw; }
     if (wave == 0) {
         unsigned long long* const desc = gather_scan_desc(state);
         constexpr unsigned long long AGG = 1ull << 32, PREFIX = 2ull << 32;
@@ -137,13 +145,21 @@ gather_scan_rects(uint32_t n, const uint2* __restrict__ rect, const uint32_t* __
         // a poll that expired (GPU heavily oversubscribed): this tile's offsets are wrong.  It says so in state[2] BEFORE it publishes;
         // the last tile, whose own look-back cannot end before every predecessor has published, then writes the failure sentinel as
         // the grand total: the call fails instead of rendering from wrong offsets (as after a timed-out radix pass, radix.hip)
-        if (expired && lane == 0) __hip_atomic_store(&state[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (ordering: the flag is stored, a RELEASE fence, then the PREFIX -- relaxed, as every descriptor --; the last tile has seen every
+        // PREFIX through relaxed loads, passes an ACQUIRE fence and reads the flag: fence-to-fence synchronisation, so a PREFIX that is
+        // visible carries the flag stored in front of it.  Until round 6 the release sat on the flag's store itself, which orders what
+        // comes BEFORE it, not the PREFIX behind it.)
+        if (expired && lane == 0) {
+            __hip_atomic_store(&state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
         if (lane == 0) {
             __hip_atomic_store(desc + tile, PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = excl;
             if (tile == gridDim.x - 1u) {
                 uint32_t grand = excl + total;
-                if (__hip_atomic_load(&state[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) grand = GOF_SORT_FAILED_COUNT;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (__hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) grand = GOF_SORT_FAILED_COUNT;
                 state[1] = grand;
                 if (total_host) __hip_atomic_store(total_host, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -189,7 +205,7 @@ uint32_t emit_instances_grid(uint32_t slots, int P)
 __global__ void __launch_bounds__(256)
 emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_off, const uint32_t* __restrict__ minxy_sorted,
                const uint32_t* __restrict__ wh_sorted, uint32_t* __restrict__ tiles, uint32_t* __restrict__ gids, uint32_t gx, uint32_t capacity,
-               uint32_t* __restrict__ inst_first, uint32_t* __restrict__ hist0)
+               uint32_t* __restrict__ inst_first, uint32_t* __restrict__ hist0, uint32_t hist_stride)
 {
     // hist0 (nullable): the [digit][block] histogram of the tile sort's FIRST pass (radix.hip: rs_hist, digit = the tile id's low byte) where
     // that sort runs as histogram / scan / scatter launches over blocks of exactly this workgroup's 4 EMIT_SLOTS slots: the workgroup
@@ -270,8 +286,11 @@ emit_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
     }
     if (hist0) {
         __syncthreads();
-        // the stride of the histogram = the blocks that hold items (radix.hip: rs_active_blocks; never 0)
-        const uint32_t nb = limit ? (limit + 4u * EMIT_SLOTS - 1u) / (4u * EMIT_SLOTS) : 1u;
+        // the stride of the histogram: what the SORT behind it will use -- hist_stride, the host's block count, where the sort is launched
+        // with a host-known count (gof_forward_render / gof_integrate_view: rs_units(R), whatever this kernel's device-side total is: a
+        // caller that passes another R than the frame's count must not make the scatter read a wrongly strided histogram), else (0) the
+        // blocks that hold items by the device-side count (radix.hip: rs_active_blocks; never 0)
+        const uint32_t nb = hist_stride ? hist_stride : (limit ? (limit + 4u * EMIT_SLOTS - 1u) / (4u * EMIT_SLOTS) : 1u);
         if (blockIdx.x < nb) hist0[(size_t)threadIdx.x * nb + blockIdx.x] = s_cnt[threadIdx.x];
     }
 }

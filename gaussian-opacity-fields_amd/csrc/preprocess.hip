@@ -251,8 +251,8 @@ constexpr int K9_ROW = 49;
 // FOOT: 1 = the full footprint (pixel box, q, zfront: the opacity-field query, tight tile rectangles), 0 = the conic alone (a forward
 // that is followed by the blend only: footprint_bbox<false>)
 template <int STAGE, int FOOT>
-__global__ void __launch_bounds__(256)
-preprocess_fwd(int P, int D, int M,
+__device__ __forceinline__ void
+preprocess_one(const int idx, int P, int D, int M,
                const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
                const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
                const float* __restrict__ shs_rest,
@@ -263,15 +263,8 @@ preprocess_fwd(int P, int D, int M,
                int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
                float4* __restrict__ conic_out, float4* __restrict__ bbox_out, float4* __restrict__ fconic_out, uint32_t* __restrict__ tiles_touched,
                uint2* __restrict__ rect_out, uint8_t* __restrict__ clamped,
-               uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags,
-               uint32_t* __restrict__ zero_ptr, uint32_t zero_n)
+               uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags)
 {
-    // zero_n words at zero_ptr are cleared on the way (the first kernel of a frame: the scratch of the depth sort's single-kernel passes and
-    // the state of the fused gather + scan behind it must be zero before those launches -- a memset launch of its own until round 5);
-    // never by stage 2, which runs BESIDE them
-    if (STAGE != 2 && zero_n)
-        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < zero_n; w += gridDim.x * 256u) zero_ptr[w] = 0u;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < P;
     int32_t my_radii = 0;
     uint32_t my_tiles = 0;
@@ -440,6 +433,39 @@ preprocess_fwd(int P, int D, int M,
     // sort key of the binning stage: positive floats order like their bit patterns; culled Gaussians go last
     depth_key[idx] = my_radii > 0 ? __float_as_uint(p_view.z) : 0xFFFFFFFFu;
     depth_val[idx] = (uint32_t)idx;
+}
+
+// The kernel: one Gaussian per thread, grid-stride.  Stages 0 and 1 are launched with a workgroup per 256 Gaussians.  Stage 2 runs on
+// the library's second stream BESIDE the binning chain (api.hip: forward_stage1), whose launches are chains of dependent steps in a
+// few hundred workgroups -- a depth-sort pass of 1 M pairs is 245 of them -- and a stage 2 that fills every wave slot of the device
+// makes those wait for a slot: measured (round 6, profiles/r06_ab_call1_*.txt) the depth sort ran 0.108 ms alone, 0.147 beside round
+// 5's stage 2 and 0.177 ms beside the lighter stage 2 of this round, which occupies MORE slots.  Stage 2 is therefore launched with a
+// BOUNDED grid (api.hip: a few workgroups per CU) and strides over the Gaussians: it has until the blend to finish.
+template <int STAGE, int FOOT>
+__global__ void __launch_bounds__(256)
+preprocess_fwd(int P, int D, int M,
+               const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+               const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+               const float* __restrict__ shs_rest,
+               const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+               const float* __restrict__ v2g_precomp, Cam cam,
+               int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, float kernel_size,
+               uint32_t gx, uint32_t gy, int mode_bits /* bit 0: prefiltered; bit 1: tight tile rectangles */,
+               int32_t* __restrict__ radii, float* __restrict__ depths, SplatRec* __restrict__ rec,
+               float4* __restrict__ conic_out, float4* __restrict__ bbox_out, float4* __restrict__ fconic_out, uint32_t* __restrict__ tiles_touched,
+               uint2* __restrict__ rect_out, uint8_t* __restrict__ clamped,
+               uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, uint32_t* __restrict__ flags,
+               uint32_t* __restrict__ zero_ptr, uint32_t zero_n)
+{
+    // zero_n words at zero_ptr are cleared on the way (the first kernel of a frame: the scratch of the depth sort's single-kernel passes and
+    // the state of the fused gather + scan behind it must be zero before those launches -- a memset launch of its own until round 5);
+    // never by stage 2, which runs BESIDE them
+    if (STAGE != 2 && zero_n)
+        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < zero_n; w += gridDim.x * 256u) zero_ptr[w] = 0u;
+    for (int base = (int)blockIdx.x * 256; base < P; base += (int)gridDim.x * 256)       // (one trip unless the grid is bounded: stage 2)
+        preprocess_one<STAGE, FOOT>(base + (int)threadIdx.x, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, shs_rest, cov3D_precomp,
+                                    colors_precomp, v2g_precomp, cam, W, H, tan_fovx, tan_fovy, focal_x, focal_y, kernel_size, gx, gy, mode_bits, radii,
+                                    depths, rec, conic_out, bbox_out, fconic_out, tiles_touched, rect_out, clamped, depth_key, depth_val, flags);
 }
 template __global__ void preprocess_fwd<0, 0>(int, int, int, const float*, const float*, float, const float*, const float*, const float*, const float*, const float*,
                                               const float*, const float*, Cam, int, int, float, float, float, float, float, uint32_t, uint32_t, int, int32_t*, float*, SplatRec*,

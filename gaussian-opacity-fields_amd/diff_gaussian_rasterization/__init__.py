@@ -65,6 +65,110 @@ def _backward_with_mask_pool_redo(rs, args_of, fwd_args, geomBuffer, num_rendere
                                    rs.debug, "snapshot_bw.dump", "backward")
 
 
+# ---- the image's channel slices without autograd's per-slice zero-fill + add -------------------------------------------------------
+# train.py takes four slices of the (9, H, W) image -- rendering[:3], [3:6], [6], [8] (train.py:149-172) -- and autograd's SliceBackward
+# turns the gradient of EACH into a zero-filled (9, H, W) tensor with the slice copied in, then adds the four: four fills and three adds
+# of 61 MB tensors at 1600x1063, ~0.18 ms of a 3.5 ms iteration (profiles/r05_full_loop_kernel_stats.md).  The image is therefore
+# returned as a tensor subclass whose channel slices (an int or a slice on dimension 0, the other dimensions whole) are taken by a
+# small autograd node of this package: its backward only REMEMBERS the slice's gradient; the first one to run hands autograd ONE
+# zero-filled (9, H, W) buffer, the others nothing, and the rasterizer's backward copies the remembered gradients into whatever tensor
+# autograd delivers (that buffer, or its sum with the gradient of a use of the whole image) before it reads it.  Same numbers (sums of
+# the same terms; a channel nobody used is zero), any other operation on the image behaves as on a plain tensor and returns plain
+# tensors.  Not covered: hooks / retain_grad on the image itself see the buffer before the slices are in it.  GOF_PLAIN_IMAGE=1
+# returns the plain tensor.
+import os as _os
+
+_SLAB_IMAGE = _os.environ.get("GOF_PLAIN_IMAGE", "0") != "1"
+
+
+class _GradSlab:
+    """per forward: the gradients of the image's channel slices on their way to the rasterizer's backward"""
+    __slots__ = ("pending", "buf")
+
+    def __init__(self):
+        self.pending, self.buf = [], None
+
+    def deliver(self, grad):
+        """called by the rasterizer's backward with the gradient autograd delivers for the image: the remembered slices go in (in place:
+        `grad` is this slab's own buffer, or a sum autograd formed for this node alone)"""
+        if not self.pending:
+            return grad
+        own = self.buf is not None and grad.data_ptr() == self.buf.data_ptr() and grad.shape == self.buf.shape
+        written = []
+        for lo, hi, squeeze, g in self.pending:
+            dst = grad[lo] if squeeze else grad[lo:hi]
+            if own and all(hi <= a or b <= lo for a, b in written):
+                dst.copy_(g)                    # the buffer is still zero there
+            else:
+                dst.add_(g)
+            written.append((lo, hi))
+        self.pending, self.buf = [], None
+        return grad
+
+
+class _ChannelSlice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, lo, hi, squeeze, slab):
+        ctx.slab, ctx.lo, ctx.hi, ctx.squeeze, ctx.image_shape = slab, lo, hi, squeeze, image.shape
+        ctx.set_materialize_grads(False)
+        return image[lo] if squeeze else image[lo:hi]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None
+        slab = ctx.slab
+        first = slab.buf is None
+        if first:
+            slab.buf = torch.zeros(ctx.image_shape, dtype=g.dtype, device=g.device)
+        slab.pending.append((ctx.lo, ctx.hi, ctx.squeeze, g))
+        return (slab.buf if first else None), None, None, None, None
+
+
+def _channel_range(index, channels):
+    """(lo, hi, squeeze) if `index` selects whole channels of a (C, H, W) image -- an int or a step-1 slice on dimension 0, every other
+    dimension taken whole -- else None"""
+    if isinstance(index, tuple):
+        if len(index) == 0 or len(index) > 3 or any(not (isinstance(r, slice) and r == slice(None)) and r is not Ellipsis for r in index[1:]):
+            return None
+        index = index[0]
+    if isinstance(index, bool):
+        return None
+    if isinstance(index, int):
+        i = index + channels if index < 0 else index
+        return (i, i + 1, True) if 0 <= i < channels else None
+    if isinstance(index, slice) and index.step in (None, 1):
+        lo, hi, _ = index.indices(channels)
+        return (lo, hi, False) if lo < hi else None
+    return None
+
+
+class RenderedImage(torch.Tensor):
+    """The (9, H, W) image of a differentiable rasterizer call: a plain tensor in every respect but one -- see the comment above."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if (func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[0], RenderedImage) and torch.is_grad_enabled()
+                and args[0].requires_grad and getattr(args[0], "_gof_slab", None) is not None and args[0].dim() == 3):
+            r = _channel_range(args[1], args[0].shape[0])
+            if r is not None:
+                with torch._C.DisableTorchFunctionSubclass():
+                    return _ChannelSlice.apply(args[0].as_subclass(torch.Tensor), r[0], r[1], r[2], args[0]._gof_slab)
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return out.as_subclass(torch.Tensor) if isinstance(out, RenderedImage) else out
+
+
+def _as_rendered_image(color, slab):
+    if not _SLAB_IMAGE or slab is None or not color.requires_grad:
+        return color
+    with torch._C.DisableTorchFunctionSubclass():
+        img = color.as_subclass(RenderedImage)
+    img._gof_slab = slab
+    return img
+
+
 def _view_args(rs, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, sh):
     """Argument order of the native forward/integrate entry points after the leading (bg[, points3D])."""
     return (means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view2gaussian_precomp,
@@ -83,6 +187,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.slab = _GradSlab() if _SLAB_IMAGE else None
         # (opacities: not an input of the reference's backward; kept -- a reference, no copy -- for the one case in which the frame's
         # forward has to be repeated before its backward: _backward_with_mask_pool_redo)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
@@ -96,6 +201,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _):
         if grad_out_color is None:          # (set_materialize_grads(False): the image took no part in the loss)
             return (None,) * 10
+        if ctx.slab is not None:
+            grad_out_color = ctx.slab.deliver(grad_out_color)      # the image's channel slices (RenderedImage)
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh,
          geomBuffer, binningBuffer, imgBuffer, opacities) = ctx.saved_tensors
@@ -146,6 +253,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
             _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.slab = _GradSlab() if _SLAB_IMAGE else None
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest,
                               geomBuffer, binningBuffer, imgBuffer, opacities)
         ctx.mark_non_differentiable(radii)
@@ -157,6 +265,8 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
     def backward(ctx, grad_out_color, _):
         if grad_out_color is None:          # (set_materialize_grads(False): the image took no part in the loss)
             return (None,) * 10
+        if ctx.slab is not None:
+            grad_out_color = ctx.slab.deliver(grad_out_color)      # the image's channel slices (RenderedImage)
         rs = ctx.raster_settings
         (means3D, scales, rotations, cov3Ds_precomp, view2gaussian_precomp, radii, sh_dc, sh_rest, geomBuffer, binningBuffer,
          imgBuffer, opacities) = ctx.saved_tensors
@@ -183,10 +293,13 @@ def _split_or_cat(shs):
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         view2gaussian_precomp, raster_settings):
     if isinstance(sh, tuple):
-        return _RasterizeGaussiansSplitSH.apply(means3D, means2D, sh[0], sh[1], opacities, scales, rotations, cov3Ds_precomp,
-                                                view2gaussian_precomp, raster_settings)
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     view2gaussian_precomp, raster_settings)
+        color, radii = _RasterizeGaussiansSplitSH.apply(means3D, means2D, sh[0], sh[1], opacities, scales, rotations, cov3Ds_precomp,
+                                                        view2gaussian_precomp, raster_settings)
+    else:
+        color, radii = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                                 view2gaussian_precomp, raster_settings)
+    fn = color.grad_fn
+    return _as_rendered_image(color, getattr(fn, "slab", None) if fn is not None else None), radii
 
 
 def _normalise_optionals(shs, colors_precomp, scales, rotations, cov3D_precomp, view2gaussian_precomp):

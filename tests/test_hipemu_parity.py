@@ -570,3 +570,4 @@ def test_emulated_capacity_far_above_the_count_in_the_histogram_scan_scatter_sor
         assert np.array_equal(f.fetch("point_list")[:R], list_two_stage) and np.array_equal(f.fetch("ranges"), ranges)
 
 
+

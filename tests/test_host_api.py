@@ -118,3 +118,96 @@ def test_pose_matrix_remembers_its_inverse_and_is_a_plain_tensor_otherwise():
         assert type(r) is torch.Tensor
     p.mul_(1.0)                                                             # an in-place edit invalidates the remembered inverse
     assert p.T.inverse() is not c2w and torch.equal(p.T.inverse(), c2w)
+
+
+def test_learnt_pools_are_inherited_when_densification_changes_the_number_of_gaussians():
+    """_backend._inherit_learnt: training changes P every 100 iterations (train.py:258-264); a new P at a resolution whose previous
+    frames had between half and twice as many Gaussians takes over their capacity / mask / record needs, scaled up by the growth (never
+    down), and the old shape's entries go -- no first-frame read-back per densification.  Outside that window nothing is inherited."""
+    from diff_gaussian_rasterization import _backend as B
+    keep = (dict(B._capacity), dict(B._mask_need), dict(B._staged_need), dict(B._recent_P), dict(B._stats))
+    try:
+        for d in (B._capacity, B._mask_need, B._staged_need, B._recent_P):
+            d.clear()
+        k0 = ("cuda:0", 100_000, 800, 800)
+        B._inherit_learnt(k0)                                   # first shape at this resolution: nothing to inherit
+        assert not B._capacity
+        B._capacity[k0], B._mask_need[k0], B._staged_need[k0] = 3 << 16, 1000, 50_000
+        k1 = ("cuda:0", 130_000, 800, 800)
+        B._inherit_learnt(k1)
+        assert k0 not in B._capacity and B._capacity[k1] >= int((3 << 16) * 1.3) and B._capacity[k1] % (1 << 16) == 0
+        assert B._mask_need[k1] >= 1300 and B._staged_need[k1] >= 65_000 and k0 not in B._mask_need and k0 not in B._staged_need
+        k2 = ("cuda:0", 90_000, 800, 800)                      # pruned: inherited as it is (a capacity above the count costs nothing)
+        cap1 = B._capacity[k1]
+        B._inherit_learnt(k2)
+        assert B._capacity[k2] == cap1 and k1 not in B._capacity
+        k3 = ("cuda:0", 30_000, 800, 800)                      # a third of it: another scene as far as the pools are concerned
+        B._inherit_learnt(k3)
+        assert k3 not in B._capacity
+        k4 = ("cuda:0", 95_000, 400, 400)                      # another resolution: its own history
+        B._inherit_learnt(k4)
+        assert k4 not in B._capacity
+    finally:
+        for d, k in zip((B._capacity, B._mask_need, B._staged_need, B._recent_P, B._stats), keep):
+            d.clear(); d.update(k)
+
+
+def test_per_call_modes_are_per_thread_and_nest():
+    """_backend.call_modes: the modes handed to the library in GofRasterArgs (ABI 12) -- 0 = the process default, 1 = on, -1 = off."""
+    import threading
+    from diff_gaussian_rasterization import _backend as B
+    assert (B._mode_field("forward_exact"), B._mode_field("tight_tile_rects"), B._mode_field("integrate_pixel_pass")) == (0, 0, 0)
+    seen = {}
+    with B.call_modes(forward_exact=True):
+        assert B._mode_field("forward_exact") == 1 and B._mode_field("tight_tile_rects") == 0
+        t = threading.Thread(target=lambda: seen.update(other=B._mode_field("forward_exact")))
+        t.start(); t.join()
+        with B.call_modes(forward_exact=False, integrate_pixel_pass=True):
+            assert (B._mode_field("forward_exact"), B._mode_field("integrate_pixel_pass")) == (-1, 1)
+            with B.call_modes(tight_tile_rects=True):
+                assert (B._mode_field("forward_exact"), B._mode_field("tight_tile_rects"), B._mode_field("integrate_pixel_pass")) == (-1, 1, 1)
+        assert B._mode_field("forward_exact") == 1 and B._mode_field("integrate_pixel_pass") == 0
+    assert seen["other"] == 0 and B._mode_field("forward_exact") == 0
+
+
+def test_channel_slices_of_the_image_reach_the_backward_through_one_buffer():
+    """RenderedImage: the four slices train.py takes of the (9, H, W) image (train.py:149-172) hand their gradients to the rasterizer's
+    backward through ONE zero-filled buffer instead of autograd's zero-fill + add per slice.  With a stand-in for the rasterizer (no GPU
+    here): the gradients are those of the plain tensor -- bit for bit when the slices are disjoint, to rounding when a whole-image use
+    or overlapping slices make autograd / the slab add --, other operations return plain tensors, a retained graph can be walked twice."""
+    class Stand(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.slab = dgr._GradSlab()
+            ctx.set_materialize_grads(False)
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return ctx.slab.deliver(g) * 2.0
+    x = torch.randn(9, 6, 5, requires_grad=True)
+
+    def image(plain):
+        y = Stand.apply(x)
+        return y if plain else dgr._as_rendered_image(y, getattr(y.grad_fn, "slab", None))      # (as diff_gaussian_rasterization.rasterize_gaussians does)
+
+    def train_py_loss(img):
+        return img[:3, :, :].abs().sum() + 3 * img[8, :, :].mean() + (img[3:6, :, :] ** 2).sum() + 0.5 * img[6, :, :].sum()
+    want, = torch.autograd.grad(train_py_loss(image(True)), x)
+    got, = torch.autograd.grad(train_py_loss(image(False)), x)
+    assert torch.equal(got, want) and got[7].abs().max() == 0          # (channel 7: nobody used it -- zero, as with autograd's slices)
+
+    def mixed(img):
+        return img[:3].sum() + (img * 0.25).sum() + img[2].sum() + img[1:4].mean() + img[-1].sum()
+    want, = torch.autograd.grad(mixed(image(True)), x)
+    got, = torch.autograd.grad(mixed(image(False)), x)
+    assert (got - want).abs().max() <= 1e-6
+    img = image(False)
+    assert type(img) is dgr.RenderedImage and type(img[:3]) is torch.Tensor and type(img + 1) is torch.Tensor and type(img.permute(1, 2, 0)) is torch.Tensor
+    assert type(img[:, 2:4]) is torch.Tensor and type(img[::2]) is torch.Tensor        # not whole channels: autograd's own slices
+    loss = train_py_loss(img)
+    g1, = torch.autograd.grad(loss, x, retain_graph=True)
+    g2, = torch.autograd.grad(loss, x)
+    assert torch.equal(g1, g2)
+    with torch.no_grad():
+        assert type(image(False)) is torch.Tensor                     # nothing to differentiate: the plain tensor

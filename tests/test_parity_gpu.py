@@ -1353,3 +1353,38 @@ def test_non_default_stream_and_two_streams():
     for i in range(2):
         for g in results[i]:
             same(g, want[i], "two threads, scene %d" % i)
+
+
+def test_the_images_channel_slices_reach_the_backward_through_one_buffer_with_the_same_gradients():
+    """RenderedImage (diff_gaussian_rasterization/__init__.py): train.py's four slices of the image (train.py:149-172) hand their gradients
+    to the rasterizer's backward through one zero-filled buffer instead of autograd's zero-fill + add per slice.  The parameter gradients
+    of a train.py-shaped loss are those of the plain tensor, bit for bit (the backward is deterministic and dL_dout holds the same
+    numbers: x + 0 = x)."""
+    import diff_gaussian_rasterization as D
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sc = SCENES["posed_mid100k"]()
+    sd = to_dev(sc)
+    gt = torch.rand((3, sd["H"], sd["W"]), generator=torch.Generator().manual_seed(3)).cuda()
+
+    def grads(slab):
+        keep = D._SLAB_IMAGE
+        D._SLAB_IMAGE = slab
+        try:
+            leaf = {k: sd[k].detach().clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+            m2d = torch.zeros_like(leaf["means3D"], requires_grad=True)
+            rendering, radii = GaussianRasterizer(settings_from(sd))(means3D=leaf["means3D"], means2D=m2d, shs=leaf["shs"], opacities=leaf["opacities"],
+                                                                     scales=leaf["scales"], rotations=leaf["rotations"])
+            assert (type(rendering) is D.RenderedImage) == slab
+            image = rendering[:3, :, :]
+            distortion = rendering[8, :, :].mean()
+            depth = rendering[6, :, :]
+            normal = torch.nn.functional.normalize(rendering[3:6, :, :], p=2, dim=0)
+            loss = (image - gt).abs().mean() + 100.0 * distortion + 0.05 * (1 - (normal * normal.roll(1, 2)).sum(dim=0)).mean() + 1e-3 * depth.mean()
+            loss.backward()
+            return [m2d.grad] + [leaf[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        finally:
+            D._SLAB_IMAGE = keep
+    a, b = grads(False), grads(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert a[0].abs().max() > 0
