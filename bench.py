@@ -23,7 +23,7 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 
-PMC_FILE = "r05_pmc_traffic_s1m.json"
+PMC_FILE = "r06_pmc_traffic_s1m.json"
 FLOP_PER_PAIR_FWD = 85       # forward.cu:504-575 per contributing pair
 FLOP_PER_PAIR_BWD = 190      # backward.cu:771-952 per contributing pair, incl. its 19 accumulating adds
 

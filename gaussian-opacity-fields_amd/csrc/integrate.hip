@@ -243,6 +243,15 @@ integrate_rays(const uint2* __restrict__ gaussian_ranges, const uint32_t* __rest
             __syncthreads();
             held_waves = (n_live + 63) / 64;
 #if GOF_IR_EXIT
+            // HARDWARE ASSUMPTION (gfx950, stated because HIP's own rule is stricter): the waves that stay keep executing
+            // __syncthreads() after these have returned.  HIP calls a barrier that not every thread of the workgroup reaches undefined;
+            // on this GPU the workgroup barrier (s_barrier) counts the waves that have not ended -- a wave that executes s_endpgm leaves
+            // the barrier's membership; observed on MI355X over every run of the suite and the soaks of round 5 -- and the exits here are
+            // WHOLE waves behind a barrier, wave-uniform, with nothing of theirs left in flight (their rays are parked in LDS above).
+            // This file is compiled for gfx950 only (gof_common.h refuses any other target); a port has to build with -DGOF_IR_EXIT=0
+            // (the idle waves then stay parked at the barriers: measured 8.23 vs 4.85 ms for the pass).  A regression
+            // shows up as a HANG, not as wrong numbers: every GPU test of the query runs under a time-out
+            // (tests/test_parity_gpu.py: QUERY_TIMEOUT) and tests/devtools run the kernel under `timeout`.
             alive_waves = max(IR_KEEP_WAVES, held_waves);
             if ((int)(tid >> 6) >= alive_waves) return;                         // (whole waves; every ray they held is parked)
 #endif

@@ -20,9 +20,16 @@
 
 namespace gof {
 
-constexpr int SCAN_ITEMS = 16;                       // per thread
-constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;         // 4096 items per block
-constexpr uint32_t SCAN_DIRECT_MAX = 2048;           // up to this many blocks (8.4M items) the scan runs as two launches
+// items per thread of the scan kernels: 16 (4096 per workgroup), or -- inputs of up to 2 M words: the radix sorts' [digit][block]
+// histograms of a 6M-Gaussian frame are 0.4 M (depth sort) and 1.4 M (tile sort) words -- 4 (1024 per workgroup: four times the
+// workgroups, a fourth of the dependent loads per thread; the scans of one 6M-Gaussian frame took 0.33 ms of its 4.1 in tiles of 4096 --
+// profiles/r06_large_p_6M_kernel_stats.md.  Measured, interleaved, tiles of 1024 / 2048 / 4096 words: S1M 2.386 / 2.397 / 2.400 ms per step,
+// clustered 3.226 / 3.238 / 3.248, 6 M Gaussians 4.131 / 4.144 / 4.157 -- profiles/r06_ab_call5_hist_scan.txt)
+#ifndef GOF_SCAN_SMALL_ITEMS
+#define GOF_SCAN_SMALL_ITEMS 4
+#endif
+constexpr int SCAN_ITEMS_BIG = 16, SCAN_ITEMS_SMALL = GOF_SCAN_SMALL_ITEMS;
+constexpr uint32_t SCAN_DIRECT_MAX = 2048;           // up to this many workgroups the scan runs as two launches
 #ifndef GOF_RS_CHUNK
 #define GOF_RS_CHUNK 1024
 #endif
@@ -59,9 +66,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
 // hist_items_dev (nullable; the radix sort's [digit][block] histogram of a launch sized for a CAPACITY, rs_hist): the scan covers only
 // the blocks that hold items -- RS_DIGITS x ceil(count / RS_BLOCK) words; the workgroups past that write a zero sum and leave
 __device__ __forceinline__ uint32_t hist_words(uint32_t n, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity);
+template <int SCAN_ITEMS>
 __global__ void __launch_bounds__(256)
 scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity)
 {
+    constexpr uint32_t SCAN_BLOCK = 256u * SCAN_ITEMS;
     __shared__ uint32_t s_wave[4];
     n = hist_words(n, hist_items_dev, capacity);
     if (blockIdx.x * SCAN_BLOCK >= n) { if (threadIdx.x == 0) sums[blockIdx.x] = 0u; return; }
@@ -95,11 +104,12 @@ scan_sums(uint32_t* __restrict__ sums, uint32_t nb, uint32_t* __restrict__ total
 // out[i] = (inclusive ? in[0..i] : in[0..i)) summed; optional gather: in[idx[i]] instead of in[i].
 // DIRECT: `sums` holds the RAW block sums (scan_sums was not run): every workgroup adds up the sums of the workgroups before it
 // itself (at most SCAN_DIRECT_MAX values -- cheaper than a third launch) and the last one leaves the grand total in sums[nb].
-template <bool INCLUSIVE, bool GATHER, bool DIRECT>
+template <bool INCLUSIVE, bool GATHER, bool DIRECT, int SCAN_ITEMS>
 __global__ void __launch_bounds__(256)
 scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ sums,
            uint32_t* __restrict__ out, uint32_t* __restrict__ total_host, const uint32_t* __restrict__ hist_items_dev, uint32_t capacity)
 {
+    constexpr uint32_t SCAN_BLOCK = 256u * SCAN_ITEMS;
     __shared__ uint32_t s_wave[4];
     if (hist_items_dev) {                           // (nobody reads the grand total of a histogram scan)
         n = hist_words(n, hist_items_dev, capacity);
@@ -139,10 +149,11 @@ scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, ui
         run += v[k];
     }
 }
-template <bool GATHER>
+template <bool GATHER, int SCAN_ITEMS>
 __global__ void __launch_bounds__(256)
 scan_block_sums_gather(const uint32_t* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ sums)
 {
+    constexpr uint32_t SCAN_BLOCK = 256u * SCAN_ITEMS;
     __shared__ uint32_t s_wave[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
@@ -153,32 +164,43 @@ scan_block_sums_gather(const uint32_t* __restrict__ in, const uint32_t* __restri
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-size_t scan_tmp_words(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK + 2; }
+size_t scan_tmp_words(size_t n) { return (n + 256 * SCAN_ITEMS_SMALL - 1) / (256 * SCAN_ITEMS_SMALL) + 2; }      // (enough for either tile size)
 
 // out = scan(in[idx]) if idx != nullptr else scan(in).  tmp: scan_tmp_words(n) u32.  The grand total is left in
 // tmp[nblocks] (device); total_dev_out (optional) receives its address.
 // total_host (nullable): a DEVICE-VISIBLE address of host memory (hipHostGetDevicePointer) that receives the grand total as well.
-static hipError_t device_scan_impl(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
-                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host,
-                                   const uint32_t* hist_items_dev, uint32_t capacity)
+template <int ITEMS>
+static hipError_t device_scan_t(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                                const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host,
+                                const uint32_t* hist_items_dev, uint32_t capacity)
 {
-    const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    constexpr size_t BLOCK = 256 * ITEMS;
+    const uint32_t nb = (uint32_t)((n + BLOCK - 1) / BLOCK);
     if (total_dev_out) *total_dev_out = tmp + nb;
     if (n == 0) {
         if (total_host) *total_host = 0;       // (host-mapped: a plain host store; nothing is queued for an empty input)
         return hipMemsetAsync(tmp, 0, 2 * sizeof(uint32_t), stream);
     }
-    if (idx) hipLaunchKernelGGL(scan_block_sums_gather<true>, dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp);
-    else hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, stream, in, (uint32_t)n, tmp, hist_items_dev, capacity);
+    if (idx) hipLaunchKernelGGL((scan_block_sums_gather<true, ITEMS>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp);
+    else hipLaunchKernelGGL((scan_block_sums<ITEMS>), dim3(nb), dim3(256), 0, stream, in, (uint32_t)n, tmp, hist_items_dev, capacity);
     const bool direct = nb <= SCAN_DIRECT_MAX;         // few workgroups: each adds up its predecessors' sums itself, two launches
     if (!direct) hipLaunchKernelGGL(scan_sums, dim3(1), dim3(256), 0, stream, tmp, nb, total_host);
 #define GOF_SCAN_APPLY(INC, GA)                                                                                                        \
-    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, total_host, hist_items_dev, capacity);   \
-         else hipLaunchKernelGGL((scan_apply<INC, GA, false>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, (uint32_t*)nullptr, hist_items_dev, capacity); } while (0)
+    do { if (direct) hipLaunchKernelGGL((scan_apply<INC, GA, true, ITEMS>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, total_host, hist_items_dev, capacity);   \
+         else hipLaunchKernelGGL((scan_apply<INC, GA, false, ITEMS>), dim3(nb), dim3(256), 0, stream, in, idx, (uint32_t)n, tmp, out, (uint32_t*)nullptr, hist_items_dev, capacity); } while (0)
     if (idx) { if (inclusive) GOF_SCAN_APPLY(true, true); else GOF_SCAN_APPLY(false, true); }
     else { if (inclusive) GOF_SCAN_APPLY(true, false); else GOF_SCAN_APPLY(false, false); }
 #undef GOF_SCAN_APPLY
     return hipGetLastError();
+}
+static hipError_t device_scan_impl(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
+                                   const uint32_t** total_dev_out, hipStream_t stream, uint32_t* total_host,
+                                   const uint32_t* hist_items_dev, uint32_t capacity)
+{
+    // small tiles while the two-launch form still holds (<= SCAN_DIRECT_MAX workgroups of 1024 items)
+    if (n <= (size_t)SCAN_DIRECT_MAX * 256 * SCAN_ITEMS_SMALL)
+        return device_scan_t<SCAN_ITEMS_SMALL>(in, idx, out, n, inclusive, tmp, total_dev_out, stream, total_host, hist_items_dev, capacity);
+    return device_scan_t<SCAN_ITEMS_BIG>(in, idx, out, n, inclusive, tmp, total_dev_out, stream, total_host, hist_items_dev, capacity);
 }
 hipError_t device_scan_u32(const uint32_t* in, const uint32_t* idx, uint32_t* out, size_t n, bool inclusive, uint32_t* tmp,
                            const uint32_t** total_dev_out, hipStream_t stream)

@@ -29,6 +29,10 @@ import synthetic_scenes as S
 from gpu_common import assert_fast_mode_matches_exact, bits, fetch, forward_exact, forward_mode_arrays, product_forward_raw, settings_from, to_dev
 
 pytestmark = pytest.mark.gpu
+# the query's ray-centric pixel pass lets whole waves LEAVE the kernel at a compaction while the others go on through the workgroup's
+# barriers (csrc/integrate.hip: GOF_IR_EXIT; a gfx950 property, documented there): a toolchain or hardware change that breaks it hangs
+# the kernel instead of producing wrong numbers -- every test that runs the query does so under this time-out (pytest-timeout)
+QUERY_TIMEOUT = pytest.mark.timeout(600)
 
 K1_ARRAYS = ["depths", "means2D", "conic_opacity", "rgb", "view2gaussian", "clamped"]
 INT_ARRAYS = ["tiles_touched", "point_list", "point_list_keys", "ranges", "n_contrib"]
@@ -207,6 +211,7 @@ def _fuzz_scene(seed):
     return sc
 
 
+@QUERY_TIMEOUT
 @pytest.mark.parametrize("seed", range(60))
 def test_forward_and_integrate_fuzz_bit_exact(seed):
     """Randomised small scenes (image size, focal length, splat size from sub-pixel to tile-covering, anisotropy up to ~1:100,
@@ -440,6 +445,7 @@ def test_autograd_surface_like_render():
     assert np.array_equal(vis, orad > 0)
 
 
+@QUERY_TIMEOUT
 def test_integrate_matches_oracle():
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = S.scene_frustum(3000, W=96, H=64, focal=70.0, seed=8, kernel_size=0.1)
@@ -465,6 +471,7 @@ def test_integrate_matches_oracle():
     assert (a[-2:] == 1.0).all()          # points outside the image keep the initial 1.0 (rasterize_points.cu:277)
 
 
+@QUERY_TIMEOUT
 @pytest.mark.parametrize("name", ["small_ks0", "long_lists", "ragged", "lego10k", "stress_box", "mid100k", "wide4k", "sub_tile", "strip_h", "strip_v"] + POSED)
 def test_integrate_bit_exact_on_scene(name):
     """The opacity-field query on the forward's scene table (incl. the cull stress scene: sub-pixel far splats, needles,
@@ -501,6 +508,7 @@ def uint16_scene():
     return sc
 
 
+@QUERY_TIMEOUT
 def test_integrate_reproduces_the_uint16_contributor_ids_of_lists_beyond_65535_entries():
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = uint16_scene()
@@ -563,6 +571,7 @@ def _integrate_outputs(sd, pts):
     return [t.cpu().numpy() for t in out]
 
 
+@QUERY_TIMEOUT
 def test_integrate_uint16_wrap_below_the_cap_in_the_ray_centric_pass():
     sc = uint16_scene_below_the_cap()
     pts = np.ascontiguousarray(S.tetra_points(sc)[::40], dtype=np.float32)
@@ -580,6 +589,7 @@ def test_integrate_uint16_wrap_below_the_cap_in_the_ray_centric_pass():
         assert np.array_equal(bits(colp), bits(ocol)), mode
 
 
+@QUERY_TIMEOUT
 @pytest.mark.parametrize("name", ["long_lists", "ragged", "stress_box", "posed_clustered150k", "strip_v"])
 def test_integrate_pixel_centric_form_gives_the_ray_centric_forms_bits(name):
     """gof_set_integrate_pixel_pass(1): the pixel pass of rounds 1-4 (thread = pixel, five sub-rays each) -- since round 5 the fallback
@@ -837,6 +847,7 @@ def test_split_sh_tensors_are_bit_identical_to_their_concatenation(P, degree):
     assert sp.shape == sd["shs"].shape and torch.equal(sp.transpose(1, 2), sd["shs"].transpose(1, 2))
 
 
+@QUERY_TIMEOUT
 def test_integrate_with_no_visible_gaussian_and_with_no_point_in_view():
     """Degenerate inputs of the opacity-field query: every Gaussian culled (behind the camera) -> points inside the image get
     alpha 0 and the background colour, points outside keep the initial 1; and a point set entirely outside the image."""
@@ -859,6 +870,7 @@ def test_integrate_with_no_visible_gaussian_and_with_no_point_in_view():
     assert (orad > 0).any() and (oal == 1.0).all()          # second case: visible Gaussians, no point in front of the camera
 
 
+@QUERY_TIMEOUT
 def test_integrate_view_cache_reuses_the_gaussian_side_bit_exactly():
     """Mesh-extraction driver fusion: under an announced view key the binning + pixel pass runs once; later
     point sets reuse it.  Outputs must be bit-identical to uncached calls, a new key (changed Gaussians) must recompute."""
@@ -908,6 +920,7 @@ def test_integrate_view_cache_reuses_the_gaussian_side_bit_exactly():
         cache.clear()
 
 
+@QUERY_TIMEOUT
 def test_integrate_full_size_s1m_against_oracle():
     """The opacity-field query at 1M Gaussians, 1600x1063, 2M query points against the oracle (host cores of the GPU box):
     every output bit-identical -- the footprint-conic cull, the zfront skip and the pixel-grouped point order at full scale."""
@@ -929,6 +942,7 @@ def test_integrate_full_size_s1m_against_oracle():
     assert np.array_equal(bits(colp.cpu().numpy()), bits(ocol))
 
 
+@QUERY_TIMEOUT
 def test_integrate_full_size_properties_config5():
     """BASELINE config 5 shape at FULL size (5M Gaussians, 45M query points, 1600x1063): size-independent properties of the
     opacity-field query instead of an oracle run -- range, untouched points, channel-8 checksum, idempotence, cache equivalence,
@@ -966,6 +980,7 @@ def test_integrate_full_size_properties_config5():
     cache.clear()
 
 
+@QUERY_TIMEOUT
 def test_integrate_config5_gaussian_count_against_oracle():
     """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 18M instances, tile lists of ~2700 entries) with a 5M-point subsample
     of its 45M query points, against the oracle on the GPU box's host cores: every output bit-identical.  (50 s of the suite: the
