@@ -390,7 +390,7 @@ def workspace_report(B, P, W, H, R, staged):
     held a record per instance, 69 B.  The reference's BinningState holds 24 B (rasterizer_impl.h:60-70): a stated deviation
     (DESIGN.md section 7): masks and records buy the backward without re-derived decisions and without atomics."""
     lib = B.lib
-    geom, image = int(lib.gof_geom_bytes(P)), int(lib.gof_image_bytes(W, H))
+    geom, image = int(lib.gof_geom_bytes_forward(P)), int(lib.gof_image_bytes(W, H))      # (what a forward / backward pair allocates: without the query's 16 B per Gaussian)
     binning_full = int(lib.gof_binning_bytes(R, W, H))
     # what the shipped binding allocates in steady state: the instance capacity (1.25 x the count + 64 Ki) and a mask pool 1.25 x the
     # largest request seen (learnt at the first backward) on top of the sort state

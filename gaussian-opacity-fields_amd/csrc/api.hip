@@ -210,14 +210,13 @@ static inline void carve(char*& p, T*& ptr, size_t count)
     p += count * sizeof(T);
 }
 
-size_t geom_layout(int32_t P, void* base, GeomWs* out)
+static size_t geom_layout_ex(int32_t P, void* base, GeomWs* out, size_t* forward_bytes_out)
 {
     GeomWs g;
     char* p = static_cast<char*>(base);
     const size_t n = (size_t)P;
     carve(p, g.rec, n);
     carve(p, g.conic, n);
-    carve(p, g.bbox, n);
     carve(p, g.fconic, 2 * n);
     carve(p, g.depths, n);
     carve(p, g.tiles_touched, n);
@@ -232,9 +231,15 @@ size_t geom_layout(int32_t P, void* base, GeomWs* out)
     carve(p, g.dkey_b, n);
     carve(p, g.dval_b, n);
     carve(p, g.sort_tmp, rs_tmp_words(n) + gather_scan_state_words(n));
+    // LAST: what only the opacity-field query reads (the footprints' pixel boxes, 16 B per Gaussian) -- a workspace for a forward /
+    // backward pair may end here (gof_geom_bytes_forward: round 6), the layout in front of it is the same either way
+    const size_t forward_bytes = (size_t)(p - static_cast<char*>(base)) + ALIGN;
+    carve(p, g.bbox, n);
     if (out) *out = g;
+    if (forward_bytes_out) *forward_bytes_out = forward_bytes;
     return (size_t)(p - static_cast<char*>(base)) + ALIGN;
 }
+size_t geom_layout(int32_t P, void* base, GeomWs* out) { return geom_layout_ex(P, base, out, nullptr); }
 size_t image_layout(int32_t W, int32_t H, void* base, ImageWs* out)
 {
     ImageWs im;
@@ -458,6 +463,7 @@ int gof_abi_version(void) { return 12; }  // 12: per-call modes in GofRasterArgs
                                           // (tile queues in the image / point-binning workspaces, queue heads in the backward scratch: sizes from the same queries)
 
 size_t gof_geom_bytes(int32_t P) { return geom_layout(P < 0 ? 0 : P, nullptr, nullptr) + ALIGN; }
+size_t gof_geom_bytes_forward(int32_t P) { size_t fb = 0; geom_layout_ex(P < 0 ? 0 : P, nullptr, nullptr, &fb); return fb + ALIGN; }
 size_t gof_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr) + ALIGN; }
 // one size for both users of a binning workspace: the opacity-field query (static masks) and the forward blend with a FULL mask pool
 size_t gof_binning_bytes(uint32_t R, int32_t W, int32_t H)
@@ -546,9 +552,11 @@ struct AuxJoin {
 // the first launch that reads the records / conics / footprints / depths / clamp flags
 // full_footprint: the per-Gaussian stage also leaves the footprint's pixel box, q and zfront (preprocess.hip: footprint_bbox<true>) -- what
 // the opacity-field query reads; a forward that is followed by the blend needs the conic alone (tight tile rectangles: the box as well)
-static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream,
+// geom_bytes: the caller's geometry workspace -- the footprints' pixel boxes are stored only into one of gof_geom_bytes(P)
+static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, size_t geom_bytes, const ImageWs& im, int32_t* radii, const uint32_t** total_dev_out, hipStream_t stream,
                           bool full_footprint, uint32_t* total_host_mapped = nullptr, AuxJoin* join = nullptr)
 {
+    float4* const bbox_out = geom_bytes >= gof_geom_bytes(a->P) ? g.bbox : nullptr;
     const Dims d = dims_of(a);
     const Cam cam = { a->viewmatrix, a->projmatrix, a->campos };
     if (a->prefiltered) GOF_HIP_CHECK(hipMemsetAsync(g.flags, 0, 4 * sizeof(uint32_t), stream));   // only then written and read
@@ -561,7 +569,7 @@ static int forward_stage1(const GofRasterArgs* a, const GeomWs& g, const ImageWs
                        a->P, a->D, a->M, a->means3D, a->scales, a->scale_modifier, a->rotations, a->opacities, a->shs, a->shs_rest,                          \
                        a->cov3D_precomp, a->colors_precomp, a->view2gaussian_precomp, cam, a->W, a->H, a->tan_fovx, a->tan_fovy,                             \
                        d.focal_x, d.focal_y, a->kernel_size, d.gx, d.gy, k1_bits,                                                                             \
-                       radii, g.depths, g.rec, g.conic, g.bbox, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags, k1_zero_ptr, k1_zero_n)
+                       radii, g.depths, g.rec, g.conic, bbox_out, g.fconic, g.tiles_touched, g.rect, g.clamped, g.dkey_a, g.dval_a, g.flags, k1_zero_ptr, k1_zero_n)
     // what the depth sort and the fused gather + scan behind it need cleared: cleared by the per-Gaussian kernel, the first launch of the
     // frame, instead of by a memset launch in front of the sort (depth sort 0.147 -> 0.140 ms at S1M, profiles/r05_ab_call8_binning.txt)
     const size_t scan_words = gather_scan_state_words((size_t)a->P);
@@ -634,13 +642,14 @@ static int prepare_impl(const GofRasterArgs* a, void* geom_ws, size_t geom_bytes
     *num_rendered_host = 0;
     if (a->P == 0) return GOF_OK;
     if (!radii || !geom_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P)) { set_error("geometry workspace too small: %zu < %zu", geom_bytes, gof_geom_bytes(a->P)); return GOF_E_WORKSPACE; }
+    { const size_t need = full_footprint ? gof_geom_bytes(a->P) : gof_geom_bytes_forward(a->P);
+      if (geom_bytes < need) { set_error("geometry workspace too small: %zu < %zu", geom_bytes, need); return GOF_E_WORKSPACE; } }
     if (image_bytes < gof_image_bytes(a->W, a->H)) { set_error("image workspace too small"); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im;
     geom_layout(a->P, aligned_base(geom_ws), &g);
     image_layout(a->W, a->H, aligned_base(image_ws), &im);
     const uint32_t* total_dev = nullptr;
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream, full_footprint);
+    rc = forward_stage1(a, g, geom_bytes, im, radii, &total_dev, stream, full_footprint);
     if (rc) return rc;
     // one blocking 4-byte read-back, as the reference (rasterizer_impl.cu:336)
     uint32_t host_words[2] = { 0, 0 };
@@ -689,7 +698,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     if (!num_rendered_pinned_host || !out_color) { set_error("num_rendered_pinned_host / out_color is NULL"); return GOF_E_INVALID; }
     if (a->P == 0 || a->prefiltered || a->debug) { set_error("gof_forward_fused: empty / prefiltered / debug calls use gof_forward_prepare + gof_forward_render"); return GOF_E_INVALID; }
     if (!radii || !geom_ws || !binning_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(capacity, a->W, a->H, 0)) {
+    if (geom_bytes < gof_geom_bytes_forward(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(capacity, a->W, a->H, 0)) {
         set_error("workspace too small (geom %zu, image %zu, binning %zu)", geom_bytes, image_bytes, binning_bytes); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
@@ -703,7 +712,7 @@ int gof_forward_fused(const GofRasterArgs* a, uint32_t capacity, void* geom_ws, 
     uint32_t* const usage_mapped = device_view_of_pinned(usage_pinned_host);
     *num_rendered_pinned_host = 0xFFFFFFFFu;
     AuxJoin heavy;                       // (its destructor joins on every way out of this call)
-    rc = forward_stage1(a, g, im, radii, &total_dev, stream, false, count_mapped, &heavy);
+    rc = forward_stage1(a, g, geom_bytes, im, radii, &total_dev, stream, false, count_mapped, &heavy);
     if (rc) return rc;
     // the event the host waits for: one per (thread, device) -- an event belongs to the device it was created on
     AuxStream* const aux = aux_stream();
@@ -750,7 +759,7 @@ int gof_forward_render(const GofRasterArgs* a, uint32_t R, const int32_t* radii,
         return GOF_OK;
     }
     if (!radii || !geom_ws || !binning_ws || !image_ws) { set_error("radii / workspace is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(R, a->W, a->H, 0)) {
+    if (geom_bytes < gof_geom_bytes_forward(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(R, a->W, a->H, 0)) {
         set_error("workspace too small (geom %zu, image %zu, binning %zu)", geom_bytes, image_bytes, binning_bytes); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
@@ -828,7 +837,7 @@ static int backward_impl(int stages, const GofRasterArgs* a, uint32_t R, const i
     const bool split_sh = a->shs_rest != nullptr;
     if (split_sh != (dL_dsh_rest != nullptr)) { set_error("dL_dsh_rest must be given exactly when args->shs_rest is"); return GOF_E_INVALID; }
     if (!a->scales || !a->rotations) { set_error("backward needs scales and rotations (backward.cu:621)"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(R, a->W, a->H, 0)) {
+    if (geom_bytes < gof_geom_bytes_forward(a->P) || image_bytes < gof_image_bytes(a->W, a->H) || binning_bytes < gof_binning_bytes_for(R, a->W, a->H, 0)) {
         set_error("workspace too small"); return GOF_E_WORKSPACE; }
     GeomWs g; ImageWs im; BinWs b;
     geom_layout(a->P, aligned_base(geom_ws), &g);
@@ -1174,7 +1183,7 @@ int gof_sh_grad_pack(int32_t P, const float* dL_dcolors, const void* geom_ws, si
     if (P < 0) { set_error("bad P"); return GOF_E_INVALID; }
     if (P == 0) return GOF_OK;
     if (!dL_dcolors || !geom_ws || !radii || !packed) { set_error("a pointer is NULL"); return GOF_E_INVALID; }
-    if (geom_bytes < gof_geom_bytes(P)) { set_error("geometry workspace too small for P = %d", P); return GOF_E_WORKSPACE; }
+    if (geom_bytes < gof_geom_bytes_forward(P)) { set_error("geometry workspace too small for P = %d", P); return GOF_E_WORKSPACE; }
     GeomWs g;
     geom_layout(P, aligned_base(const_cast<void*>(geom_ws)), &g);
     GOF_PROFILE("sh_grad_pack", stream);

@@ -403,7 +403,7 @@ preprocess_one(const int idx, int P, int D, int M,
         dst[2] = make_float4(r.f[8], r.f[9], r.f[10], r.f[11]);
         dst[3] = make_float4(r.f[12], r.f[13], r.f[14], r.f[15]);
         conic_out[idx] = make_float4(conx, cony, conz, r.f[REC_W]);      // .w: the blend weight again, where gather_tile_partials finds it beside nothing else it reads (blend_backward.hip)
-        bbox_out[idx] = box;
+        if (FOOT && bbox_out) bbox_out[idx] = box;      // (only the query reads it: stored into a full-size geometry workspace, api.hip)
         fconic_out[2 * (size_t)idx] = fc[0];
         fconic_out[2 * (size_t)idx + 1] = fc[1];
         depths[idx] = p_view.z;

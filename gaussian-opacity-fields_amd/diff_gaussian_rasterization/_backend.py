@@ -44,7 +44,7 @@ def _load():
     A = C.POINTER(GofRasterArgs)
     lib.gof_last_error.restype = C.c_char_p
     lib.gof_abi_version.restype = C.c_int
-    for name, args in (("gof_geom_bytes", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]), ("gof_binning_bytes_for", [u32, i32, i32, u32]),
+    for name, args in (("gof_geom_bytes", [i32]), ("gof_geom_bytes_forward", [i32]), ("gof_image_bytes", [i32, i32]), ("gof_binning_bytes", [u32, i32, i32]), ("gof_binning_bytes_for", [u32, i32, i32, u32]),
                        ("gof_point_bytes", [i32]), ("gof_backward_scratch_bytes", [i32, u32]), ("gof_backward_scratch_bytes_for", [i32, u32, u32]),
                        ("gof_mtets_tet_ws_bytes", [i64]),
                        ("gof_mtets_edge_ws_bytes", [i64])):
@@ -230,7 +230,7 @@ class _View:
 def _prepare_and_bin(v, for_query=False):
     """Stage 1 shared by forward and integrate: preprocess + scan + instance count.  for_query: the footprints complete (pixel box,
     front depth: gof_integrate_prepare), which only the opacity-field query reads."""
-    geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
+    geom = v.bytes_tensor(lib.gof_geom_bytes(v.P) if for_query else lib.gof_geom_bytes_forward(v.P))      # (the query's part of the footprints: 16 B per Gaussian more)
     img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
     radii = torch.empty(v.P, dtype=torch.int32, device=v.device)       # preprocess_fwd writes every element (0 for culled Gaussians)
     n = C.c_uint32(0)
@@ -371,7 +371,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             _inherit_learnt(shape_key)
         cap = _capacity.get(shape_key) if (use_fused and not prefiltered and not debug) else None
         if cap is not None:
-            geom = v.bytes_tensor(lib.gof_geom_bytes(v.P))
+            geom = v.bytes_tensor(lib.gof_geom_bytes_forward(v.P))
             img = v.bytes_tensor(lib.gof_image_bytes(v.W, v.H))
             sub = _mask_pool_subchunks(shape_key)
             binning = v.bytes_tensor(lib.gof_binning_bytes(cap, v.W, v.H) if sub is None else lib.gof_binning_bytes_for(cap, v.W, v.H, sub))

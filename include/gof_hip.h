@@ -116,6 +116,10 @@ int gof_set_integrate_pixel_pass(int on);
 /* ---- workspace size queries (host only) ------------------------------------------------ */
 /* replaces required<GeometryState>(P)  (rasterizer_impl.cu:277, 188-204) */
 size_t gof_geom_bytes(int32_t P);
+/* ... for a forward / backward pair (gof_forward_prepare / _render / _fused, gof_backward*, gof_sh_grad_pack): the same layout without its
+ * tail, the footprints' pixel boxes that only the opacity-field query reads (16 B per Gaussian less; ABI 12).  The query's entry points
+ * (gof_integrate_prepare / _view / _run / _points, gof_integrate_pack_geom) need gof_geom_bytes; a buffer of that size serves both. */
+size_t gof_geom_bytes_forward(int32_t P);
 /* replaces required<ImageState>(W*H)   (rasterizer_impl.cu:290, 218-228) */
 size_t gof_image_bytes(int32_t W, int32_t H);
 /* replaces required<BinningState>(num_rendered) (rasterizer_impl.cu:338, 230-243) */

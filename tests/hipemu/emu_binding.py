@@ -114,7 +114,7 @@ class EmuScene:
         lib = self.lib
         lib.gof_set_forward_exact(1 if self.exact else 0)
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
-        self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
+        self.geom = _aligned(lib.gof_geom_bytes_forward(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")      # (geometry as the binding sizes it for a forward: without the query's 16 B per Gaussian; guard bytes behind it)
         self.radii = np.zeros(self.P, np.int32)
         n = C.c_uint32(0)
         lib.gof_set_tight_tile_rects(1 if self.tight else 0)
@@ -200,7 +200,7 @@ class EmuScene:
         The binning workspace is allocated at EXACTLY gof_binning_bytes(capacity) with `guard` bytes of 0xA5 behind it.
         -> (rc, true instance count, guard intact?)"""
         lib = self.lib
-        self.geom = _aligned(lib.gof_geom_bytes(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
+        self.geom = _aligned(lib.gof_geom_bytes_forward(self.P), what="geom"); self.img = _aligned(lib.gof_image_bytes(self.W, self.H), what="image")
         nb = int(lib.gof_binning_bytes(int(capacity), self.W, self.H))
         raw = _aligned(nb + guard)
         raw[nb:] = 0xA5

@@ -38,6 +38,8 @@ def test_size_queries_are_host_only_and_monotone():
     assert L.gof_geom_bytes(0) > 0
     assert L.gof_geom_bytes(1000) < L.gof_geom_bytes(100000)
     assert L.gof_geom_bytes(1_000_000) >= 1_000_000 * (64 + 16 + 4 + 4 + 4 + 1)
+    # the forward / backward pair's geometry workspace: the same layout without its tail, the query's 16 B per Gaussian (ABI 12)
+    assert 0 < L.gof_geom_bytes(1_000_000) - L.gof_geom_bytes_forward(1_000_000) - 16_000_000 < 4096
     assert L.gof_image_bytes(1600, 1063) >= 1600 * 1063 * 24
     assert L.gof_binning_bytes(0, 400, 400) > 0
     assert L.gof_binning_bytes(5_000_000, 1600, 1063) >= 5_000_000 * 16
