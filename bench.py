@@ -33,7 +33,7 @@ KERNEL_SOURCES = {
     "blend_forward": "blend_forward.hip", "blend_forward_exact": "blend_forward.hip",
     "blend_backward": "blend_backward.hip", "gather_tile_partials": "blend_backward.hip",
     "preprocess_fwd": "preprocess.hip", "preprocess_fwd_heavy": "preprocess.hip", "preprocess_bwd": "preprocess.hip", "preprocess_points": "preprocess.hip",
-    "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_rects": "binning.hip", "gather_scan_rects": "binning.hip",
+    "emit_instances": "binning.hip", "tile_ranges": "binning.hip", "order_tiles": "binning.hip", "gather_scan_rects": "binning.hip",
     "point_keys": "binning.hip", "gather_sorted_points": "binning.hip",
     "os_hist": "radix.hip", "os_pass": "radix.hip", "rs_hist": "radix.hip", "rs_scatter": "radix.hip", "scan_block": "radix.hip",
     "integrate_pixels": "integrate.hip", "integrate_points": "integrate.hip", "integrate_rays": "integrate.hip", "integrate_pixels_capped": "integrate.hip",
@@ -607,7 +607,7 @@ def reference_leg(sd, dL, product_ms):
         return {"available": False, "why": "%s: %s" % (type(e).__name__, e)}
 
 
-def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
+def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False, only_launcher=False):
     """SURVEY.md 8(d)(i) "full-loop variant": one complete training iteration of train.py:125-190, 263-265 on the same
     scene -- the parameter activations render() reads (scene/gaussian_model.py:157-194, HIP), rasterizer forward, the reference's loss
     (L1 + D-SSIM + depth-normal consistency + distortion), backward, Adam over the 59 floats per Gaussian -- with the
@@ -641,7 +641,11 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
     lambda_dssim, lambda_dn, lambda_dist = 0.2, 0.05, 100.0        # arguments/__init__.py defaults
     filter_3D = (sd["scales"].min(dim=1, keepdim=True).values * 0.1).contiguous()           # a small 3D smoothing filter (compute_3D_filter's role)
 
-    def iteration(one_call_loss=False, split_sh=False):
+    from train_epilogue import deferred as Dl
+
+    def iteration(one_call_loss=False, split_sh=False, launcher=False):
+        # launcher: the helper names as launch/run_reference_script.py binds them -- deferred evaluation on (train_epilogue/deferred.py):
+        # the SAME lines below then cost no launch until loss.backward(), which is one fused call
         # get_features (gaussian_model.py:173-176): the concatenation as the reference forms it, or -- with the launcher's default
         # rebinding -- the two stored tensors handed over as they are (SplitSH)
         shs = SplitSH(params["f_dc"], params["f_rest"]) if split_sh else torch.cat((params["f_dc"], params["f_rest"]), dim=1)
@@ -655,10 +659,11 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
             opt.step()
             opt.zero_grad(set_to_none=True)
             return loss
+        l1_loss, ssim, depth_to_normal = (Dl.l1_loss, Dl.ssim, Dl.depth_to_normal) if launcher else (T.l1_loss, T.ssim, T.depth_to_normal)
         image = rendering[:3]
-        rgb_loss = (1.0 - lambda_dssim) * T.l1_loss(image, gt) + lambda_dssim * (1.0 - T.ssim(image, gt))   # train.py:156-161
+        rgb_loss = (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))       # train.py:156-161
         distortion_loss = rendering[8].mean()                                                # :164-167
-        depth_normal = T.depth_to_normal(view, rendering[6][None])[0].permute(2, 0, 1)       # :170-172
+        depth_normal = depth_to_normal(view, rendering[6][None])[0].permute(2, 0, 1)         # :170-172
         render_normal = torch.nn.functional.normalize(rendering[3:6], p=2, dim=0)            # :174-175
         c2w = (view.world_view_transform.T).inverse()                                        # :177
         world = (c2w[:3, :3] @ render_normal.reshape(3, -1)).reshape(3, H, W)                # :178-179
@@ -669,6 +674,20 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
         opt.zero_grad(set_to_none=True)                                                      # :265
         return loss
 
+    if only_launcher:          # (tests/devtools/dev_full_loop_trace.py launcher: a kernel trace of what the launcher runs by default)
+        Dl.enable(True)
+        try:
+            for _ in range(warmup):
+                iteration(False, True, True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                iteration(False, True, True)
+            torch.cuda.synchronize()
+        finally:
+            Dl.enable(False)
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        return {"ms_per_iter": round(ms, 4), "iters_per_s": round(1e3 / ms, 2), "steps": steps, "deferred_loss": dict(Dl.stats)}
     for _ in range(warmup):
         iteration()
     torch.cuda.synchronize()
@@ -687,7 +706,22 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
     for _ in range(steps):
         iteration(False, True)
     torch.cuda.synchronize()
-    ms_launcher = 1e3 * (time.perf_counter() - t0) / steps
+    ms_eager = 1e3 * (time.perf_counter() - t0) / steps
+    reset()
+    Dl.enable(True)
+    fused0 = Dl.stats["fused_backwards"]
+    try:
+        for _ in range(warmup):
+            iteration(False, True, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            iteration(False, True, True)
+        torch.cuda.synchronize()
+        ms_launcher = 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        Dl.enable(False)
+    fused_calls = Dl.stats["fused_backwards"] - fused0
     reset()
     for _ in range(warmup):
         iteration(True)
@@ -721,9 +755,14 @@ def full_loop(sd, dev, W, H, steps=10, warmup=3, only_inline=False):
                        "the camera pose is the launcher's PoseMatrix (train.py:177-179: inverse computed once, 3x3 block applied by one streaming launch)",
            "epilogue_kernels_ms": ep,
            "launcher_default": {"ms_per_iter": round(ms_launcher, 4), "iters_per_s": round(1e3 / ms_launcher, 2),
-                                "what": "the unchanged train.py as launch/run_reference_script.py runs it: the inline loss composition above, "
-                                        "GaussianModel.get_features rebound to the two stored SH tensors (SplitSH: no 192 B/Gaussian concatenation "
-                                        "and gradient split per iteration)"},
+                                "losses_evaluated_by_one_fused_call": "%d of %d" % (fused_calls, steps + warmup),
+                                "what": "the unchanged train.py as launch/run_reference_script.py runs it: the inline loss composition above with "
+                                        "the helper names bound to train_epilogue/deferred.py (the script's lines collect coefficients, "
+                                        "loss.backward() is one gof_train_loss call), GaussianModel.get_features rebound to the two stored SH "
+                                        "tensors (SplitSH: no 192 B/Gaussian concatenation and gradient split per iteration)"},
+           "launcher_eager_loss": {"ms_per_iter": round(ms_eager, 4), "iters_per_s": round(1e3 / ms_eager, 2),
+                                   "what": "the same with GOF_EAGER_LOSS=1: every helper eager (one HIP launch pair each, torch for the rest) -- the "
+                                           "launcher's default until round 6"},
            "one_call_loss": {"ms_per_iter": round(ms_one, 4), "iters_per_s": round(1e3 / ms_one, 2),
                              "what": "the same iteration with train.py:150-188 evaluated by train_epilogue.training_loss (gof_train_loss, "
                                      "five launches) instead of the inline torch composition; needs the 7-line train.py change of INTEGRATION.md"},

@@ -79,6 +79,7 @@ def _backward_with_mask_pool_redo(rs, args_of, fwd_args, geomBuffer, num_rendere
 import os as _os
 
 _SLAB_IMAGE = _os.environ.get("GOF_PLAIN_IMAGE", "0") != "1"
+_slice_hook = None          # train_epilogue/deferred.py: (slice, image, lo, hi, squeeze) -> what the script receives for a whole-channel slice
 
 
 class _GradSlab:
@@ -154,7 +155,8 @@ class RenderedImage(torch.Tensor):
             r = _channel_range(args[1], args[0].shape[0])
             if r is not None:
                 with torch._C.DisableTorchFunctionSubclass():
-                    return _ChannelSlice.apply(args[0].as_subclass(torch.Tensor), r[0], r[1], r[2], args[0]._gof_slab)
+                    out = _ChannelSlice.apply(args[0].as_subclass(torch.Tensor), r[0], r[1], r[2], args[0]._gof_slab)
+                return out if _slice_hook is None else _slice_hook(out, args[0], r[0], r[1], r[2])
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         return out.as_subclass(torch.Tensor) if isinstance(out, RenderedImage) else out

@@ -17,7 +17,9 @@ What it does, in this order (nothing in the reference checkout is edited):
      optimizer GaussianModel.training_setup builds (scene/gaussian_model.py:360 -> FusedAdam over the same param groups) and
      GaussianModel.compute_3D_filter (scene/gaussian_model.py:262-311, one launch over points x cameras) and
      GaussianModel.densify_and_prune (:685-707: device index lists + one row gather per tensor; GOF_TORCH_DENSIFY=1 keeps the reference's).
-     GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations; scene.cameras.Camera.world_view_transform becomes a
+     GOF_TORCH_EPILOGUE=1 keeps the reference's torch implementations; the loss train.py composes inline from these helpers
+     (train.py:150-189) is evaluated by ONE fused call at `loss.backward()` (train_epilogue/deferred.py; GOF_EAGER_LOSS=1 keeps the
+     helpers eager, one launch pair each); scene.cameras.Camera.world_view_transform becomes a
      train_epilogue.PoseMatrix (train.py:177-179: `.T.inverse()` computed once per camera, `c2w[:3, :3] @ normals` one streaming
      launch instead of a GEMM; GOF_PLAIN_POSE=1 keeps the plain tensor);
   5. wraps gaussian_renderer.integrate (imported by name at extract_mesh.py:5) so that the Gaussian side of the opacity-field
@@ -41,15 +43,20 @@ def rebind_train_epilogue():
     """Swap the reference's pure-torch loss helpers and optimizer for the HIP ones, by name, before the script's
     `from ... import` statements run.  Modules that are not importable (a script that does not train) are skipped."""
     import train_epilogue as T
+    from train_epilogue import deferred
+    # train.py:150-189 composes its loss inline from these helpers, the image's channel slices and the camera pose: with deferred
+    # evaluation on, the script's own lines collect coefficients and loss.backward() is ONE fused call (train_epilogue/deferred.py: any
+    # other spelling computes eagerly with the mirrors below); GOF_EAGER_LOSS=1 keeps every line eager
+    deferred.enable(os.environ.get("GOF_EAGER_LOSS") != "1")
     try:
         import utils.loss_utils as ref_loss
-        ref_loss.ssim = T.ssim
-        ref_loss.l1_loss = T.l1_loss
+        ref_loss.ssim = deferred.ssim                       # (eager: T.ssim)
+        ref_loss.l1_loss = deferred.l1_loss                 # (eager: T.l1_loss)
     except ImportError:
         pass
     try:
         import utils.depth_utils as ref_depth
-        ref_depth.depth_to_normal = T.depth_to_normal
+        ref_depth.depth_to_normal = deferred.depth_to_normal      # (eager: T.depth_to_normal)
         ref_depth.depths_to_points = T.depths_to_points
     except ImportError:
         pass
@@ -158,6 +165,10 @@ def main():
         def _dump_stats(path=os.environ["GOF_STATS_JSON"]):
             st = getattr(getattr(diff_gaussian_rasterization, "_C", None), "_stats", None)
             if st is not None:
+                st = dict(st)
+                d = sys.modules.get("train_epilogue.deferred")
+                if d is not None:                       # how many iterations' losses were one fused call / fell back to the eager mirrors
+                    st["deferred_loss"] = dict(d.stats)
                 with open(path, "w") as f:
                     json.dump(st, f)
         atexit.register(_dump_stats)

@@ -54,6 +54,8 @@ class SmallMatrix(_PlainResults):
         return r.as_subclass(SmallMatrix) if isinstance(r, torch.Tensor) and r.dim() == 2 else r
 
     def __matmul__(self, other):
+        if not isinstance(other, torch.Tensor) and hasattr(type(other), "_gof_rmatmul"):      # a deferred intermediate of train.py:175-178 (deferred.py)
+            return other._gof_rmatmul(self)
         m = _plain(self)
         if (isinstance(other, torch.Tensor) and m.dim() == 2 and tuple(m.shape) == (3, 3) and other.dim() == 2 and other.shape[0] == 3
                 and other.shape[1] >= _MIN_COLUMNS and m.device.type == "cuda" and other.device == m.device

@@ -9,6 +9,7 @@ launch/run_train_dp.py exactly as INTEGRATION.md tells a user to start them.
 
   * train.py, 1150 iterations on 24 views of 160x120: crosses densification (every 100 from 200), three opacity resets, the
     `oneupSHdegree` at 1000 and the late 3D-filter refresh, saves the model; the test PSNR must rise by > 6 dB and end above 24 dB.
+    The loss of every iteration was one fused call (the launcher's deferred evaluation of train.py:150-189, train_epilogue/deferred.py).
   * the same run with GOF_TORCH_EPILOGUE=1 (the reference's own torch loss / optimizer / filter code instead of the HIP training
     epilogue): same PSNR after the first 100 iterations (no densification yet) within 0.3 dB, same final PSNR within 1.5 dB.
   * render.py on the trained model (forward-only use): 4 test renderings whose PSNR against the written ground truths matches what
@@ -93,7 +94,7 @@ def _train(scene, model, **envextra):
 @pytest.fixture(scope="module")
 def trained(scene, tmp_path_factory):
     model = str(tmp_path_factory.mktemp("model_hip"))
-    out = _train(scene, model)
+    out = _train(scene, model, GOF_STATS_JSON=os.path.join(model, "binding_stats.json"))
     return model, out
 
 
@@ -122,6 +123,11 @@ def test_train_py_runs_unchanged_and_learns_the_scene(trained):
     for nme in names:
         assert np.isfinite(v[nme]).all(), nme
     assert n != 6000, "no densification / pruning took place"
+    # the loss train.py composes inline (train.py:150-189) was ONE fused call in every iteration (train_epilogue/deferred.py): none of
+    # the script's spellings fell back to the eager helpers
+    import json
+    st = json.load(open(os.path.join(model, "binding_stats.json")))["deferred_loss"]
+    assert st["fused_backwards"] == ITERS and st["eager_terms"] == 0 and st["eager_tensors"] == 0, st
 
 
 def test_hip_epilogue_and_the_references_torch_epilogue_train_alike(scene, trained, tmp_path_factory):

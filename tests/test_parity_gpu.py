@@ -1204,8 +1204,10 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "gaussian-opacity-fields_amd", "lib", "libgof_hip_audit.so")
     assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
-    names = ["s1m", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
-             "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01", "clustered150k", "posed_clustered150k"]
+    # (round 6: s1m_posed, posed_ragged, mid100k and clustered150k left the list -- each repeats a scene that is still in it under another
+    # camera, and the audit build walks every entry of every list: the four cost 40 s of the suite's 450)
+    names = ["s1m", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
+             "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01", "posed_clustered150k"]
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib, GOF_FW_EXACT="1"),      # (audit: the pairs the EXACT arithmetic accepts)
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]

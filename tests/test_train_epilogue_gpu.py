@@ -712,6 +712,82 @@ def test_end_to_end_training_iterations_reduce_the_loss(variant):
     assert means2D.grad is not None and (radii > 0).any() and (means2D.grad[:, 2] >= 0).all() and means2D.grad[:, 2].max() > 0
 
 
+@pytest.mark.parametrize("lambdas", [(0.2, 0.05, 100.0), (0.2, 0.0, 0.0)])
+def test_the_launchers_deferred_loss_is_the_one_call_loss_bit_for_bit(lambdas):
+    """launch/run_reference_script.py binds train.py's helper names to train_epilogue/deferred.py: the script's own lines
+    (train.py:151-189, spelled below as the script spells them) then launch nothing and `loss.backward()` is ONE gof_train_loss call.
+    Against the 7-line edit of INTEGRATION.md (training_loss(...).loss.backward()) on the same rendering: the gradients of every
+    rasterizer input are identical bits (the same kernels; the edit's extra multiplication by the upstream gradient 1.0 is exact), the
+    values agree to fp32 rounding (the script's python arithmetic on the read-back terms against the kernel's fp32 sum); against the
+    eager mirrors (GOF_EAGER_LOSS=1) they agree as test_training_loss_equals_the_composition_of_the_mirrors... holds them."""
+    import math
+    import train_epilogue as T
+    from train_epilogue import deferred as Dl
+    import synthetic_scenes as S
+    from gpu_common import to_dev, settings_from
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sd = to_dev(S.scene_frustum(20000, W=400, H=263, focal=300.0, seed=5, sigma_px=3.0))
+    W, H = sd["W"], sd["H"]
+    rast = GaussianRasterizer(settings_from(sd))
+    gt = torch.rand((3, H, W), generator=torch.Generator().manual_seed(3)).to(DEV)
+    view = types.SimpleNamespace(world_view_transform=T.PoseMatrix.wrap(sd["viewmatrix"]), image_width=W, image_height=H,
+                                 FoVx=2 * math.atan(sd["tanfovx"]), FoVy=2 * math.atan(sd["tanfovy"]))
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def render():
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        rendering, _ = rast(means2D=means2D, **leaves)
+        return rendering, dict(leaves, means2D=means2D)
+
+    def script_lines(rendering, gt_image, viewpoint_cam, l1_loss, ssim, depth_to_normal):
+        image = rendering[:3, :, :]
+        Ll1 = l1_loss(image, gt_image)
+        rgb_loss = (1.0 - lambdas[0]) * Ll1 + lambdas[0] * (1.0 - ssim(image, gt_image))
+        distortion_map = rendering[8, :, :]
+        distortion_loss = distortion_map.mean()
+        depth = rendering[6, :, :]
+        depth_normal, _ = depth_to_normal(viewpoint_cam, depth[None, ...])
+        depth_normal = depth_normal.permute(2, 0, 1)
+        render_normal = rendering[3:6, :, :]
+        render_normal = torch.nn.functional.normalize(render_normal, p=2, dim=0)
+        c2w = (viewpoint_cam.world_view_transform.T).inverse()
+        normal2 = c2w[:3, :3] @ render_normal.reshape(3, -1)
+        render_normal_world = normal2.reshape(3, *render_normal.shape[1:])
+        normal_error = 1 - (render_normal_world * depth_normal).sum(dim=0)
+        depth_normal_loss = normal_error.mean()
+        return rgb_loss + depth_normal_loss * lambdas[1] + distortion_loss * lambdas[2], Ll1
+
+    Dl.enable(True)
+    try:
+        before = dict(Dl.stats)
+        r, leaves_d = render()
+        loss_d, Ll1_d = script_lines(r, gt, view, Dl.l1_loss, Dl.ssim, Dl.depth_to_normal)
+        assert isinstance(loss_d, Dl.DeferredLoss) and Dl.stats == before              # nothing evaluated yet
+        loss_d.backward()
+        assert Dl.stats["fused_backwards"] == before["fused_backwards"] + 1 and Dl.stats["eager_terms"] == before["eager_terms"]
+        value_d, l1_d = loss_d.item(), Ll1_d.item()
+    finally:
+        Dl.enable(False)
+    r, leaves_f = render()
+    out = T.training_loss(r, gt, view, *lambdas)
+    out.loss.backward()
+    for k in leaves_d:
+        assert leaves_d[k].grad is not None and torch.equal(leaves_d[k].grad, leaves_f[k].grad), k
+    assert value_d == pytest.approx(out.loss.item(), rel=2e-6) and l1_d == pytest.approx(out.Ll1.item(), rel=1e-7)
+    r, leaves_e = render()
+    loss_e, _ = script_lines(r, gt, view, T.l1_loss, T.ssim, T.depth_to_normal)          # deferred evaluation off: the eager mirrors
+    assert type(loss_e) is torch.Tensor
+    loss_e.backward()
+    assert value_d == pytest.approx(loss_e.item(), rel=1e-5)
+    # (the two losses' gradients w.r.t. the IMAGE differ by fp32 rounding -- test_training_loss_equals_the_composition_of_the_mirrors...;
+    # the colour and opacity gradients carry that through unchanged, the geometric ones amplify it by the cancellation in the
+    # per-Gaussian backward that tests/test_reference_gpu.py measures: 5 % of the largest entry here, so they are not compared)
+    for k in ("shs", "opacities"):
+        a, b = leaves_d[k].grad, leaves_e[k].grad
+        assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-12, k
+
+
 def test_densify_and_prune_on_the_device_equals_the_references_own_method():
     """train_epilogue.densify_and_prune (ordered device index lists + one row gather per tensor) against the reference's
     GaussianModel.densify_and_prune executed on this GPU (staged copy, oracle/_ref/refpy): the same Gaussians in the same order --
