@@ -428,6 +428,9 @@ loss_final_kernel(const float* __restrict__ p_ssim, const float* __restrict__ p_
 
 // ---- Adam --------------------------------------------------------------------------------------------
 constexpr int ADAM_BLOCK_ELEMS = 4096;     // 256 threads x 4 float4
+#ifndef GOF_ADAM_NT
+#define GOF_ADAM_NT 1                      // nontemporal loads / stores in the vector body (adam_kernel below)
+#endif
 struct AdamArgs {
     GofAdamTensor t[GOF_ADAM_MAX_TENSORS];
     uint32_t block_end[GOF_ADAM_MAX_TENSORS];   // exclusive prefix of blocks per tensor
@@ -456,30 +459,51 @@ adam_kernel(AdamArgs a, float w1, float beta2, float w2, float eps)
     if (vec && start + ADAM_BLOCK_ELEMS <= t.n) {
         // all sixteen 16-byte loads of the thread first, then the arithmetic and the twelve stores: the four tensors come through
         // plain pointers of a struct (they may alias as far as the compiler knows), so a store of one iteration kept the loads of the
-        // next behind it -- 64 bytes per lane in flight instead of 256 (round 5: 5.0 -> see profiles/r05_*; same bits)
-        float4 p[4], g[4], m[4], v[4];
+        // next behind it -- 64 bytes per lane in flight instead of 256 (round 5: 5.0 -> see profiles/r05_*; same bits).
+        // Round 6: NONTEMPORAL loads and stores -- every byte is touched once per step and the four tensors together (0.94 GB at 1M
+        // Gaussians, 5.7 GB at 6M) are far beyond L2 + MALL: 9.91 GB in 1.817 -> 1.694 ms (5.46 -> 5.85 TB/s) at 6M x 59 floats,
+        // 1.65 GB in 0.2715 -> 0.2523 ms (6.09 -> 6.55 TB/s) at 1M x 59, interleaved with eight other forms of the loop (stores only:
+        // nothing; the gradient load only: half of it; 2 or 8 float4 per tensor and thread, persistent workgroups: nothing or worse --
+        // tests/devtools/microbench/adam_stream.hip, profiles/r06_adam_stream.txt).  GOF_ADAM_NT=2 keeps the parameter store cached.
+        typedef float v4f __attribute__((ext_vector_type(4)));
+#if GOF_ADAM_NT
+#define GOF_ADAM_LD(PTR) __builtin_nontemporal_load(reinterpret_cast<const v4f*>(PTR))
+#define GOF_ADAM_ST(PTR, X) __builtin_nontemporal_store(X, reinterpret_cast<v4f*>(PTR))
+#else
+#define GOF_ADAM_LD(PTR) (*reinterpret_cast<const v4f*>(PTR))
+#define GOF_ADAM_ST(PTR, X) (*reinterpret_cast<v4f*>(PTR) = (X))
+#endif
+        v4f p[4], g[4], m[4], v[4];
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const uint64_t i = start + (uint64_t)(it * 256 + threadIdx.x) * 4;
-            p[it] = *reinterpret_cast<const float4*>(t.param + i);
-            g[it] = *reinterpret_cast<const float4*>(t.grad + i);
-            m[it] = *reinterpret_cast<const float4*>(t.exp_avg + i);
-            v[it] = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
+            p[it] = GOF_ADAM_LD(t.param + i);
+            g[it] = GOF_ADAM_LD(t.grad + i);
+            m[it] = GOF_ADAM_LD(t.exp_avg + i);
+            v[it] = GOF_ADAM_LD(t.exp_avg_sq + i);
         }
 #pragma unroll
         for (int it = 0; it < 4; it++) {
-            adam_one(p[it].x, g[it].x, m[it].x, v[it].x, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            adam_one(p[it].y, g[it].y, m[it].y, v[it].y, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            adam_one(p[it].z, g[it].z, m[it].z, v[it].z, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
-            adam_one(p[it].w, g[it].w, m[it].w, v[it].w, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float pp = p[it][c], mm = m[it][c], vv = v[it][c];
+                adam_one(pp, g[it][c], mm, vv, w1, beta2, w2, t.step_size, t.bias_correction2_sqrt, eps);
+                p[it][c] = pp; m[it][c] = mm; v[it][c] = vv;
+            }
         }
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const uint64_t i = start + (uint64_t)(it * 256 + threadIdx.x) * 4;
-            *reinterpret_cast<float4*>(t.param + i) = p[it];
-            *reinterpret_cast<float4*>(t.exp_avg + i) = m[it];
-            *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v[it];
+#if GOF_ADAM_NT == 2
+            *reinterpret_cast<v4f*>(t.param + i) = p[it];
+#else
+            GOF_ADAM_ST(t.param + i, p[it]);
+#endif
+            GOF_ADAM_ST(t.exp_avg + i, m[it]);
+            GOF_ADAM_ST(t.exp_avg_sq + i, v[it]);
         }
+#undef GOF_ADAM_LD
+#undef GOF_ADAM_ST
     } else {
         for (uint64_t i = start + threadIdx.x; i < start + ADAM_BLOCK_ELEMS && i < t.n; i += 256) {
             float p = t.param[i], m = t.exp_avg[i], v = t.exp_avg_sq[i];

@@ -8,7 +8,9 @@ reference's UNCHANGED train.py (oracle/_ref/refpy, byte-identical staged copy) f
   * `product`    : this package's rasterizer, the reference's own torch loss / optimizer / densification (GOF_TORCH_EPILOGUE=1),
   * `reference`, `reference2` : the reference's CUDA kernels compiled for gfx950 (tests/reference_backend), same epilogue, twice (its
                    backward accumulates with atomicAdd: two runs of the same kernels differ -- that spread is the yardstick),
-  * `product_default` : the product as a user runs it (launcher defaults: HIP epilogue, fused Adam, device-side densification).
+  * `product_default` : the product as a user runs it (launcher defaults: HIP epilogue, fused Adam, device-side densification; since
+                   the second half of round 6 with the script's inline loss evaluated by one fused call per iteration),
+  * `product_default_eager_loss` : the same with GOF_EAGER_LOSS=1 (every loss helper eager: the defaults of the first half of round 6).
 Per run: test PSNR / L1 and the number of Gaussians at the marks, wall time and it/s of the training loop (tqdm-free: from the
 iteration timestamps train.py prints at the marks), and for the product runs the binding's counters over the WHOLE run
 (_backend._stats: frames redone because a learnt capacity / pool was too small, read-backs, shapes that inherited their pools).
@@ -39,8 +41,10 @@ def env_for(name, stats_path):
     env["PYTHONPATH"] = os.pathsep.join([SHIMS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
     env["GOF_E2E_SEED"] = "0"
     env["PYTHONUNBUFFERED"] = "1"                     # (the marks are time-stamped as train.py prints them)
-    if name != "product_default":
+    if not name.startswith("product_default"):
         env["GOF_TORCH_EPILOGUE"] = "1"
+    if name == "product_default_eager_loss":          # the launcher's defaults until the deferred loss (train_epilogue/deferred.py)
+        env["GOF_EAGER_LOSS"] = "1"
     if name.startswith("product"):
         env["GOF_STATS_JSON"] = stats_path
     return env

@@ -49,11 +49,17 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
     L = _load_launcher()
     L.rebind_train_epilogue()
     import train_epilogue as T
+    from train_epilogue import deferred as Dl
+    import diff_gaussian_rasterization as DGR
     try:
+        # the three loss helpers in their deferred form (train_epilogue/deferred.py: the script's inline loss becomes one fused call),
+        # switched on; GOF_EAGER_LOSS=1 leaves the same names bound but every call eager
+        assert Dl._ENABLED and DGR._slice_hook is Dl._on_slice
         # Camera.world_view_transform -> train_epilogue.PoseMatrix (train.py:177-179): the constructor is wrapped, its signature kept
         assert ref_cameras.Camera.__init__ is not orig["camera_init"]
         assert "world_view_transform" in inspect.getsource(orig["camera_init"])              # the attribute the wrapper replaces exists in the reference
-        assert ref_loss.l1_loss is T.l1_loss and ref_loss.ssim is T.ssim and ref_depth.depth_to_normal is T.depth_to_normal and ref_depth.depths_to_points is T.depths_to_points
+        assert ref_loss.l1_loss is Dl.l1_loss and ref_loss.ssim is Dl.ssim and ref_depth.depth_to_normal is Dl.depth_to_normal and ref_depth.depths_to_points is T.depths_to_points
+        assert Dl.impl["l1"] is T.l1_loss and Dl.impl["ssim"] is T.ssim and Dl.impl["depth_to_normal"] is T.depth_to_normal      # what they fall back to
         assert GaussianModel.compute_3D_filter is T.compute_3D_filter and GaussianModel.add_densification_stats is T.add_densification_stats
         assert GaussianModel.training_setup is not orig["setup"]
         for prop in ("get_scaling_with_3D_filter", "get_opacity_with_3D_filter", "get_rotation"):
@@ -70,9 +76,11 @@ def test_train_epilogue_rebinding_hits_existing_reference_names(reference_on_pat
         assert not SplitSH(torch.randn(5, 1, 3), torch.randn(5, 8, 3)).native()       # fewer stored bands: the rasterizer concatenates
         # same call signatures as the functions they replace
         for new, old in ((T.ssim, orig["ssim"]), (T.l1_loss, orig["l1"]), (T.depth_to_normal, orig["d2n"]), (T.depths_to_points, orig["d2p"]),
+                         (Dl.ssim, orig["ssim"]), (Dl.l1_loss, orig["l1"]), (Dl.depth_to_normal, orig["d2n"]),
                          (T.compute_3D_filter, orig["f3d"]), (T.add_densification_stats, orig["stats"])):
             assert list(inspect.signature(new).parameters) == list(inspect.signature(old).parameters), (new, old)
     finally:
+        Dl.enable(False)
         ref_cameras.Camera.__init__ = orig["camera_init"]
         ref_loss.ssim, ref_loss.l1_loss, ref_depth.depth_to_normal, ref_depth.depths_to_points = orig["ssim"], orig["l1"], orig["d2n"], orig["d2p"]
         GaussianModel.training_setup, GaussianModel.compute_3D_filter, GaussianModel.add_densification_stats = orig["setup"], orig["f3d"], orig["stats"]
