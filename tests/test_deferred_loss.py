@@ -178,9 +178,15 @@ def _deviations():
         assert math.isfinite(loss.item())            # a read-back BEFORE the backward: the eager composition
         return loss
 
+    def plain_pose(r, gt, view):
+        """GOF_PLAIN_POSE=1: the camera's pose is a plain tensor, `.T.inverse()` a fresh matrix nobody can vouch for"""
+        plain = types.SimpleNamespace(**dict(vars(view), world_view_transform=view.world_view_transform.as_subclass(torch.Tensor).clone()))
+        return _train_py_lines(r, gt, plain, 0.2, 0.05, 100.0)[0]
+
     def tensor_valued_ssim(r, gt, view):
         return _train_py_lines(r, gt, view, 0.2, 0.05, 100.0, ssim=lambda a, b: D.ssim(a, b) * torch.ones(()))[0]
-    return {"other_gt": other_gt, "tensor_factor": tensor_factor, "extra_term": extra_term, "value_first": value_first, "tensor_valued_ssim": tensor_valued_ssim}
+    return {"other_gt": other_gt, "tensor_factor": tensor_factor, "extra_term": extra_term, "value_first": value_first, "tensor_valued_ssim": tensor_valued_ssim,
+            "plain_pose": plain_pose}
 
 
 @pytest.mark.parametrize("name", sorted(_deviations()))
