@@ -132,7 +132,14 @@ def _dev_f32(t, device, what):
     return t.contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the current stream's handle without building a torch.cuda.Stream object
+
+
 def _stream():
+    """The caller's stream: every launch of a call goes to the CURRENT stream of the current device (ten lookups per training iteration:
+    torch.cuda.current_stream() costs 4-14 us each, the raw query a fraction of that)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
