@@ -112,26 +112,26 @@ def _expected(x, gt, view, *lambdas, **kw):
     return [float(t.detach()) for t in terms], xr.grad
 
 
-def _train_py_lines(rendering, gt_image, viewpoint_cam, lambda_dssim, lambda_depth_normal, lambda_distortion, l1_loss=D.l1_loss, ssim=D.ssim,
+def _train_py_lines(rendering, target, cam, lambda_dssim, lambda_depth_normal, lambda_distortion, l1_loss=D.l1_loss, ssim=D.ssim,
                     depth_to_normal=D.depth_to_normal):
     """the statements of train.py:151-188 as the script spells them (the helpers are what the launcher binds)"""
-    image = rendering[:3, :, :]
-    Ll1 = l1_loss(image, gt_image)
-    rgb_loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image))
-    distortion_map = rendering[8, :, :]
-    distortion_loss = distortion_map.mean()
-    depth = rendering[6, :, :]
-    depth_normal, _ = depth_to_normal(viewpoint_cam, depth[None, ...])
-    depth_normal = depth_normal.permute(2, 0, 1)
-    render_normal = rendering[3:6, :, :]
-    render_normal = torch.nn.functional.normalize(render_normal, p=2, dim=0)
-    c2w = (viewpoint_cam.world_view_transform.T).inverse()
-    normal2 = c2w[:3, :3] @ render_normal.reshape(3, -1)
-    render_normal_world = normal2.reshape(3, *render_normal.shape[1:])
-    normal_error = 1 - (render_normal_world * depth_normal).sum(dim=0)
-    depth_normal_loss = normal_error.mean()
-    loss = rgb_loss + depth_normal_loss * lambda_depth_normal + distortion_loss * lambda_distortion
-    return loss, Ll1
+    img = rendering[:3, :, :]
+    l1_term = l1_loss(img, target)
+    rgb_term = (1.0 - lambda_dssim) * l1_term + lambda_dssim * (1.0 - ssim(img, target))
+    dmap = rendering[8, :, :]
+    dist_term = dmap.mean()
+    zmap = rendering[6, :, :]
+    n_from_depth, _ = depth_to_normal(cam, zmap[None, ...])
+    n_from_depth = n_from_depth.permute(2, 0, 1)
+    n_img = rendering[3:6, :, :]
+    n_img = torch.nn.functional.normalize(n_img, p=2, dim=0)
+    pose_inv = (cam.world_view_transform.T).inverse()
+    n_flat = pose_inv[:3, :3] @ n_img.reshape(3, -1)
+    n_world = n_flat.reshape(3, *n_img.shape[1:])
+    n_err = 1 - (n_world * n_from_depth).sum(dim=0)
+    dn_term = n_err.mean()
+    loss = rgb_term + dn_term * lambda_depth_normal + dist_term * lambda_distortion
+    return loss, l1_term
 
 
 @pytest.mark.parametrize("lambdas", [(0.2, 0.05, 100.0), (0.2, 0.0, 0.0), (0.35, 0.05, 0.0)])

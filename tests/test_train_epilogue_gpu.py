@@ -740,23 +740,23 @@ def test_the_launchers_deferred_loss_is_the_one_call_loss_bit_for_bit(lambdas):
         rendering, _ = rast(means2D=means2D, **leaves)
         return rendering, dict(leaves, means2D=means2D)
 
-    def script_lines(rendering, gt_image, viewpoint_cam, l1_loss, ssim, depth_to_normal):
-        image = rendering[:3, :, :]
-        Ll1 = l1_loss(image, gt_image)
-        rgb_loss = (1.0 - lambdas[0]) * Ll1 + lambdas[0] * (1.0 - ssim(image, gt_image))
-        distortion_map = rendering[8, :, :]
-        distortion_loss = distortion_map.mean()
-        depth = rendering[6, :, :]
-        depth_normal, _ = depth_to_normal(viewpoint_cam, depth[None, ...])
-        depth_normal = depth_normal.permute(2, 0, 1)
-        render_normal = rendering[3:6, :, :]
-        render_normal = torch.nn.functional.normalize(render_normal, p=2, dim=0)
-        c2w = (viewpoint_cam.world_view_transform.T).inverse()
-        normal2 = c2w[:3, :3] @ render_normal.reshape(3, -1)
-        render_normal_world = normal2.reshape(3, *render_normal.shape[1:])
-        normal_error = 1 - (render_normal_world * depth_normal).sum(dim=0)
-        depth_normal_loss = normal_error.mean()
-        return rgb_loss + depth_normal_loss * lambdas[1] + distortion_loss * lambdas[2], Ll1
+    def script_lines(rendering, target, cam, l1_loss, ssim, depth_to_normal):
+        img = rendering[:3, :, :]
+        l1_term = l1_loss(img, target)
+        rgb_term = (1.0 - lambdas[0]) * l1_term + lambdas[0] * (1.0 - ssim(img, target))
+        dmap = rendering[8, :, :]
+        dist_term = dmap.mean()
+        zmap = rendering[6, :, :]
+        n_from_depth, _ = depth_to_normal(cam, zmap[None, ...])
+        n_from_depth = n_from_depth.permute(2, 0, 1)
+        n_img = rendering[3:6, :, :]
+        n_img = torch.nn.functional.normalize(n_img, p=2, dim=0)
+        pose_inv = (cam.world_view_transform.T).inverse()
+        n_flat = pose_inv[:3, :3] @ n_img.reshape(3, -1)
+        n_world = n_flat.reshape(3, *n_img.shape[1:])
+        n_err = 1 - (n_world * n_from_depth).sum(dim=0)
+        dn_term = n_err.mean()
+        return rgb_term + dn_term * lambdas[1] + dist_term * lambdas[2], l1_term
 
     Dl.enable(True)
     try:
