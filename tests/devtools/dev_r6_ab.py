@@ -27,6 +27,9 @@ ROUNDS = int(os.environ.get("AB_ROUNDS", "5"))
 
 
 def main():
+    if len(sys.argv) - 1 > 3:
+        print("WARNING: more than three libraries in one process -- one of them will run ~11 %% slow whatever its code (profiles/r06_ab_call9_scalar_prelude.txt); "
+              "do not read the row whose preprocess_fwd takes 0.06 ms", file=sys.stderr)
     variants = []
     for a in sys.argv[1:]:
         parts = a.split(":")
