@@ -17,11 +17,14 @@ keeps the eager mirrors) those hand back DEFERRED values:
                                 scale; ONE training_loss call (five launches) and its backward deliver d loss / d rendering to
                                 the rasterizer's backward; .item() afterwards reads the terms that call left
 
+    + / - a 0-dim tensor        carried along as it is (its own autograd graph): the decoupled-appearance L1 of train.py:158-159 -- the
+                                reference's TNT / DTU runs -- goes through a network and stays torch code; `0.8 * that + 0.2 * (1 - ssim)`
+                                keeps the rest deferred, and loss.backward() starts ONE pass from the fused gradient and from the tensor
+
 ANY other use of a deferred object -- an operator, torch function, attribute or argument pattern not listed above, a different
 ground-truth tensor for ssim than for l1_loss, a tensor-valued factor -- makes it compute itself EAGERLY with exactly the mirrors
 the launcher bound before this module existed (loss_utils.l1_loss / ssim, depth_utils.depth_to_normal, torch for the rest) and
-continue as the plain tensor: a script that composes its loss differently (the decoupled-appearance L1 of train.py:158-159, a
-fork's extra term) runs as before, only without the saving.  Values: training_loss's (tests: the trajectory and epilogue tests of
+continue as the plain tensor: a script that composes its loss differently runs as before, only without (that part of) the saving.  Values: training_loss's (tests: the trajectory and epilogue tests of
 tests/test_e2e_scripts_gpu.py and tests/test_train_epilogue_gpu.py hold it against the eager composition and the oracle)."""
 import numbers
 import operator
@@ -213,23 +216,35 @@ class DeferredTensor(_Deferred):
         return m @ self.eager()
 
 
-class DeferredLoss(_Deferred):
-    """sum_i coef[i] * term_i + const over the terms "l1", "ssim", "dn", "dist" of one frame (train.py:156-182)"""
-    def __init__(self, frame, coef, const):
-        self.frame, self.coef, self.const = frame, coef, const
+def _is_scalar_tensor(x):
+    return type(x) in (torch.Tensor, torch.nn.Parameter) and x.dim() == 0 and x.is_floating_point()
 
-    # ---- python-number arithmetic: coefficients only
+
+class DeferredLoss(_Deferred):
+    """sum_i coef[i] * term_i + const (+ extra) over the terms "l1", "ssim", "dn", "dist" of one frame (train.py:156-182).  `extra`: a 0-dim
+    TENSOR the script added -- the decoupled-appearance L1 of train.py:158-159, which goes through a network and stays torch code -- carried
+    along as it is (its own autograd graph): the deferred part is still one fused call, and the backward starts from both."""
+    def __init__(self, frame, coef, const, extra=None):
+        self.frame, self.coef, self.const, self.extra = frame, coef, const, extra
+
+    # ---- python-number arithmetic: coefficients only (a carried tensor term: 0-dim torch arithmetic)
     def _scaled(self, k):
-        return DeferredLoss(self.frame, {t: a * k for t, a in self.coef.items()}, self.const * k)
+        return DeferredLoss(self.frame, {t: a * k for t, a in self.coef.items()}, self.const * k, None if self.extra is None else self.extra * k)
 
     def _plus(self, other, sign):
         if _is_number(other):
-            return DeferredLoss(self.frame, dict(self.coef), self.const + sign * other)
+            return DeferredLoss(self.frame, dict(self.coef), self.const + sign * other, self.extra)
         if isinstance(other, DeferredLoss) and other.frame is self.frame:
             c = dict(self.coef)
             for t, a in other.coef.items():
                 c[t] = c.get(t, 0.0) + sign * a
-            return DeferredLoss(self.frame, c, self.const + sign * other.const)
+            extra = self.extra
+            if other.extra is not None:
+                extra = (other.extra if sign > 0 else -other.extra) if extra is None else (extra + other.extra if sign > 0 else extra - other.extra)
+            return DeferredLoss(self.frame, c, self.const + sign * other.const, extra)
+        if _is_scalar_tensor(other) and self.frame.image is not None and other.device == self.frame.image.device:
+            term = other if sign > 0 else -other
+            return DeferredLoss(self.frame, dict(self.coef), self.const, term if self.extra is None else self.extra + term)
         return NotImplemented
 
     def __add__(self, other):
@@ -245,8 +260,10 @@ class DeferredLoss(_Deferred):
         return self.tensor() - _materialize(other) if r is NotImplemented else r
 
     def __rsub__(self, other):
-        if _is_number(other):
-            return self._scaled(-1.0)._plus(other, 1.0)
+        if _is_number(other) or _is_scalar_tensor(other):
+            r = self._scaled(-1.0)._plus(other, 1.0)
+            if r is not NotImplemented:
+                return r
         if isinstance(other, DeferredLoss):
             return other.__sub__(self)
         return _materialize(other) - self.tensor()
@@ -263,6 +280,33 @@ class DeferredLoss(_Deferred):
     def __neg__(self):
         return self._scaled(-1.0)
 
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        """`tensor + deferred`, `tensor - deferred`, `torch.add(...)`: the tensor's own operator reaches this hook -- a 0-dim tensor term
+        is carried along (see `extra`); everything else computes the value"""
+        if not kwargs and len(args) == 2:
+            a, b = args
+            if func in _ADDS:
+                d, t = (a, b) if isinstance(a, DeferredLoss) else (b, a)
+                if isinstance(d, DeferredLoss) and (_is_scalar_tensor(t) or _is_number(t)):
+                    r = d._plus(t, 1.0)
+                    if r is not NotImplemented:
+                        return r
+            elif func in _SUBS:
+                if isinstance(a, DeferredLoss) and (_is_scalar_tensor(b) or _is_number(b)):
+                    r = a._plus(b, -1.0)
+                elif isinstance(b, DeferredLoss) and (_is_scalar_tensor(a) or _is_number(a)):
+                    r = b._scaled(-1.0)._plus(a, 1.0)
+                else:
+                    r = NotImplemented
+                if r is not NotImplemented:
+                    return r
+            elif func in _RSUBS and isinstance(b, DeferredLoss) and _is_scalar_tensor(a):       # Tensor.__rsub__(a, b) = b - a
+                r = b._plus(a, -1.0)
+                if r is not NotImplemented:
+                    return r
+        return func(*_materialize(args), **_materialize(kwargs or {}))
+
     # ---- evaluation
     def eager(self):
         """the combination as torch would have built it from the eager mirrors (differentiable)"""
@@ -272,6 +316,8 @@ class DeferredLoss(_Deferred):
         for t, a in self.coef.items():
             v = self.frame.eager_term(t) * a
             out = v if out is None else out + v
+        if self.extra is not None:
+            out = self.extra if out is None else out + self.extra
         return out + self.const if self.const != 0 or out is None else out
 
     def tensor(self):
@@ -283,7 +329,7 @@ class DeferredLoss(_Deferred):
         for t, a in self.coef.items():
             if a != 0:
                 out = out + f.terms[t].detach() * a
-        return out
+        return out if self.extra is None else out + self.extra.detach()
 
     def item(self):
         f = self.frame
@@ -298,7 +344,7 @@ class DeferredLoss(_Deferred):
                 f.terms_host = {"l1": v[1], "ssim": v[2], "dn": v[4], "dist": v[5]}
             else:
                 f.terms_host = dict(zip(names, torch.stack([f.terms[n].detach() for n in names]).tolist()))
-        return self.const + sum(a * f.terms_host[t] for t, a in self.coef.items() if a != 0)
+        return self.const + sum(a * f.terms_host[t] for t, a in self.coef.items() if a != 0) + (0.0 if self.extra is None else self.extra.item())
 
     def __float__(self):
         return float(self.item())
@@ -326,10 +372,18 @@ class DeferredLoss(_Deferred):
         f.image.__dict__.pop("_gof_frame", None)
         f._eager, f.dn_err, f.c2w33, f.image = {"consumed": True}, None, None, None
         stats["fused_backwards"] += 1
-        torch.autograd.backward(image, dL)
+        if self.extra is not None and self.extra.requires_grad:
+            torch.autograd.backward([image, self.extra], [dL, torch.ones_like(self.extra)])      # one pass over the graph: the rasterizer's backward runs once
+        else:
+            torch.autograd.backward(image, dL)
 
 
 # ---- what the image's channel slices become -------------------------------------------------------------------------------------
+_ADDS = (torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__)
+_SUBS = (torch.sub, torch.Tensor.sub, torch.Tensor.__sub__)
+_RSUBS = (torch.Tensor.__rsub__,)
+
+
 class RenderedChannels(torch.Tensor):
     """Whole channels [lo, hi) of a RenderedImage (diff_gaussian_rasterization): a plain tensor that remembers which, so that the
     three uses train.py makes of them -- rendering[8].mean(), depth[None, ...] on its way to depth_to_normal, F.normalize of

@@ -130,6 +130,25 @@ def test_train_py_runs_unchanged_and_learns_the_scene(trained):
     assert st["fused_backwards"] == ITERS and st["eager_terms"] == 0 and st["eager_tensors"] == 0, st
 
 
+def test_train_py_with_decoupled_appearance_keeps_the_rest_of_the_loss_fused(scene, tmp_path_factory):
+    """`--use_decoupled_appearance` (the reference's own TNT and DTU runs: scripts/run_tnt.py:26, run_dtu.py:21) replaces the L1 term by one
+    that goes through a network (train.py:67-88, 158-159) and stays torch code.  The launcher's deferred loss carries that tensor along:
+    every iteration is still ONE fused call for ssim / normal consistency / distortion, no helper falls back to its eager form, the network
+    and the embeddings train (FusedAdam steps their groups too) and the scene is learnt."""
+    import json
+    model = str(tmp_path_factory.mktemp("model_appearance"))
+    iters = 200
+    args = ["--iterations", str(iters), "--densify_from_iter", "100", "--densification_interval", "50", "--distortion_from_iter", "100",
+            "--depth_normal_from_iter", "100", "--test_iterations", "1", str(iters), "--save_iterations", str(iters), "--eval", "--use_decoupled_appearance"]
+    cmd = [sys.executable, os.path.join(PKG, "launch", "run_reference_script.py"), os.path.join(REFPY, "train.py"), "-s", scene, "-m", model] + args
+    out = _run(cmd, _env(GOF_STATS_JSON=os.path.join(model, "binding_stats.json")))
+    assert "Training complete." in out
+    ps = _psnr(out)
+    assert ps[iters] > ps[1] + 3.0, ps
+    st = json.load(open(os.path.join(model, "binding_stats.json")))["deferred_loss"]
+    assert st["fused_backwards"] == iters and st["eager_terms"] == 0 and st["eager_tensors"] == 0, st
+
+
 def test_hip_epilogue_and_the_references_torch_epilogue_train_alike(scene, trained, tmp_path_factory):
     _, out_hip = trained
     model = str(tmp_path_factory.mktemp("model_torch_epilogue"))
