@@ -982,13 +982,13 @@ def test_integrate_full_size_properties_config5():
 
 @QUERY_TIMEOUT
 def test_integrate_config5_gaussian_count_against_oracle():
-    """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 18M instances, tile lists of ~2700 entries) with a 5M-point subsample
+    """BASELINE config 5's Gaussian count (5M, sigma_px 1.5, 18M instances, tile lists of ~2700 entries) with a 2.5M-point subsample
     of its 45M query points, against the oracle on the GPU box's host cores: every output bit-identical.  (50 s of the suite: the
     oracle's pixel pass over 5M Gaussians; the full 45M-point shape is covered by test_integrate_full_size_properties_config5.)"""
     from diff_gaussian_rasterization import GaussianRasterizer
     sc = S.scene_frustum(5_000_000, seed=0, sigma_px=1.5)
-    pts = np.ascontiguousarray(S.tetra_points(sc)[::9], dtype=np.float32)
-    assert pts.shape[0] == 5_000_000
+    pts = np.ascontiguousarray(S.tetra_points(sc)[::18], dtype=np.float32)         # (round 6: 2.5M instead of 5M points -- the oracle's point pass is a sixth of this test's minute)
+    assert pts.shape[0] == 2_500_000
     o = ob.OracleScene(sc)
     oc, oal, ocol, orad = o.integrate(pts)
     sd = to_dev(sc)
