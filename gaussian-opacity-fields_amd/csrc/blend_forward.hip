@@ -53,7 +53,24 @@ constexpr int FW_CHUNK = GOF_FW_CHUNK;
 // (lane, entry) pairs, [2] phase-2 wave iterations, [3] exact-pass pairs, [4] contributing pairs, [5] lane-iterations active,
 // [6] (GOF_CULL_AUDIT) pairs the exact path accepts that the cull scan had dropped, [7] scanned wave-entries with a candidate in the wave
 __device__ unsigned long long g_fw_stats[8];
-#define STAT_ADD(i, v) atomicAdd(&g_fw_stats[i], (unsigned long long)(v))
+// one atomic per WAVE and statement: the sum over the lanes that execute it (an atomic per lane and contributing pair -- 5e8 atomics on a
+// handful of words at S1M -- made the audit build's full-size frame take tens of seconds of the GPU suite)
+__device__ __forceinline__ void stat_add_wave(unsigned long long* p, unsigned long long v, bool is_one)
+{
+    const unsigned long long active = __ballot(true);
+    unsigned long long total;
+    if (is_one) total = (unsigned long long)__popcll(active);
+    else {
+        total = 0;
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        for (unsigned long long m = active; m; m &= m - 1ull) {
+            const int l = __builtin_ctzll(m);
+            total += ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, l);
+        }
+    }
+    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(active)) atomicAdd(p, total);
+}
+#define STAT_ADD(i, v) stat_add_wave(&g_fw_stats[i], (unsigned long long)(v), __builtin_constant_p(v) && (v) == 1)
 #else
 #define STAT_ADD(i, v)
 #endif

@@ -45,7 +45,24 @@ namespace gof {
 // lane utilisation 0.45 -> 0.54 -- the rest is pixels that have finished while their wave has not); integrate_rays: [6]-[9] per RAY, [11] (audit
 // build) pairs accepted outside the scan's candidates, [12]-[14] trips by wave kind, [15] staged batches
 __device__ unsigned long long g_int_stats[16];
-#define ISTAT_ADD(i, v) atomicAdd(&g_int_stats[i], (unsigned long long)(v))
+// one atomic per WAVE and statement: the sum over the lanes that execute it (an atomic per lane and contributing pair -- 5e8 atomics on a
+// handful of words at S1M -- made the audit build's full-size frame take tens of seconds of the GPU suite)
+__device__ __forceinline__ void istat_add_wave(unsigned long long* p, unsigned long long v, bool is_one)
+{
+    const unsigned long long active = __ballot(true);
+    unsigned long long total;
+    if (is_one) total = (unsigned long long)__popcll(active);
+    else {
+        total = 0;
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        for (unsigned long long m = active; m; m &= m - 1ull) {
+            const int l = __builtin_ctzll(m);
+            total += ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, l);
+        }
+    }
+    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(active)) atomicAdd(p, total);
+}
+#define ISTAT_ADD(i, v) istat_add_wave(&g_int_stats[i], (unsigned long long)(v), __builtin_constant_p(v) && (v) == 1)
 #else
 #define ISTAT_ADD(i, v)
 #endif
