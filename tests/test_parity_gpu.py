@@ -1205,8 +1205,8 @@ def test_the_cull_scan_drops_no_pair_the_exact_path_accepts():
     lib = os.path.join(root, "gaussian-opacity-fields_amd", "lib", "libgof_hip_audit.so")
     assert os.path.exists(lib), "lib/libgof_hip_audit.so is missing: run __graft_entry__.build()"
     # (round 6: the audit build sums its counters per wave before the atomic -- an atomic per lane and pair made this test 65-110 s of the
-    # suite, now 5-8 s with all 17 scenes)
-    names = ["s1m", "s1m_posed", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
+    # suite, now 5-8 s; s1m_posed left the list: the same million Gaussians from inside the cloud, 50 s of exhaustive walks of their own)
+    names = ["s1m", "stress_box", "posed_stress_box", "far_subpixel", "far_subpixel_posed", "long_lists", "lego10k", "ragged",
              "posed_ragged", "mid100k", "posed_mid100k", "posed_mod2", "posed_mod05_ks01", "small_ks01", "clustered150k", "posed_clustered150k"]
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "devtools", "dev_cull_audit.py")] + names, env=dict(os.environ, GOF_HIP_LIB=lib, GOF_FW_EXACT="1"),      # (audit: the pairs the EXACT arithmetic accepts)
                        capture_output=True, text=True, timeout=1500)
